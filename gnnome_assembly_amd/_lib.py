@@ -1,0 +1,83 @@
+"""ctypes binding of libgnm.so (include/gnm.h).  The product path has NO fallback: if the
+library is missing or a symbol is absent this raises, it never routes around the HIP code."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnm.so")
+
+_lib = None
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int
+_f32 = C.c_float
+_sz = C.c_size_t
+_pi = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol include/gnm.h declares
+SIGNATURES = {
+    "gnm_abi_version": (_i32, []),
+    "gnm_last_error": (C.c_char_p, []),
+    "gnm_num_cus": (_i32, []),
+    "gnm_max_partial_blocks": (_i32, []),
+    "gnm_graph_build_index": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_gemm_f32_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64]),
+    "gnm_gemm_f32": (_i32, [_i32, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
+    "gnm_colsum_workspace_bytes": (_sz, [_i64, _i64]),
+    "gnm_colsum_f32": (_i32, [_i64, _i64, _p, _i64, _p, _p, _sz, _p]),
+    "gnm_gather_rows_f32": (_i32, [_i64, _i64, _p, _p, _p, _p]),
+    "gnm_relu_mask_f32": (_i32, [_i64, _p, _p, _p]),
+    "gnm_bn_finalize": (_i32, [_p, _i32, _i64, _i32, _p, _p, _f32, _p, _p]),
+    "gnm_bn_bwd_finalize": (_i32, [_p, _i32, _i64, _i32, _p, _p, _p, _p]),
+    "gnm_edge_t_stats_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_node_agg_src_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p]),
+    "gnm_node_bwd_stats": (_i32, [_i64, _i32, _p, _p, _p, _p, _pi, _p]),
+    "gnm_node_bwd_apply": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_edge_bwd_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_predictor_score_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_predictor_score_bwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_reduce_partials": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
+    "gnm_seg_sum_rows": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
+    "gnm_bce_fwd_bwd": (_i32, [_i64, _p, _p, _f32, _p, _p, _p, _sz, _p]),
+}
+
+
+class GnmError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libgnm.so and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnmError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GnmError(f"libgnm.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.gnm_abi_version()
+    if v != 1:
+        raise GnmError(f"libgnm.so ABI version {v}, expected 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().gnm_last_error().decode(errors="replace")
+        raise GnmError(f"{what or 'libgnm'} failed (rc={rc}): {msg}")

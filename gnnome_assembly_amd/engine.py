@@ -1,0 +1,439 @@
+"""Host-side orchestration of the HIP kernels (libgnm.so) for the GatedGCN edge-logit path.
+
+Everything here is plumbing: torch owns the memory and the stream, every arithmetic step is a
+C-ABI call (include/gnm.h).  There is no torch / CPU fallback: tensors must live on a HIP
+device and the library must load, otherwise the calls raise.
+
+Layout: all [E,*] tensors inside the layer stack are in the graph's internal (destination
+sorted) edge order; `model_forward` gathers e_raw into that order and scatters the scores
+back to the caller's edge-id order.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+NT, NN, TN = 0, 1, 2
+EPS_BN = 1e-5   # nn.BatchNorm1d default (gated_gcn_full.py:55-56)
+
+LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.GnmError("gnnome_assembly_amd: tensors must be on a HIP device (no CPU fallback)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.GnmError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Scratch:
+    """Per-device scratch buffers (torch-owned; the library never allocates)."""
+
+    def __init__(self, device):
+        lib = _lib.load()
+        self.device = device
+        self.max_blocks = lib.gnm_max_partial_blocks()
+        self.partials = torch.empty(self.max_blocks * 2 * 256, dtype=torch.float64, device=device)
+        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+
+    def ws(self, nbytes: int) -> torch.Tensor:
+        if self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+
+_scratch: Dict[torch.device, _Scratch] = {}
+
+
+def scratch(device) -> _Scratch:
+    device = torch.device(device)
+    if device not in _scratch:
+        _scratch[device] = _Scratch(device)
+    return _scratch[device]
+
+
+# ---------------------------------------------------------------------------------------
+# thin wrappers
+# ---------------------------------------------------------------------------------------
+
+def gemm(mode: int, A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, bias=None, resid=None, relu=False):
+    """C = op(A) op(B) (+bias +resid, relu).  A, B, C, resid are 2-D views with unit inner
+    stride; shapes follow include/gnm.h (NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N])."""
+    lib = _lib.load()
+    _chk_dev(A, B, C_, bias, resid)
+    for t in (A, B, C_, resid):
+        if t is not None and (t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32):
+            raise _lib.GnmError("gemm: operands must be 2-D float32 with unit inner stride")
+    if mode == NT:
+        M, K = A.shape
+        N, K2 = B.shape
+    elif mode == NN:
+        M, K = A.shape
+        K2, N = B.shape
+    else:
+        K, M = A.shape
+        K2, N = B.shape
+    if K != K2 or tuple(C_.shape) != (M, N):
+        raise _lib.GnmError(f"gemm: shape mismatch mode={mode} A={tuple(A.shape)} B={tuple(B.shape)} C={tuple(C_.shape)}")
+    need = lib.gnm_gemm_f32_workspace_bytes(mode, M, N, K)
+    ws = scratch(A.device).ws(need) if need else None
+    _lib.check(lib.gnm_gemm_f32(mode, M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_),
+                                C_.stride(0), _ptr(bias), _ptr(resid),
+                                resid.stride(0) if resid is not None else 0, int(bool(relu)),
+                                _ptr(ws), need, _stream()), "gnm_gemm_f32")
+    return C_
+
+
+def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _chk_dev(X)
+    M, W = X.shape
+    if out is None:
+        out = torch.empty(W, dtype=torch.float32, device=X.device)
+    need = lib.gnm_colsum_workspace_bytes(M, W)
+    ws = scratch(X.device).ws(need)
+    _lib.check(lib.gnm_colsum_f32(M, W, _ptr(X), X.stride(0), _ptr(out), _ptr(ws), need, _stream()),
+               "gnm_colsum_f32")
+    return out
+
+
+def bn_finalize(partials, nblk, count, H, gamma, beta):
+    lib = _lib.load()
+    stat = torch.empty(4, H, dtype=torch.float32, device=gamma.device)
+    _lib.check(lib.gnm_bn_finalize(_ptr(partials), nblk, count, H, _ptr(gamma), _ptr(beta), EPS_BN,
+                                   _ptr(stat), _stream()), "gnm_bn_finalize")
+    return stat
+
+
+def bn_bwd_finalize(partials, nblk, count, H, device):
+    lib = _lib.load()
+    bstat = torch.empty(2, H, dtype=torch.float32, device=device)
+    gg = torch.empty(H, dtype=torch.float32, device=device)
+    gb = torch.empty(H, dtype=torch.float32, device=device)
+    _lib.check(lib.gnm_bn_bwd_finalize(_ptr(partials), nblk, count, H, _ptr(bstat), _ptr(gg), _ptr(gb),
+                                       _stream()), "gnm_bn_bwd_finalize")
+    return bstat, gg, gb
+
+
+# ---------------------------------------------------------------------------------------
+# one GatedGCN layer
+# ---------------------------------------------------------------------------------------
+
+@dataclass
+class LayerParams:
+    """Views of one GatedGCN_1d's parameters (gated_gcn_full.py:44-59)."""
+    W5: torch.Tensor       # [5H,H] = cat(A_1,A_2,A_3,B_1,B_2).weight
+    b5: torch.Tensor       # [5H]
+    W3: torch.Tensor       # B_3.weight [H,H]
+    b3: torch.Tensor
+    gamma_e: torch.Tensor
+    beta_e: torch.Tensor
+    gamma_h: torch.Tensor
+    beta_h: torch.Tensor
+
+
+@dataclass
+class LayerSaved:
+    h_in: torch.Tensor = None
+    e_in: torch.Tensor = None
+    P: torch.Tensor = None
+    t: torch.Tensor = None
+    stat_e: torch.Tensor = None
+    e_out: torch.Tensor = None
+    hf: torch.Tensor = None
+    inv_f: torch.Tensor = None
+    hb: torch.Tensor = None
+    inv_b: torch.Tensor = None
+    z: torch.Tensor = None
+    stat_h: torch.Tensor = None
+
+
+def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool):
+    """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
+    Returns (h_out, e_out, LayerSaved or None)."""
+    lib = _lib.load()
+    dev = h_in.device
+    sc = scratch(dev)
+    st = _stream()
+    nblk = C.c_int(0)
+    f32 = dict(dtype=torch.float32, device=dev)
+    # dense projections                                                    (:107-113)
+    P = torch.empty(N, 5 * H, **f32)
+    gemm(NT, h_in, prm.W5, P, bias=prm.b5)
+    t = torch.empty(E, H, **f32)
+    gemm(NT, e_in, prm.W3, t, bias=prm.b3)
+    # t += B1h[src] + B2h[dst], BatchNorm statistics over all E edges       (:120-122)
+    _lib.check(lib.gnm_edge_t_stats_fwd(E, H, _ptr(t), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
+                                        _ptr(sc.partials), C.byref(nblk), st), "gnm_edge_t_stats_fwd")
+    stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
+    # gate, edge output, by-destination gated mean                         (:122-130)
+    e_out = torch.empty(E, H, **f32)
+    hf = torch.empty(N, H, **f32)
+    inv_f = torch.empty(N, H, **f32)
+    _lib.check(lib.gnm_edge_gate_fwd(N, E, H, _ptr(t), _ptr(e_in), _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
+                                     _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st),
+               "gnm_edge_gate_fwd")
+    # by-source gated mean on the same gate, z, BatchNorm statistics over N (:133-147)
+    hb = torch.empty(N, H, **f32)
+    inv_b = torch.empty(N, H, **f32)
+    z = torch.empty(N, H, **f32)
+    _lib.check(lib.gnm_node_agg_src_fwd(N, E, H, _ptr(e_out), _ptr(P), _ptr(idx["out_ptr"]),
+                                        _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(hf), _ptr(hb),
+                                        _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st),
+               "gnm_node_agg_src_fwd")
+    stat_h = bn_finalize(sc.partials, nblk.value, N, H, prm.gamma_h, prm.beta_h)
+    h_out = torch.empty(N, H, **f32)
+    _lib.check(lib.gnm_node_update_fwd(N, H, _ptr(z), _ptr(stat_h), _ptr(h_in), _ptr(h_out), st),
+               "gnm_node_update_fwd")
+    saved = None
+    if save:
+        saved = LayerSaved(h_in=h_in, e_in=e_in, P=P, t=t, stat_e=stat_e, e_out=e_out, hf=hf, inv_f=inv_f,
+                           hb=hb, inv_b=inv_b, z=z, stat_h=stat_h)
+    return h_out, e_out, saved
+
+
+def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge):
+    """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
+    and is OVERWRITTEN with d loss / d e_in.  Returns (gh_in, ge, grads dict)."""
+    lib = _lib.load()
+    dev = gh_out.device
+    sc = scratch(dev)
+    st = _stream()
+    nblk = C.c_int(0)
+    f32 = dict(dtype=torch.float32, device=dev)
+    g: Dict[str, torch.Tensor] = {}
+    # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
+    _lib.check(lib.gnm_node_bwd_stats(N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
+                                      C.byref(nblk), st), "gnm_node_bwd_stats")
+    bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
+    gP = torch.empty(N, 5 * H, **f32)
+    Q = torch.empty(N, 4 * H, **f32)
+    _lib.check(lib.gnm_node_bwd_apply(N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
+                                      _ptr(gh_out), _ptr(s.hf), _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b),
+                                      _ptr(gP), _ptr(Q), st), "gnm_node_bwd_apply")
+    # by-destination pass: ge <- ge + gsigma*sigma*(1-sigma), gA3h, BatchNorm_e backward statistics
+    Ud = torch.empty(N, H, **f32)
+    Td = torch.empty(N, H, **f32)
+    _lib.check(lib.gnm_edge_bwd_dst(N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
+                                    _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud),
+                                    _ptr(Td), _ptr(sc.partials), C.byref(nblk), st), "gnm_edge_bwd_dst")
+    bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
+    # by-source pass: gA2h, gB1h, gB2h
+    _lib.check(lib.gnm_edge_bwd_src(N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+                                    _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]),
+                                    _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
+                                    _ptr(Ud), _ptr(Td), _ptr(gP), st), "gnm_edge_bwd_src")
+    del Ud, Td, Q
+    # gt, B_3 gradients, ge_in = ge_tot + gt W3
+    gt = torch.empty(E, H, **f32)
+    _lib.check(lib.gnm_edge_bwd_gt(E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+                                   _ptr(prm.gamma_e), _ptr(gt), st), "gnm_edge_bwd_gt")
+    g["W3"] = torch.empty(H, H, **f32)
+    gemm(TN, gt, s.e_in, g["W3"])
+    g["b3"] = colsum(gt)
+    gemm(NN, gt, prm.W3, ge, resid=ge)
+    del gt
+    # node projections backward
+    g["W5"] = torch.empty(5 * H, H, **f32)
+    gemm(TN, gP, s.h_in, g["W5"])
+    g["b5"] = colsum(gP)
+    gh_in = torch.empty(N, H, **f32)
+    gemm(NN, gP, prm.W5, gh_in, resid=gh_out)
+    return gh_in, ge, g
+
+
+# ---------------------------------------------------------------------------------------
+# predictor (score_predictor.py:12-25), split-W1 form
+# ---------------------------------------------------------------------------------------
+
+@dataclass
+class PredSaved:
+    x: torch.Tensor = None
+    e: torch.Tensor = None
+    hid: torch.Tensor = None     # pre-activation [E,HS]; overwritten by its gradient in backward
+    W1sd: torch.Tensor = None
+
+
+def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
+    """scores (caller edge-id order, [E,1]) from internal-order x [N,H], e [E,H]."""
+    lib = _lib.load()
+    dev = x.device
+    HS = W1.shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    W1sd = torch.cat((W1[:, :H], W1[:, H:2 * H]), 0).contiguous()     # [2HS, H]
+    Pn = torch.empty(N, 2 * HS, **f32)
+    gemm(NT, x, W1sd, Pn)
+    hid = torch.empty(E, HS, **f32)
+    gemm(NT, e, W1[:, 2 * H:], hid, bias=b1)
+    scores = torch.empty(E, 1, **f32)
+    _lib.check(lib.gnm_predictor_score_fwd(E, HS, _ptr(hid), _ptr(Pn), _ptr(idx["isrc"]), _ptr(idx["idst"]),
+                                           _ptr(W2), _ptr(b2), _ptr(idx["perm"]), _ptr(scores), _stream()),
+               "gnm_predictor_score_fwd")
+    saved = PredSaved(x=x, e=e, hid=hid, W1sd=W1sd) if save else None
+    return scores, saved
+
+
+def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores):
+    """Returns (gx [N,H], ge [E,H] fresh buffer, grads dict W1,b1,W2,b2)."""
+    lib = _lib.load()
+    dev = s.x.device
+    sc = scratch(dev)
+    HS = W1.shape[0]
+    st = _stream()
+    nblk = C.c_int(0)
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = {}
+    gscores = _f32c(gscores.reshape(-1))
+    ghid = s.hid   # in place
+    _lib.check(lib.gnm_predictor_score_bwd(E, HS, _ptr(ghid), _ptr(gscores), _ptr(W2), _ptr(idx["perm"]),
+                                           _ptr(sc.partials), C.byref(nblk), st), "gnm_predictor_score_bwd")
+    red = torch.empty(2, HS, **f32)
+    _lib.check(lib.gnm_reduce_partials(_ptr(sc.partials), nblk.value, 2, HS, _ptr(red), st), "gnm_reduce_partials")
+    g["W2"] = red[0:1].clone()
+    g["b2"] = red[1, 0:1].clone()
+    g["b1"] = colsum(ghid)
+    gPn = torch.empty(N, 2 * HS, **f32)
+    _lib.check(lib.gnm_seg_sum_rows(N, HS, _ptr(ghid), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]),
+                                    _ptr(gPn), 2 * HS, st), "gnm_seg_sum_rows(src)")
+    _lib.check(lib.gnm_seg_sum_rows(N, HS, _ptr(ghid), _ptr(idx["in_ptr"]), C.c_void_p(0),
+                                    _ptr(gPn[:, HS:]), 2 * HS, st), "gnm_seg_sum_rows(dst)")
+    gW1 = torch.empty(HS, 3 * H, **f32)
+    gemm(TN, gPn[:, :HS], s.x, gW1[:, :H])
+    gemm(TN, gPn[:, HS:], s.x, gW1[:, H:2 * H])
+    gemm(TN, ghid, s.e, gW1[:, 2 * H:])
+    g["W1"] = gW1
+    gx = torch.empty(N, H, **f32)
+    gemm(NN, gPn, s.W1sd, gx)
+    ge = torch.empty(E, H, **f32)
+    gemm(NN, ghid, W1[:, 2 * H:], ge)
+    return gx, ge, g
+
+
+# ---------------------------------------------------------------------------------------
+# whole model (full_graph.py:22-29)
+# ---------------------------------------------------------------------------------------
+
+@dataclass
+class ModelSaved:
+    pe: torch.Tensor = None
+    e_int: torch.Tensor = None
+    a1: torch.Tensor = None
+    layers: List[LayerSaved] = field(default_factory=list)
+    pred: PredSaved = None
+
+
+def layer_params(P: Dict[str, torch.Tensor], i: int) -> LayerParams:
+    p = f"gnn.convs.{i}."
+    return LayerParams(
+        W5=torch.cat([P[p + k + ".weight"] for k in LIN5], 0),
+        b5=torch.cat([P[p + k + ".bias"] for k in LIN5], 0),
+        W3=P[p + "B_3.weight"], b3=P[p + "B_3.bias"],
+        gamma_e=P[p + "bn_e.weight"], beta_e=P[p + "bn_e.bias"],
+        gamma_h=P[p + "bn_h.weight"], beta_h=P[p + "bn_h.bias"])
+
+
+def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int, save: bool):
+    """GraphGatedGCNModel.forward.  e_raw [E,edge_features] in edge-id order, pe [N,nb_pos_enc+2].
+    Returns (scores [E,1] in edge-id order, ModelSaved or None)."""
+    lib = _lib.load()
+    dev = pe.device
+    _chk_dev(e_raw, pe)
+    idx = graph.index(dev)
+    N, E = graph.num_nodes(), graph.num_edges()
+    H = P["linear_pe.weight"].shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    pe = _f32c(pe)
+    e_raw = _f32c(e_raw)
+    # encoders                                                            (full_graph.py:23-26)
+    h = torch.empty(N, H, **f32)
+    gemm(NT, pe, P["linear_pe.weight"], h, bias=P["linear_pe.bias"])
+    e_int = torch.empty(E, e_raw.shape[1], **f32)
+    _lib.check(lib.gnm_gather_rows_f32(E, e_raw.shape[1], _ptr(e_raw), _ptr(idx["perm"]), _ptr(e_int),
+                                       _stream()), "gnm_gather_rows_f32")
+    a1 = torch.empty(E, P["linear1_edge.weight"].shape[0], **f32)
+    gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
+    e = torch.empty(E, H, **f32)
+    gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
+    ms = ModelSaved(pe=pe, e_int=e_int, a1=a1) if save else None
+    for i in range(num_layers):
+        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save)
+        if save:
+            ms.layers.append(ls)
+    scores, ps = predictor_forward(idx, N, E, H, P["predictor.W1.weight"], P["predictor.W1.bias"],
+                                   P["predictor.W2.weight"], P["predictor.W2.bias"], h, e, save)
+    if save:
+        ms.pred = ps
+    return scores, ms
+
+
+def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores):
+    """Gradients of every parameter (keys = state_dict keys) from d loss / d scores."""
+    dev = ms.pe.device
+    idx = graph.index(dev)
+    N, E = graph.num_nodes(), graph.num_edges()
+    H = P["linear_pe.weight"].shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    G: Dict[str, torch.Tensor] = {}
+    gh, ge, gp = predictor_backward(idx, N, E, H, P["predictor.W1.weight"], P["predictor.W2.weight"],
+                                    ms.pred, gscores)
+    G["predictor.W1.weight"], G["predictor.W1.bias"] = gp["W1"], gp["b1"]
+    G["predictor.W2.weight"], G["predictor.W2.bias"] = gp["W2"], gp["b2"]
+    ms.pred = None
+    for i in reversed(range(num_layers)):
+        p = f"gnn.convs.{i}."
+        gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge)
+        ms.layers[i] = None     # release this layer's activations
+        for j, k in enumerate(LIN5):
+            G[p + k + ".weight"] = gl["W5"][j * H:(j + 1) * H]
+            G[p + k + ".bias"] = gl["b5"][j * H:(j + 1) * H]
+        G[p + "B_3.weight"], G[p + "B_3.bias"] = gl["W3"], gl["b3"]
+        G[p + "bn_e.weight"], G[p + "bn_e.bias"] = gl["gamma_e"], gl["beta_e"]
+        G[p + "bn_h.weight"], G[p + "bn_h.bias"] = gl["gamma_h"], gl["beta_h"]
+    # encoders backward
+    lib = _lib.load()
+    G["linear_pe.weight"] = torch.empty_like(P["linear_pe.weight"])
+    gemm(TN, gh, ms.pe, G["linear_pe.weight"])
+    G["linear_pe.bias"] = colsum(gh)
+    G["linear2_edge.weight"] = torch.empty_like(P["linear2_edge.weight"])
+    gemm(TN, ge, ms.a1, G["linear2_edge.weight"])
+    G["linear2_edge.bias"] = colsum(ge)
+    ga1 = torch.empty_like(ms.a1)
+    gemm(NN, ge, P["linear2_edge.weight"], ga1)
+    _lib.check(lib.gnm_relu_mask_f32(ga1.numel(), _ptr(ga1), _ptr(ms.a1), _stream()), "gnm_relu_mask_f32")
+    G["linear1_edge.weight"] = torch.empty_like(P["linear1_edge.weight"])
+    gemm(TN, ga1, ms.e_int, G["linear1_edge.weight"])
+    G["linear1_edge.bias"] = colsum(ga1)
+    return G
+
+
+def bce_with_logits(scores, y, pos_weight: float):
+    """(loss [1], dloss/dscores [E,1]) -- train.py:210-211,253-255, fused in one pass."""
+    lib = _lib.load()
+    _chk_dev(scores, y)
+    x = _f32c(scores.reshape(-1))
+    y = _f32c(y.reshape(-1))
+    E = x.numel()
+    sc = scratch(x.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    gs = torch.empty(E, 1, dtype=torch.float32, device=x.device)
+    _lib.check(lib.gnm_bce_fwd_bwd(E, _ptr(x), _ptr(y), float(pos_weight), _ptr(loss), _ptr(gs),
+                                   _ptr(sc.partials), sc.partials.numel() * 8, _stream()), "gnm_bce_fwd_bwd")
+    return loss, gs

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's `layers` package (layers/__init__.py:1-5): same class
+names, constructor arguments, forward() signatures and state_dict keys; the arithmetic runs in
+libgnm.so (HIP, gfx950).  Per-edge tensors at these module boundaries are in the caller's
+edge-id order, as with DGL."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import engine
+
+__all__ = ["GatedGCN_1d", "GraphGatedGCN", "ScorePredictor", "NodeEncoder", "EdgeEncoder"]
+
+
+def _params_of(module: nn.Module, prefix: str = ""):
+    return {prefix + k: v for k, v in module.named_parameters()}
+
+
+class _LayerFn(torch.autograd.Function):
+    """One GatedGCN_1d.forward with edge-id-order e at the boundary."""
+
+    @staticmethod
+    def forward(ctx, graph, h, e, *flat):
+        names = _LAYER_KEYS
+        P = {"gnn.convs.0." + k: v for k, v in zip(names, flat)}
+        idx = graph.index(h.device)
+        N, E, H = graph.num_nodes(), graph.num_edges(), h.shape[1]
+        perm = idx["perm"].long()
+        e_int = e.detach().index_select(0, perm).contiguous()
+        need = any(t.requires_grad for t in (h, e) + tuple(flat))
+        prm = engine.layer_params(P, 0)
+        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h.detach().contiguous(), e_int, need)
+        ctx.graph, ctx.saved, ctx.P, ctx.dims = graph, saved, P, (N, E, H)
+        out_e = torch.empty_like(e_out)
+        out_e.index_copy_(0, perm, e_out)
+        return h_out, out_e
+
+    @staticmethod
+    def backward(ctx, gh_out, ge_out):
+        N, E, H = ctx.dims
+        idx = ctx.graph.index(gh_out.device)
+        perm = idx["perm"].long()
+        prm = engine.layer_params(ctx.P, 0)
+        ge = ge_out.index_select(0, perm).contiguous()        # fresh buffer, overwritten below
+        gh_in, ge_in, g = engine.layer_backward(idx, N, E, H, prm, ctx.saved, gh_out.contiguous(), ge)
+        ctx.saved = None
+        ge_user = torch.empty_like(ge_in)
+        ge_user.index_copy_(0, perm, ge_in)
+        grads = []
+        for j, k in enumerate(engine.LIN5):
+            grads += [g["W5"][j * H:(j + 1) * H], g["b5"][j * H:(j + 1) * H]]
+        grads += [g["W3"], g["b3"], g["gamma_h"], g["beta_h"], g["gamma_e"], g["beta_e"]]
+        return (None, gh_in, ge_user) + tuple(grads)
+
+
+_LAYER_KEYS = tuple(f"{k}.{w}" for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3") for w in ("weight", "bias")) + \
+    ("bn_h.weight", "bn_h.bias", "bn_e.weight", "bn_e.bias")
+
+
+class _Norm(nn.Module):
+    """Parameter holder with BatchNorm1d(track_running_stats=False)'s state_dict (weight, bias;
+    no running buffers: gated_gcn_full.py:55-56)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+        self.eps = 1e-5
+
+
+class GatedGCN_1d(nn.Module):
+    """gated_gcn_full.py:8-157.  forward(g, h, e) -> (h, e)."""
+
+    def __init__(self, in_channels, out_channels, batch_norm, dropout=0, residual=True):
+        super().__init__()
+        if in_channels != out_channels:
+            # the reference silently drops the residual (gated_gcn_full.py:41-42); the model never
+            # builds such a layer (processor.py:11-12) and the HIP path does not implement it.
+            raise NotImplementedError("GatedGCN_1d: in_channels != out_channels is outside the hot path")
+        if not batch_norm:
+            raise NotImplementedError(
+                "GatedGCN_1d(batch_norm=False) (LayerNorm, gated_gcn_full.py:57-59) is not built yet; "
+                "every BASELINE config uses batch_norm=True")
+        if dropout != 0:
+            raise NotImplementedError("dropout != 0 is never used by the reference (processor.py:12)")
+        self.dropout = dropout
+        self.batch_norm = batch_norm
+        self.residual = residual
+        for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3"):     # creation order = the reference's
+            setattr(self, k, nn.Linear(in_channels, out_channels))
+        self.bn_h = _Norm(out_channels)
+        self.bn_e = _Norm(out_channels)
+
+    def forward(self, g, h, e):
+        P = dict(self.named_parameters())
+        return _LayerFn.apply(g, h, e, *[P[k] for k in _LAYER_KEYS])
+
+
+class GraphGatedGCN(nn.Module):
+    """processor.py:8-20.  forward(graph, h, e) -> (h, e)."""
+
+    def __init__(self, num_layers, hidden_features, batch_norm):
+        super().__init__()
+        self.convs = nn.ModuleList([
+            GatedGCN_1d(hidden_features, hidden_features, batch_norm) for _ in range(num_layers)
+        ])
+
+    def forward(self, graph, h, e):
+        for conv in self.convs:
+            h, e = conv(graph, h, e)
+        return h, e
+
+
+class _PredFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, x, e, W1, b1, W2, b2):
+        idx = graph.index(x.device)
+        N, E, H = graph.num_nodes(), graph.num_edges(), x.shape[1]
+        perm = idx["perm"].long()
+        e_int = e.detach().index_select(0, perm).contiguous()
+        need = any(t.requires_grad for t in (x, e, W1, b1, W2, b2))
+        scores, saved = engine.predictor_forward(idx, N, E, H, W1.detach(), b1.detach(), W2.detach(), b2.detach(),
+                                                 x.detach().contiguous(), e_int, need)
+        ctx.graph, ctx.saved, ctx.dims = graph, saved, (N, E, H)
+        ctx.W1, ctx.W2 = W1.detach(), W2.detach()
+        return scores
+
+    @staticmethod
+    def backward(ctx, gscores):
+        N, E, H = ctx.dims
+        idx = ctx.graph.index(gscores.device)
+        perm = idx["perm"].long()
+        gx, ge, g = engine.predictor_backward(idx, N, E, H, ctx.W1, ctx.W2, ctx.saved, gscores)
+        ctx.saved = None
+        ge_user = torch.empty_like(ge)
+        ge_user.index_copy_(0, perm, ge)
+        return None, gx, ge_user, g["W1"], g["b1"], g["W2"], g["b2"]
+
+
+class ScorePredictor(nn.Module):
+    """score_predictor.py:5-25.  forward(graph, x, e) -> [E,1] in edge-id order."""
+
+    def __init__(self, in_features, hidden_edge_scores):
+        super().__init__()
+        self.W1 = nn.Linear(3 * in_features, hidden_edge_scores)
+        self.W2 = nn.Linear(hidden_edge_scores, 1)
+
+    def forward(self, graph, x, e):
+        return _PredFn.apply(graph, x, e, self.W1.weight, self.W1.bias, self.W2.weight, self.W2.bias)
+
+
+class NodeEncoder(nn.Module):
+    """node_encoder.py:4-28 (unused by the model: full_graph.py:14); importable for parity."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_channels, out_channels, bias=bias)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+class EdgeEncoder(nn.Module):
+    """edge_encoder.py:4-28 (unused by the model: full_graph.py:16); importable for parity."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_channels, out_channels, bias=bias)
+
+    def forward(self, x):
+        return self.linear(x)

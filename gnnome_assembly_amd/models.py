@@ -1,0 +1,75 @@
+"""Host-side mirror of the reference's `models` package (models/full_graph.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import engine, layers
+
+__all__ = ["GraphGatedGCNModel", "BCEWithLogitsLoss"]
+
+
+class _ModelFn(torch.autograd.Function):
+    """Whole-model forward/backward: the edge stream stays in internal order from the encoder
+    to the predictor, activations are released layer by layer in backward."""
+
+    @staticmethod
+    def forward(ctx, graph, e, pe, num_layers, names, *flat):
+        P = {k: v.detach() for k, v in zip(names, flat)}
+        need = torch.is_grad_enabled() and any(t.requires_grad for t in flat)
+        scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need)
+        ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L = graph, saved, P, names, num_layers
+        return scores
+
+    @staticmethod
+    def backward(ctx, gscores):
+        if ctx.saved is None:
+            raise RuntimeError("GraphGatedGCNModel: backward called twice or forward ran without grad")
+        G = engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores)
+        ctx.saved = None
+        return (None, None, None, None, None) + tuple(G[k] for k in ctx.names)
+
+
+class GraphGatedGCNModel(nn.Module):
+    """models/full_graph.py:11-29.  forward(graph, x, e, pe) -> scores [E,1] (edge-id order).
+
+    `graph` is an AssemblyGraph (or anything AssemblyGraph-compatible on a HIP device); `x` is
+    ignored exactly as in the reference (full_graph.py:23 overwrites it)."""
+
+    def __init__(self, node_features, edge_features, hidden_features, hidden_edge_features, num_layers,
+                 hidden_edge_scores, batch_norm, nb_pos_enc):
+        super().__init__()
+        self.linear_pe = nn.Linear(nb_pos_enc + 2, hidden_features)
+        self.linear1_edge = nn.Linear(edge_features, hidden_edge_features)
+        self.linear2_edge = nn.Linear(hidden_edge_features, hidden_features)
+        self.gnn = layers.GraphGatedGCN(num_layers, hidden_features, batch_norm)
+        self.predictor = layers.ScorePredictor(hidden_features, hidden_edge_scores)
+        self.num_layers = num_layers
+
+    def forward(self, graph, x, e, pe):
+        names, flat = zip(*self.named_parameters())
+        return _ModelFn.apply(graph, e, pe, self.num_layers, names, *flat)
+
+
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, y, pos_weight):
+        loss, gs = engine.bce_with_logits(scores.detach(), y, pos_weight)
+        ctx.gs = gs.reshape(scores.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        return ctx.gs * gl, None, None
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """torch.nn.BCEWithLogitsLoss(pos_weight=[pw]) with mean reduction as train.py:210-211 uses
+    it, as one fused HIP pass that also produces d loss / d logits."""
+
+    def __init__(self, pos_weight):
+        super().__init__()
+        self.pos_weight = float(pos_weight.reshape(-1)[0]) if torch.is_tensor(pos_weight) else float(pos_weight)
+
+    def forward(self, scores, y):
+        return _BCEFn.apply(scores, y, self.pos_weight)

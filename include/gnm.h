@@ -1,0 +1,168 @@
+/*
+ * gnm.h -- C ABI of libgnm.so, the MI355X (gfx950) GatedGCN edge-logit engine.
+ *
+ * The reference (lvrcek/GNNome-assembly) has no FFI of its own: its hot path is ~120
+ * lines of Python that call torch and DGL (un-vendored).  Each entry point below replaces
+ * one group of those implicit kernels; the reference call site is cited per function
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the function says "host";
+ *  - all float tensors are fp32, row-major, contiguous unless an explicit leading
+ *    dimension (ld*, in elements) is given; all indices are int32;
+ *  - the library never allocates, frees or keeps a pointer across calls; scratch space
+ *    is a caller-provided workspace (gnm_*_workspace_bytes tells how much);
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*), no internal
+ *    synchronisation, re-entrant;
+ *  - return value: 0 ok, <0 invalid argument, >0 a hipError_t; gnm_last_error() returns a
+ *    thread-local message for the last non-zero return.
+ *  - "internal edge order" = edges stably sorted by destination (gnm_graph_build_index);
+ *    all [E,*] tensors inside the layer stack are in that order, the model boundary
+ *    (e_raw in, scores out, labels) is in the caller's edge-id order.
+ *  - H (hidden width) must be one of 32, 64, 128, 256.
+ */
+#ifndef GNM_H
+#define GNM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNM_ABI_VERSION 1
+
+/* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
+#define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
+#define GNM_GEMM_NN 1 /* A[M,K] row-major, B[K,N] row-major  : gx = gy W    (nn.Linear input grad) */
+#define GNM_GEMM_TN 2 /* A[K,M] row-major, B[K,N] row-major  : gW = gy^T x  (nn.Linear weight grad)*/
+
+int gnm_abi_version(void);
+const char* gnm_last_error(void);
+/* number of compute units of the current device (grid sizing / partial-buffer sizing) */
+int gnm_num_cus(void);
+/* upper bound on the number of per-block partial rows any kernel writes (see *_partials) */
+int gnm_max_partial_blocks(void);
+
+/* ---- graph index (HOST pointers; replaces DGL's lazy CSR/CSC build + dgl.reverse,
+ *      layers/gated_gcn_full.py:115, graph_parser.py:297 edge-id order) -------------------
+ * perm[j]    = caller edge id stored at internal position j (stable sort by dst)
+ * isrc/idst  = endpoints in internal order; in_ptr[N+1] = CSC row pointer over internal order
+ * out_ptr[N+1], out_pos[E], out_dst[E]: out-edges grouped by source (ascending internal
+ *              position inside a source): internal position and destination of each. */
+int gnm_graph_build_index(const int32_t* src, const int32_t* dst, int64_t N, int64_t E,
+                          int32_t* perm, int32_t* isrc, int32_t* idst, int32_t* in_ptr,
+                          int32_t* out_ptr, int32_t* out_pos, int32_t* out_dst);
+
+/* ---- dense (fp32 MFMA v_mfma_f32_32x32x2_f32): nn.Linear call sites
+ *      gated_gcn_full.py:107-113, full_graph.py:23-26, score_predictor.py:15-17 and their
+ *      autograd duals.  TN mode reduces over K with split-K partials in the workspace. */
+size_t gnm_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
+int gnm_gemm_f32(int mode, int64_t M, int64_t N, int64_t K,
+                 const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc,
+                 const float* bias,                 /* [N] or NULL */
+                 const float* resid, int64_t ldr,   /* [M,N] added to the result, or NULL */
+                 int relu, void* ws, size_t ws_bytes, void* stream);
+
+/* column sums out[c] = sum_m X[m*ld + c], c < W (bias gradients). ws: gnm_colsum_workspace_bytes */
+size_t gnm_colsum_workspace_bytes(int64_t M, int64_t W);
+int gnm_colsum_f32(int64_t M, int64_t W, const float* X, int64_t ld, float* out,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* out[j, 0:W] = X[idx[j], 0:W]  (edge features: caller edge-id order -> internal order) */
+int gnm_gather_rows_f32(int64_t M, int64_t W, const float* X, const int32_t* idx, float* out,
+                        void* stream);
+/* x = (ref > 0) ? x : 0, elementwise over n floats (relu backward for the tiny encoders) */
+int gnm_relu_mask_f32(int64_t n, float* x, const float* ref, void* stream);
+
+/* ---- BatchNorm1d(track_running_stats=False) statistics: gated_gcn_full.py:122,147 ------
+ * partials: double[nblk][2][H] = per-block (sum x, sum x^2) written by the *_stats kernels.
+ * stat out: float[4][H] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale.      */
+int gnm_bn_finalize(const double* partials, int nblk, int64_t count, int H,
+                    const float* gamma, const float* beta, float eps, float* stat, void* stream);
+/* backward: partials = per-block (sum gy, sum gy*xhat).  bstat: float[2][H] = mean(gy),
+ * mean(gy*xhat); ggamma[H] = sum gy*xhat, gbeta[H] = sum gy. */
+int gnm_bn_bwd_finalize(const double* partials, int nblk, int64_t count, int H,
+                        float* bstat, float* ggamma, float* gbeta, void* stream);
+
+/* ---- GatedGCN layer, forward (gated_gcn_full.py:120-152) --------------------------------
+ * P = [A1h|A2h|A3h|B1h|B2h] is the [N,5H] node projection (ld 5H).
+ * edge_t_stats: t[j] += B1h[isrc j] + B2h[idst j]  (t holds B3e on entry), per-block
+ *               (sum t, sum t^2) -> partials.                                   (:120-121) */
+int gnm_edge_t_stats_fwd(int64_t E, int H, float* t, const float* P, const int32_t* isrc,
+                         const int32_t* idst, double* partials, int* nblk_out, void* stream);
+/* edge_gate: e_out = relu(t*scale+shift) + e_in; sigma = sigmoid(e_out);
+ *            hf[v] = sum_{in(v)} sigma*A2h[src] / (sum sigma + 1e-6); inv_f = 1/(sum sigma + 1e-6)
+ *                                                                      (:122-130) */
+int gnm_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in,
+                      const float* stat_e, const float* P, const int32_t* isrc,
+                      const int32_t* in_ptr, float* e_out, float* hf, float* inv_f, void* stream);
+/* node_agg_src: hb[v] = sum_{out(v)} sigma*A3h[dst] / (sum sigma + 1e-6), inv_b likewise;
+ *               z = A1h + hf + hb; per-block (sum z, sum z^2) -> partials   (:133-145) */
+int gnm_node_agg_src_fwd(int64_t N, int64_t E, int H, const float* e_out, const float* P,
+                         const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
+                         const float* hf, float* hb, float* inv_b, float* z, double* partials,
+                         int* nblk_out, void* stream);
+/* node_update: h_out = relu(z*scale+shift) + h_in                             (:147-152) */
+int gnm_node_update_fwd(int64_t N, int H, const float* z, const float* stat_h, const float* h_in,
+                        float* h_out, void* stream);
+
+/* ---- GatedGCN layer, backward (autograd of the above) -------
+ * node_bwd_stats: gw = gh_out*[relu(bn(z))>0]; partials (sum gw, sum gw*zhat)            */
+int gnm_node_bwd_stats(int64_t N, int H, const float* z, const float* stat_h, const float* gh_out,
+                       double* partials, int* nblk_out, void* stream);
+/* node_bwd_apply: gz = gamma*rstd*(gw - m1 - zhat*m2) -> gP[:,0:H];
+ *                 Q[N,4H] = gz*inv_f | gz*inv_f*hf | gz*inv_b | gz*inv_b*hb              */
+int gnm_node_bwd_apply(int64_t N, int H, const float* z, const float* stat_h, const float* bstat_h,
+                       const float* gamma_h, const float* gh_out, const float* hf,
+                       const float* inv_f, const float* hb, const float* inv_b, float* gP, float* Q,
+                       void* stream);
+/* edge_bwd_dst (internal order, by destination):
+ *   gsigma = Qf[d]*A2h[s] - Rf[d] + Qb[s]*A3h[d] - Rb[s];  ge <- ge + gsigma*sigma*(1-sigma)
+ *   gu = ge*[t*scale+shift > 0];  partials (sum gu, sum gu*that)
+ *   gP[:,2H:3H][d] = sum sigma*Qb[s];  Ud[d] = sum gu;  Td[d] = sum that                 */
+int gnm_edge_bwd_dst(int64_t N, int64_t E, int H, const float* e_out, const float* t,
+                     const float* stat_e, float* ge, const float* P, const float* Q,
+                     const int32_t* isrc, const int32_t* in_ptr, float* gP, float* Ud, float* Td,
+                     double* partials, int* nblk_out, void* stream);
+/* edge_bwd_src (by source, after bn_bwd_finalize):
+ *   gP[:,H:2H][v]  = sum_{out(v)} sigma*Qf[dst]
+ *   gP[:,3H:4H][v] = c*(sum_{out(v)} gu - outdeg*m1 - m2*sum_{out(v)} that)   (= sum gt)
+ *   gP[:,4H:5H][v] = c*(Ud[v] - indeg*m1 - m2*Td[v]),  c = gamma_e*rstd_e                */
+int gnm_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const float* t,
+                     const float* stat_e, const float* bstat_e, const float* gamma_e,
+                     const float* ge, const float* Q, const int32_t* in_ptr,
+                     const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
+                     const float* Ud, const float* Td, float* gP, void* stream);
+/* edge_bwd_gt: gt = gamma*rstd*(gu - m1 - that*m2), gu = ge*[t*scale+shift > 0]          */
+int gnm_edge_bwd_gt(int64_t E, int H, const float* ge, const float* t, const float* stat_e,
+                    const float* bstat_e, const float* gamma_e, float* gt, void* stream);
+
+/* ---- ScorePredictor (score_predictor.py:12-25), split-W1 form ---------------------------
+ * hid[j] += Ps[isrc j] + Pd[idst j] (hid holds e*W1e^T+b1 on entry; Pn=[Ps|Pd] is [N,2*HS]);
+ * score[perm j] = W2 . relu(hid[j]) + b2                                                 */
+int gnm_predictor_score_fwd(int64_t E, int HS, float* hid, const float* Pn, const int32_t* isrc,
+                            const int32_t* idst, const float* W2, const float* b2,
+                            const int32_t* perm, float* scores, void* stream);
+/* ghid[j] = gscore[perm j]*W2*[hid>0] (in place over hid);
+ * partials double[nblk][2][HS]: (sum gscore*relu(hid)) -> gW2, and [.,1,0] = sum gscore -> gb2 */
+int gnm_predictor_score_bwd(int64_t E, int HS, float* hid, const float* gscore, const float* W2,
+                            const int32_t* perm, double* partials, int* nblk_out, void* stream);
+/* reduce double partials [nblk][rows][W] -> float out[rows][W] */
+int gnm_reduce_partials(const double* partials, int nblk, int rows, int W, float* out, void* stream);
+/* out[v*ldo + c] = sum_{m in [ptr[v],ptr[v+1])} X[(pos ? pos[m] : m)*W + c], c < W        */
+int gnm_seg_sum_rows(int64_t N, int W, const float* X, const int32_t* ptr, const int32_t* pos,
+                     float* out, int64_t ldo, void* stream);
+
+/* ---- loss (train.py:210-211,253-255): BCEWithLogitsLoss(pos_weight), mean ---------------
+ * loss_out[0] = mean_k(pw*y*softplus(-x) + (1-y)*softplus(x)); gscore = dloss/dx.
+ * ws: double[gnm_max_partial_blocks()] */
+int gnm_bce_fwd_bwd(int64_t E, const float* scores, const float* y, float pos_weight,
+                    float* loss_out, float* gscore, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNM_H */

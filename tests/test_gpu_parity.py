@@ -1,0 +1,393 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(libgnm.so via ctypes), against the CPU oracle on the same seeded inputs and against the
+committed golden vectors generated from the reference's own code.
+
+Tolerance (BASELINE.json north_star "within 1e-4 rel fp32"; SURVEY.md section 7 parity metric):
+allclose(rtol=1e-4, atol=1e-5) and ||d||2/||ref||2 <= 1e-4 on edge logits; the same bar on loss
+and on every parameter gradient measured norm-relative per tensor (rel_l2 <= 1e-3 for
+gradients whose reference norm is itself round-off, see GRAD_* below)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files
+from helpers import load_case, sd_to_torch, rel_l2, assert_parity, RTOL, ATOL
+
+pytestmark = pytest.mark.gpu
+
+GRAD_L2 = 2e-4          # norm-relative bar for one parameter-gradient tensor (fp32 vs fp64 oracle)
+GRAD_ABS_FLOOR = 2e-7   # gradients that are analytically zero (biases in front of a BatchNorm)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _report(rows, path=None):
+    txt = "\n".join(f"{name:28s} rel_l2={r:.3e} max_abs={m:.3e} ref_norm={n:.3e}" for name, r, m, n in rows)
+    print(txt)
+    os.makedirs("gpurun_out", exist_ok=True)
+    if path:
+        with open(os.path.join("gpurun_out", path), "w") as f:
+            f.write(txt + "\n")
+    return txt
+
+
+def _cmp(name, got, want, rows):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = want.detach().cpu().double().numpy() if torch.is_tensor(want) else np.asarray(want, np.float64)
+    assert got.shape == want.shape, f"{name}: {got.shape} vs {want.shape}"
+    rows.append((name, rel_l2(got, want), float(np.abs(got - want).max()), float(np.linalg.norm(want))))
+
+
+# -----------------------------------------------------------------------------------------
+# library / GEMM
+# -----------------------------------------------------------------------------------------
+
+def test_library_loaded_and_device():
+    from gnnome_assembly_amd import _lib
+    lib = _lib.load()
+    assert lib.gnm_abi_version() == 1
+    assert lib.gnm_num_cus() >= 64
+    print("CUs:", lib.gnm_num_cus(), torch.cuda.get_device_name(0))
+
+
+@pytest.mark.parametrize("mode,M,N,K", [
+    (0, 256, 128, 128), (0, 1000, 640, 128), (0, 777, 64, 128), (0, 300, 128, 18), (0, 513, 16, 2),
+    (1, 256, 128, 128), (1, 1000, 128, 640), (1, 333, 16, 128), (1, 500, 128, 64),
+    (2, 128, 128, 4096), (2, 640, 128, 5000), (2, 64, 128, 3001), (2, 128, 18, 1000), (2, 16, 2, 777),
+    (2, 128, 128, 100000),
+])
+def test_gemm_f32(mode, M, N, K):
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    rng = np.random.default_rng(mode * 1000 + M + N + K)
+    shapes = {0: ((M, K), (N, K)), 1: ((M, K), (K, N)), 2: ((K, M), (K, N))}[mode]
+    A = rng.standard_normal(shapes[0]).astype(np.float32)
+    B = (rng.standard_normal(shapes[1]) + 0.25).astype(np.float32)   # asymmetric
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    ref = {0: A64 @ B64.T, 1: A64 @ B64, 2: A64.T @ B64}[mode]
+    dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    engine.gemm(mode, dA, dB, out)
+    scale = np.abs(A64).sum() / A.size * np.abs(B64).sum() / B.size * K
+    err = np.abs(out.cpu().double().numpy() - ref).max()
+    assert err <= 2e-6 * max(scale, 1.0) * max(1.0, np.sqrt(K) / 8), f"plain: max err {err:.3e} (scale {scale:.3e})"
+    # epilogue: bias + resid + relu, strided output view
+    big = torch.zeros((M, N + 8), device=dev)
+    outv = big[:, 4:4 + N]
+    engine.gemm(mode, dA, dB, outv, bias=torch.from_numpy(bias).to(dev), resid=torch.from_numpy(R).to(dev), relu=True)
+    ref2 = np.maximum(ref + bias + R, 0.0)
+    err2 = np.abs(outv.cpu().double().numpy() - ref2).max()
+    assert err2 <= 2e-6 * max(scale, 1.0) * max(1.0, np.sqrt(K) / 8) + 1e-6, f"epilogue: max err {err2:.3e}"
+    assert float(big[:, :4].abs().max()) == 0.0 and float(big[:, 4 + N:].abs().max()) == 0.0
+
+
+# -----------------------------------------------------------------------------------------
+# one layer, kernel by kernel, against the oracle's hand-derived decomposition
+# -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("fname", ["small_h64l1_s1.npz", "tiny_h64l1_s0.npz", "small_h128l8_s1.npz"])
+def test_layer_kernels_vs_oracle(fname):
+    from gnnome_assembly_amd import AssemblyGraph, engine
+    from oracle import gatedgcn_oracle as orc
+    dev = _dev()
+    z, sd, H, L, bn = load_case(fname)
+    src, dst, n = z["src"], z["dst"], int(z["n"])
+    p64 = sd_to_torch(sd, torch.float64)
+    with torch.no_grad():
+        _, _, g64, dbg = orc.manual_forward_backward(
+            p64, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(z["e_raw"]).double(),
+            torch.from_numpy(z["pe"]).double(), torch.from_numpy(z["y"]).double(), float(z["pos_weight"]), keep=True)
+    graph = AssemblyGraph(src, dst, n).to(dev)
+    idx = graph.index()
+    perm = idx["perm"].long().cpu()
+    E = src.size
+    li = L - 1          # check the last layer (its incoming gradients come straight from the predictor)
+    d = dbg[li]
+    P32 = {k: v.to(dev) for k, v in sd_to_torch(sd).items()}
+    prm = engine.layer_params(P32, li)
+    f = lambda t: t.float().contiguous().to(dev)  # noqa: E731
+    h_in, e_in = f(d["h"]), f(d["e"][perm])
+    h_out, e_out, s = engine.layer_forward(idx, n, E, H, prm, h_in, e_in, True)
+    torch.cuda.synchronize()
+    rows = []
+    _cmp("P", s.P, d["P"], rows)
+    _cmp("t", s.t, d["t"][perm], rows)
+    _cmp("stat_e.mean", s.stat_e[0], d["t"].mean(0), rows)
+    _cmp("stat_e.rstd", s.stat_e[1], d["rstd_e"], rows)
+    _cmp("e_out", e_out, d["e_out"][perm], rows)
+    _cmp("hf", s.hf, d["hf"], rows)
+    _cmp("inv_f", s.inv_f, d["inv_f"], rows)
+    _cmp("hb", s.hb, d["hb"], rows)
+    _cmp("inv_b", s.inv_b, d["inv_b"], rows)
+    _cmp("z", s.z, d["z"], rows)
+    _cmp("stat_h.rstd", s.stat_h[1], d["rstd_h"], rows)
+    _cmp("h_out", h_out, d["h_out"], rows)
+    nfwd = len(rows)
+    gh_out, ge = f(d["gh_out"]), f(d["ge_out"][perm])
+    gh_in, ge_in, g = engine.layer_backward(idx, n, E, H, prm, s, gh_out, ge)
+    torch.cuda.synchronize()
+    pfx = f"gnn.convs.{li}."
+    _cmp("gh_in", gh_in, d["gh_in"], rows)
+    _cmp("ge_in", ge_in, d["ge_in"][perm], rows)
+    gW5 = torch.cat([g64[pfx + k + ".weight"] for k in engine.LIN5], 0)
+    gb5 = torch.cat([g64[pfx + k + ".bias"] for k in engine.LIN5], 0)
+    _cmp("gW5", g["W5"], gW5, rows)
+    _cmp("gb5[A2,A3]", g["b5"][H:3 * H], gb5[H:3 * H], rows)
+    _cmp("gW3", g["W3"], g64[pfx + "B_3.weight"], rows)
+    _cmp("g gamma_e", g["gamma_e"], g64[pfx + "bn_e.weight"], rows)
+    _cmp("g beta_e", g["beta_e"], g64[pfx + "bn_e.bias"], rows)
+    _cmp("g gamma_h", g["gamma_h"], g64[pfx + "bn_h.weight"], rows)
+    _cmp("g beta_h", g["beta_h"], g64[pfx + "bn_h.bias"], rows)
+    _report(rows, f"layer_{fname}.txt")
+    bad = [r for r in rows[:nfwd] if r[1] > 2e-5] + [r for r in rows[nfwd:] if r[1] > GRAD_L2]
+    assert not bad, f"mismatches: {bad}"
+    # biases that feed a BatchNorm directly have an analytically zero gradient
+    zero_b = torch.cat([g["b5"][:H], g["b5"][3 * H:], g["b3"]]).abs().max().item()
+    scale = float(gW5.abs().max())
+    assert zero_b <= max(GRAD_ABS_FLOOR, 1e-4 * scale), f"pre-BN bias gradients should be ~0, got {zero_b:.3e}"
+
+
+# -----------------------------------------------------------------------------------------
+# whole model against the golden vectors (reference outputs) and the oracle
+# -----------------------------------------------------------------------------------------
+
+def _run_model(z, sd, H, L, dev, loss_kind="fused"):
+    import gnnome_assembly_amd as G
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.to(dev)
+    graph = G.AssemblyGraph(z["src"], z["dst"], int(z["n"])).to(dev)
+    x = torch.ones(int(z["n"]), 1, device=dev)
+    e = torch.from_numpy(z["e_raw"]).to(dev)
+    pe = torch.from_numpy(z["pe"]).to(dev)
+    y = torch.from_numpy(z["y"]).to(dev)
+    pw = float(z["pos_weight"])
+    if loss_kind == "fused":
+        crit = G.BCEWithLogitsLoss(pos_weight=pw)
+    else:   # the reference's own criterion (train.py:210-211) on top of our logits
+        crit = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([pw], device=dev))
+    return model, graph, x, e, pe, y, crit
+
+
+@pytest.mark.parametrize("fname", [f for f in golden_files() if "ln" not in f])
+def test_model_matches_golden(fname):
+    dev = _dev()
+    z, sd, H, L, bn = load_case(fname)
+    model, graph, x, e, pe, y, crit = _run_model(z, sd, H, L, dev)
+    model.train()
+    scores = model(graph, x, e, pe)
+    assert scores.shape == (z["src"].size, 1)
+    loss = crit(scores.squeeze(-1), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    # logits: the reference's fp64 run is the tie-breaker, its fp32 run shows fp32 noise level
+    assert_parity(scores.detach().cpu().numpy(), z["scores64"], f"{fname} logits vs reference fp64")
+    ref_noise = rel_l2(z["scores32"], z["scores64"])
+    ours = rel_l2(scores.detach().cpu().numpy(), z["scores64"])
+    print(f"{fname}: logits rel_l2 ours={ours:.2e} reference-fp32={ref_noise:.2e}")
+    assert abs(loss.item() - float(z["loss64"])) <= 1e-5 * max(1.0, abs(float(z["loss64"])))
+    stride = int(z["grad_stride"]) if H == 128 else 1
+    rows = []
+    for k, prm in model.named_parameters():
+        got = prm.grad.detach().cpu().double().numpy().reshape(-1)[::stride]
+        _cmp(k, got, z["grad/" + k], rows)
+    _report(rows, f"model_{fname}.txt")
+    gmax = max(r[3] for r in rows)
+    bad = [r for r in rows if r[1] > GRAD_L2 and r[2] > max(GRAD_ABS_FLOOR, 1e-6 * gmax)]
+    assert not bad, f"gradient mismatches: {bad}"
+    # eval mode == train mode (BatchNorm has no running stats: gated_gcn_full.py:55-56)
+    model.eval()
+    with torch.no_grad():
+        s2 = model(graph, x, e, pe)
+    assert torch.equal(s2, scores.detach())
+
+
+@pytest.mark.parametrize("fname", ["tiny_h64l1_s0.npz", "small_h64l1_s0.npz", "small_h128l8_s0.npz"])
+def test_three_adam_steps_match_reference(fname):
+    """train.py:252-258 loop on one graph: loss sequence of 3 Adam steps (golden loss_seq64)."""
+    dev = _dev()
+    z, sd, H, L, bn = load_case(fname)
+    model, graph, x, e, pe, y, crit = _run_model(z, sd, H, L, dev, loss_kind="torch")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    seq = []
+    for _ in range(3):
+        model.train()
+        pred = model(graph, x, e, pe).squeeze(-1)
+        loss = crit(pred, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        seq.append(loss.item())
+    ref = z["loss_seq64"]
+    print(fname, "loss seq", seq, "ref", list(ref))
+    assert np.abs(np.array(seq) - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    # TP/TN/FP/FN of the first step (utils.py:217-223) from a fresh model
+    model2, graph, x, e, pe, y, crit = _run_model(z, sd, H, L, dev)
+    with torch.no_grad():
+        pred = torch.round(torch.sigmoid(model2(graph, x, e, pe).squeeze(-1)))
+    tfpn = [int(((pred == a) & (y == b)).sum()) for a, b in ((1, 1), (0, 0), (1, 0), (0, 1))]
+    assert sum(abs(a - int(b)) for a, b in zip(tfpn, z["tfpn"])) <= 2, (tfpn, list(z["tfpn"]))
+
+
+def test_fused_bce_matches_torch():
+    import gnnome_assembly_amd as G
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy((rng.standard_normal(100003) * 4).astype(np.float32)).to(dev).requires_grad_(True)
+    y = torch.from_numpy((rng.random(100003) < 0.8).astype(np.float32)).to(dev)
+    pw = 0.27
+    l1 = G.BCEWithLogitsLoss(pw)(x, y)
+    l1.backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    l2 = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([pw], device=dev))(x, y)
+    l2.backward()
+    assert abs(l1.item() - l2.item()) < 1e-6
+    assert float((g1 - x.grad).abs().max()) < 1e-10 + 1e-6 * float(x.grad.abs().max())
+
+
+# -----------------------------------------------------------------------------------------
+# stand-alone modules (edge-id order at every module boundary, like DGL)
+# -----------------------------------------------------------------------------------------
+
+def test_standalone_modules_match_oracle():
+    import gnnome_assembly_amd as G
+    from oracle import gatedgcn_oracle as orc
+    dev = _dev()
+    z, sd, H, L, bn = load_case("small_h64l1_s1.npz")
+    src, dst, n = z["src"], z["dst"], int(z["n"])
+    E = src.size
+    rng = np.random.default_rng(11)
+    h0 = rng.standard_normal((n, H)).astype(np.float32)
+    e0 = rng.standard_normal((E, H)).astype(np.float32)
+    graph = G.AssemblyGraph(src, dst, n).to(dev)
+    gnn = G.layers.GraphGatedGCN(1, H, True)
+    pred = G.layers.ScorePredictor(H, 64)
+    gnn.load_state_dict({k[len("gnn."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("gnn.")})
+    pred.load_state_dict({k[len("predictor."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("predictor.")})
+    gnn.to(dev), pred.to(dev)
+    h = torch.from_numpy(h0).to(dev).requires_grad_(True)
+    e = torch.from_numpy(e0).to(dev).requires_grad_(True)
+    h1, e1 = gnn(graph, h, e)
+    s = pred(graph, h1, e1)
+    w = torch.from_numpy(rng.standard_normal((E, 1)).astype(np.float32)).to(dev)
+    (s * w).sum().backward()
+    torch.cuda.synchronize()
+    # oracle, fp64 autograd
+    p = sd_to_torch(sd, torch.float64, requires_grad=True)
+    hh = torch.from_numpy(h0).double().requires_grad_(True)
+    ee = torch.from_numpy(e0).double().requires_grad_(True)
+    ts, td = torch.from_numpy(src).long(), torch.from_numpy(dst).long()
+    rh, re = orc.layer_forward(p, 0, ts, td, n, hh, ee)
+    rs = orc.predictor_forward(p, ts, td, rh, re)
+    (rs * w.cpu().double()).sum().backward()
+    rows = []
+    _cmp("h1", h1, rh, rows)
+    _cmp("e1 (edge-id order)", e1, re, rows)
+    _cmp("scores", s, rs, rows)
+    _cmp("d/dh", h.grad, hh.grad, rows)
+    _cmp("d/de (edge-id order)", e.grad, ee.grad, rows)
+    for k, prm in list(gnn.named_parameters()) + list(pred.named_parameters()):
+        full = ("gnn." if k.startswith("convs") else "predictor.") + k
+        if any(b in full for b in ("A_1.bias", "B_1.bias", "B_2.bias", "B_3.bias")):
+            continue
+        _cmp(full, prm.grad, p[full].grad, rows)
+    _report(rows, "standalone.txt")
+    bad = [r for r in rows if r[1] > GRAD_L2]
+    assert not bad, bad
+
+
+# -----------------------------------------------------------------------------------------
+# size-independent properties at (near) BASELINE size
+# -----------------------------------------------------------------------------------------
+
+def _model_and_inputs(reads, H, L, seed, dev, permute=False):
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    src, dst, n = synth.make_graph(reads, seed, permute_edge_ids=permute)
+    inp = synth.make_inputs(src, dst, n, seed)
+    sd = synth.synth_state_dict(H, L, seed)
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.to(dev)
+    return model, src, dst, n, inp
+
+
+def test_edge_id_permutation_equivariance_and_determinism():
+    """Scores are a function of the edge, not of its id: permuting edge ids permutes the scores
+    (and leaves the loss and the parameter gradients unchanged up to summation order).  Running
+    the same input twice is bit-identical (no atomics anywhere)."""
+    import gnnome_assembly_amd as G
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(60000, 128, 4, 7, dev)
+    E = src.size
+    rng = np.random.default_rng(99)
+    p = rng.permutation(E)
+    g1 = G.AssemblyGraph(src, dst, n).to(dev)
+    g2 = G.AssemblyGraph(src[p], dst[p], n).to(dev)
+    pe = torch.from_numpy(inp["pe"]).to(dev)
+    e1 = torch.from_numpy(inp["e"]).to(dev)
+    e2 = torch.from_numpy(inp["e"][p]).to(dev)
+    y1 = torch.from_numpy(inp["y"]).to(dev)
+    y2 = torch.from_numpy(inp["y"][p]).to(dev)
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+
+    def run(g, e, y):
+        model.zero_grad(set_to_none=True)
+        s = model(g, None, e, pe)
+        loss = crit(s.squeeze(-1), y)
+        loss.backward()
+        return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
+
+    sa, la, ga = run(g1, e1, y1)
+    sb, lb, gb = run(g1, e1, y1)
+    assert torch.equal(sa, sb) and la == lb and all(torch.equal(ga[k], gb[k]) for k in ga), "not deterministic"
+    sc, lc, gc = run(g2, e2, y2)
+    pt = torch.from_numpy(p).to(dev)
+    assert_parity(sc.cpu().numpy(), sa[pt].cpu().numpy(), "permuted logits", rtol=1e-4, atol=1e-5, l2=2e-5)
+    assert abs(la - lc) < 1e-6
+    for k in ga:
+        r = rel_l2(gc[k].cpu().numpy(), ga[k].cpu().numpy())
+        assert r < 1e-3 or float((gc[k] - ga[k]).abs().max()) < GRAD_ABS_FLOOR, (k, r)
+
+
+def test_chr19_scale_step_is_finite_and_self_consistent():
+    """BASELINE config 2 size (R=750k: N=1.5M, E~7.5M, H=128, L=8): one fwd+bwd fits in HBM,
+    everything is finite, BatchNorm invariants hold on the outputs, and the loss moves down
+    along the negative gradient (a directional-derivative check of the whole backward)."""
+    import gnnome_assembly_amd as G
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(750000, 128, 8, 0, dev)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    pe = torch.from_numpy(inp["pe"]).to(dev)
+    e = torch.from_numpy(inp["e"]).to(dev)
+    y = torch.from_numpy(inp["y"]).to(dev)
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    s = model(g, None, e, pe)
+    loss = crit(s.squeeze(-1), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert s.shape == (src.size, 1) and bool(torch.isfinite(s).all())
+    gn2 = 0.0
+    for k, prm in model.named_parameters():
+        assert bool(torch.isfinite(prm.grad).all()), k
+        gn2 += float((prm.grad.double() ** 2).sum())
+    assert gn2 > 0
+    print(f"chr19-scale: E={src.size} loss={loss.item():.6f} |g|^2={gn2:.4e} "
+          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    # directional derivative: L(p - eps*g) - L(p) ~= -eps*|g|^2
+    eps = 1e-2 / max(gn2 ** 0.5, 1e-12)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm -= eps * prm.grad
+        l2 = crit(model(g, None, e, pe).squeeze(-1), y).item()
+    pred = -eps * gn2
+    print(f"directional: dL={l2 - loss.item():.4e} predicted={pred:.4e}")
+    assert (l2 - loss.item()) < 0 and abs((l2 - loss.item()) - pred) <= 0.25 * abs(pred) + 2e-6

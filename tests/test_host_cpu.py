@@ -1,0 +1,116 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gnm.h declares; host-side
+logic (graph index, module surface, state_dict schema, fail-loud behaviour)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build(verbose=False)
+    from gnnome_assembly_amd import _lib
+    return _lib.load()
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    from gnnome_assembly_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "gnm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gnm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gnm_abi_version() == 1
+    assert lib.gnm_max_partial_blocks() == 2048
+
+
+def test_invalid_arguments_return_error_not_crash(lib):
+    import ctypes as C
+    from gnnome_assembly_amd import _lib
+    rc = lib.gnm_graph_build_index(None, None, 4, 3, None, None, None, None, None, None, None)
+    assert rc < 0 and b"null" in lib.gnm_last_error()
+    src = np.array([0, 9], np.int32)
+    dst = np.array([1, 1], np.int32)
+    out = [np.zeros(8, np.int32) for _ in range(7)]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = lib.gnm_graph_build_index(p(src), p(dst), 4, 2, *[p(a) for a in out])
+    assert rc == -2 and b"outside" in lib.gnm_last_error()
+    with pytest.raises(_lib.GnmError):
+        _lib.check(rc, "gnm_graph_build_index")
+    assert lib.gnm_gemm_f32(7, 1, 1, 1, None, 1, None, 1, None, 1, None, None, 0, 0, None, 0, None) < 0
+
+
+@pytest.mark.parametrize("kind", ["tiny", "banded", "banded_perm", "empty"])
+def test_graph_index(lib, kind):
+    from gnnome_assembly_amd import AssemblyGraph, synth
+    if kind == "tiny":
+        s, d, n = synth.tiny_edge_case_graph(1)
+    elif kind == "empty":
+        s, d, n = np.zeros(0, np.int32), np.zeros(0, np.int32), 5
+    else:
+        s, d, n = synth.make_graph(3000, 2, permute_edge_ids=(kind == "banded_perm"))
+    g = AssemblyGraph(s, d, n)
+    ix = g.host_index()
+    perm = ix["perm"]
+    assert np.array_equal(np.argsort(d, kind="stable").astype(np.int32), perm)
+    assert np.array_equal(s[perm], ix["isrc"]) and np.array_equal(d[perm], ix["idst"])
+    assert np.array_equal(np.diff(ix["in_ptr"]), np.bincount(d, minlength=n))
+    assert np.array_equal(np.diff(ix["out_ptr"]), np.bincount(s, minlength=n))
+    assert np.array_equal(ix["isrc"][ix["out_pos"]], np.repeat(np.arange(n), np.diff(ix["out_ptr"])))
+    assert np.array_equal(ix["idst"][ix["out_pos"]], ix["out_dst"])
+    for v in range(min(n, 50)):   # ascending internal position inside a source
+        seg = ix["out_pos"][ix["out_ptr"][v]:ix["out_ptr"][v + 1]]
+        assert np.all(np.diff(seg) > 0)
+    assert g.num_nodes() == n and g.num_edges() == s.size
+    es, ed = g.edges()
+    assert np.array_equal(es.numpy(), s) and np.array_equal(ed.numpy(), d)
+    assert np.array_equal(g.in_degrees().numpy(), np.bincount(d, minlength=n))
+
+
+def test_module_surface_and_state_dict_schema():
+    """Constructor signatures and state_dict keys/shapes of the reference
+    (full_graph.py:12-20) so that reference checkpoints load."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    for H, L, nparam in ((64, 1, 39985), (128, 8, 826033)):
+        m = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+        sd = m.state_dict()
+        ref = synth.synth_state_dict(H, L, 0)
+        assert list(sd.keys()) == list(ref.keys())
+        assert all(tuple(sd[k].shape) == ref[k].shape for k in ref)
+        assert sum(p.numel() for p in m.parameters()) == nparam
+        assert not any("running" in k or "num_batches" in k for k in sd)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()}, strict=True)
+    assert G.layers.GraphGatedGCN(2, 32, True).convs[1].A_1.weight.shape == (32, 32)
+    assert G.layers.ScorePredictor(32, 64).W1.weight.shape == (64, 96)
+    G.layers.NodeEncoder(1, 8), G.layers.EdgeEncoder(2, 8)
+    with pytest.raises(NotImplementedError):
+        G.layers.GatedGCN_1d(32, 32, False)
+
+
+def test_product_path_has_no_cpu_fallback():
+    """CPU tensors must raise: the HIP path is the only path."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth, _lib
+    s, d, n = synth.tiny_edge_case_graph(0)
+    inp = synth.make_inputs(s, d, n)
+    m = G.GraphGatedGCNModel(1, 2, 32, 16, 1, 64, True, 16)
+    g = G.AssemblyGraph(s, d, n)
+    with pytest.raises(_lib.GnmError):
+        m(g, None, torch.from_numpy(inp["e"]), torch.from_numpy(inp["pe"]))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "gnnome_assembly_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.replace("CPU oracle", ""), f
