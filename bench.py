@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- GatedGCN edges/s, fwd+bwd (BASELINE.json metric) on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step on one whole synthetic chr19-scale assembly graph per GPU
+(BASELINE.json configs[1]: R=750k reads -> N=1.5M nodes, E~7.5M edges, hidden=128, 8 layers):
+encoders + 8 GatedGCN layers + score predictor + BCE loss + backward of all of it + (N>1) one
+RCCL all-reduce of the flat gradient + Adam step.  Graph, features and index are resident in
+HBM before the timed region.  Weak scaling: every rank owns one graph (seed = rank), value =
+sum of edges over ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant HIP kernel: algorithmic bytes per launch / its average launch time
+                (HIP events on the launch stream, measured here) vs the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (torch restatement of the reference path; "port") timed on this
+                box's host cores on a bounded 1/10-size sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+F32_MFMA_PEAK = 157.3e12   # FLOP/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=750_000, help="R; N=2R nodes, E~10R edges")
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=int, default=75_000)
+    ap.add_argument("--inference", action="store_true", help="forward only under no_grad (config 5)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(op: str, N: int, E: int, H: int):
+    """Compulsory HBM bytes of ONE launch of `op` (fp32, perfect reuse of gathered node rows):
+    the [E,H] / [N,H] streams it must read or write once.  None for ops not modelled."""
+    eh, nh = 4.0 * E * H, 4.0 * N * H
+    table = {
+        "gnm_edge_t_stats_fwd": 2 * eh + 2 * nh,            # t in/out, B1h/B2h rows
+        "gnm_edge_gate_fwd": 3 * eh + 3 * nh,               # t, e_in in; e_out out; A2h in; hf, inv_f out
+        "gnm_node_agg_src_fwd": 1 * eh + 6 * nh,            # e_out in; A1h, A3h, hf in; hb, inv_b, z out
+        "gnm_edge_bwd_dst": 4 * eh + 9 * nh,                # e_out, t, ge in; ge out; Q(4) A2h A3h in; gA3h Ud Td out
+        "gnm_edge_bwd_src": 3 * eh + 6 * nh,                # e_out, t, ge in; Qf Ud Td in; gA2h gB1h gB2h out
+        "gnm_edge_bwd_gt": 3 * eh,                          # ge, t in; gt out
+    }
+    if op in table:
+        return table[op]
+    if op.startswith("gemm_"):
+        kind = op[5:7]
+        M, Nn, K = (int(x) for x in op[op.index("[") + 1:-1].split("x"))
+        if kind == "TN":
+            return 4.0 * K * (M + Nn)                        # both operands stream over the contraction
+        return 4.0 * M * (K + Nn) + (4.0 * M * Nn if kind == "NN" else 0.0)   # A in, C out (+resid in)
+    return None
+
+
+def gemm_flops(op: str):
+    M, Nn, K = (int(x) for x in op[op.index("[") + 1:-1].split("x"))
+    return 2.0 * M * Nn * K
+
+
+def cpu_baseline(reads, H, L):
+    """fwd+bwd edges/s of the CPU oracle on this host (all cores torch gives us)."""
+    from gnnome_assembly_amd import synth
+    from oracle import gatedgcn_oracle as orc
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    src, dst, n = synth.make_graph(reads, seed=0)
+    inp = synth.make_inputs(src, dst, n, seed=0)
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.synth_state_dict(H, L, 0).items()}
+    ts, td = torch.from_numpy(src).long(), torch.from_numpy(dst).long()
+    e, pe, y = torch.from_numpy(inp["e"]), torch.from_numpy(inp["pe"]), torch.from_numpy(inp["y"])
+    pw = float(inp["pos_weight"])
+
+    def step():
+        for p in sd.values():
+            p.grad = None
+        loss = orc.bce_loss(orc.model_forward(sd, ts, td, n, e, pe), y, pw)
+        loss.backward()
+        return loss.item()
+
+    step()  # warm-up
+    times = []
+    t_total = time.time()
+    for _ in range(3):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+        if time.time() - t_total > 45:
+            break
+    med = float(np.median(times))
+    return {"value": src.size / med, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"R={reads} (N={n}, E={src.size}) H={H} L={L} fwd+bwd, torch-CPU oracle fp32, "
+                      f"median of {len(times)} steps after 1 warm-up ({med:.2f} s/step)"}
+
+
+def main():
+    args = parse()
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth, engine, dp
+    if world > 1:
+        dp.init_process_group("nccl")
+
+    H, L, R = args.hidden, args.layers, args.reads
+    src, dst, n = synth.make_graph(R, seed=rank)
+    inp = synth.make_inputs(src, dst, n, seed=rank)
+    E = int(src.size)
+    graph = G.AssemblyGraph(src, dst, n).to(dev)
+    graph.index()                                   # index resident in HBM before timing
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(H, L, 0, randomize_norm=False).items()})
+    model.to(dev)
+    e = torch.from_numpy(inp["e"]).to(dev)
+    pe = torch.from_numpy(inp["pe"]).to(dev)
+    y = torch.from_numpy(inp["y"]).to(dev)
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    flat = dp.FlatGradients(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def step():
+        if args.inference:
+            with torch.no_grad():
+                return model(graph, None, e, pe)
+        flat.zero_()
+        scores = model(graph, None, e, pe)
+        loss = crit(scores.squeeze(-1), y)
+        loss.backward()
+        flat.all_reduce_mean()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(E)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        esum = tt[1:2].clone()
+        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+        dt, total_edges = float(tmax.item()), float(esum.item())
+    else:
+        total_edges = float(E)
+    ms = dt / args.steps * 1e3
+    value = total_edges * args.steps / dt
+
+    res = None
+    if rank == 0:
+        # per-op timing of ONE extra (untimed) step: HIP events on the launch stream
+        engine.profile_ops(True)
+        step()
+        ops = engine.profile_ops(False)
+        tot = sum(t for _, t in ops.values())
+        ranked = sorted(ops.items(), key=lambda kv: -kv[1][1])
+        dom, (dc, dt_ms) = ranked[0]
+        ab = algorithmic_bytes(dom, n, E, H)
+        avg_s = dt_ms / dc / 1e3
+        if dom.startswith("gemm_") and ab is not None and gemm_flops(dom) / ab > F32_MFMA_PEAK / HBM_PEAK:
+            fl = gemm_flops(dom)
+            roof = {"kernel": dom, "bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": F32_MFMA_PEAK / 1e12,
+                    "unit": "TFLOP/s", "frac": fl / avg_s / F32_MFMA_PEAK, "traffic": None,
+                    "launches_per_step": dc, "avg_launch_ms": avg_s * 1e3}
+        else:
+            roof = {"kernel": dom, "bound": "hbm", "achieved": (ab or 0.0) / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": (ab or 0.0) / avg_s / HBM_PEAK, "traffic": None,
+                    "launches_per_step": dc, "avg_launch_ms": avg_s * 1e3}
+        per_edge = (12 if args.inference else 32) * H * L
+        step_frac = per_edge * total_edges / world / (ms / 1e3) / HBM_PEAK
+        res = {
+            "metric": "GatedGCN edges/sec fwd+bwd, chr19 assembly graph" if not args.inference
+                      else "GatedGCN edges/sec fwd only (inference)",
+            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic chr19-scale assembly graph per GPU: R={R} reads, N={n} nodes, "
+                                   f"E={E} edges, hidden={H}, layers={L}, BCE fwd+bwd + Adam"
+                                   + (", RCCL grad all-reduce" if world > 1 else ""),
+                       "reads": R, "nodes": n, "edges": E, "hidden": H, "layers": L,
+                       "parallelism": f"dp{world}", "edge_layers_per_s": value * L},
+            "roofline": roof,
+            "step_hbm_roofline_frac": step_frac,
+            "algorithmic_bytes_per_edge_step": per_edge,
+            "op_ms": {k: round(v[1], 3) for k, v in ranked[:14]},
+            "op_total_ms": round(tot, 3),
+            "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.cpu_reads, H, L)
+            except Exception as ex:  # noqa: BLE001  (baseline is reported, never fatal)
+                res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {ex}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -253,12 +253,13 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_dst_k(
       const float4 a3_d = ld4(P + v * (5 * H) + 2 * H + c4);
       for (int64_t j = a + sub; j < b; j += RPW) {
         const int64_t s = isrc[j];
-        const float4 sg = sigmoid4(ld4(e_out + j * H + c4));
+        float4 sg, dsg;
+        sigmoid_grad4(ld4(e_out + j * H + c4), sg, dsg);
         const float4 a2_s = ld4(P + s * (5 * H) + H + c4);
         const float4 qb_s = ld4(Q + s * (4 * H) + 2 * H + c4);
         const float4 rb_s = ld4(Q + s * (4 * H) + 3 * H + c4);
         const float4 gsig = fma4(qf_d, a2_s, fma4(qb_s, a3_d, f4(0.f) - rf_d - rb_s));
-        const float4 g = fma4(gsig, sg * (f4(1.f) - sg), ld4(ge + j * H + c4));
+        const float4 g = fma4(gsig, dsg, ld4(ge + j * H + c4));
         st4(ge + j * H + c4, g);
         const float4 tt = ld4(t + j * H + c4);
         const float4 gu = gate4(fma4(tt, sc, sh), g);

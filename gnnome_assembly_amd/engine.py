@@ -28,6 +28,40 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-op timing (bench.py / profiling only): when `_prof` is a list every C-ABI call is
+# bracketed by HIP events recorded on the stream the kernels are launched on.
+_prof = None
+
+
+def profile_ops(enable: bool):
+    """Start (True) or stop (False) per-op event timing; stop returns {op: (calls, total_ms)}."""
+    global _prof
+    if enable:
+        _prof = []
+        return None
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in rec or []:
+        c, t = out.get(name, (0, 0.0))
+        out[name] = (c + 1, t + e0.elapsed_time(e1))
+    return out
+
+
+def _call(name: str, *args, tag: str = None):
+    fn = getattr(_lib.load(), name)
+    if _prof is None:
+        rc = fn(*args)
+    else:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        _prof.append((tag or name, e0, e1))
+    _lib.check(rc, name)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -95,10 +129,11 @@ def gemm(mode: int, A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, bias=Non
         raise _lib.GnmError(f"gemm: shape mismatch mode={mode} A={tuple(A.shape)} B={tuple(B.shape)} C={tuple(C_.shape)}")
     need = lib.gnm_gemm_f32_workspace_bytes(mode, M, N, K)
     ws = scratch(A.device).ws(need) if need else None
-    _lib.check(lib.gnm_gemm_f32(mode, M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_),
+    _call("gnm_gemm_f32", mode, M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_),
                                 C_.stride(0), _ptr(bias), _ptr(resid),
                                 resid.stride(0) if resid is not None else 0, int(bool(relu)),
-                                _ptr(ws), need, _stream()), "gnm_gemm_f32")
+                                _ptr(ws), need, _stream(),
+          tag=f"gemm_{('NT', 'NN', 'TN')[mode]}[{M}x{N}x{K}]" if _prof is not None else None)
     return C_
 
 
@@ -110,16 +145,15 @@ def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = torch.empty(W, dtype=torch.float32, device=X.device)
     need = lib.gnm_colsum_workspace_bytes(M, W)
     ws = scratch(X.device).ws(need)
-    _lib.check(lib.gnm_colsum_f32(M, W, _ptr(X), X.stride(0), _ptr(out), _ptr(ws), need, _stream()),
-               "gnm_colsum_f32")
+    _call("gnm_colsum_f32", M, W, _ptr(X), X.stride(0), _ptr(out), _ptr(ws), need, _stream())
     return out
 
 
 def bn_finalize(partials, nblk, count, H, gamma, beta):
     lib = _lib.load()
     stat = torch.empty(4, H, dtype=torch.float32, device=gamma.device)
-    _lib.check(lib.gnm_bn_finalize(_ptr(partials), nblk, count, H, _ptr(gamma), _ptr(beta), EPS_BN,
-                                   _ptr(stat), _stream()), "gnm_bn_finalize")
+    _call("gnm_bn_finalize", _ptr(partials), nblk, count, H, _ptr(gamma), _ptr(beta), EPS_BN,
+                                   _ptr(stat), _stream())
     return stat
 
 
@@ -128,8 +162,8 @@ def bn_bwd_finalize(partials, nblk, count, H, device):
     bstat = torch.empty(2, H, dtype=torch.float32, device=device)
     gg = torch.empty(H, dtype=torch.float32, device=device)
     gb = torch.empty(H, dtype=torch.float32, device=device)
-    _lib.check(lib.gnm_bn_bwd_finalize(_ptr(partials), nblk, count, H, _ptr(bstat), _ptr(gg), _ptr(gb),
-                                       _stream()), "gnm_bn_bwd_finalize")
+    _call("gnm_bn_bwd_finalize", _ptr(partials), nblk, count, H, _ptr(bstat), _ptr(gg), _ptr(gb),
+                                       _stream())
     return bstat, gg, gb
 
 
@@ -181,28 +215,25 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     t = torch.empty(E, H, **f32)
     gemm(NT, e_in, prm.W3, t, bias=prm.b3)
     # t += B1h[src] + B2h[dst], BatchNorm statistics over all E edges       (:120-122)
-    _lib.check(lib.gnm_edge_t_stats_fwd(E, H, _ptr(t), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
-                                        _ptr(sc.partials), C.byref(nblk), st), "gnm_edge_t_stats_fwd")
+    _call("gnm_edge_t_stats_fwd", E, H, _ptr(t), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
+                                        _ptr(sc.partials), C.byref(nblk), st)
     stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
     inv_f = torch.empty(N, H, **f32)
-    _lib.check(lib.gnm_edge_gate_fwd(N, E, H, _ptr(t), _ptr(e_in), _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
-                                     _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st),
-               "gnm_edge_gate_fwd")
+    _call("gnm_edge_gate_fwd", N, E, H, _ptr(t), _ptr(e_in), _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
+                                     _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
     # by-source gated mean on the same gate, z, BatchNorm statistics over N (:133-147)
     hb = torch.empty(N, H, **f32)
     inv_b = torch.empty(N, H, **f32)
     z = torch.empty(N, H, **f32)
-    _lib.check(lib.gnm_node_agg_src_fwd(N, E, H, _ptr(e_out), _ptr(P), _ptr(idx["out_ptr"]),
+    _call("gnm_node_agg_src_fwd", N, E, H, _ptr(e_out), _ptr(P), _ptr(idx["out_ptr"]),
                                         _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(hf), _ptr(hb),
-                                        _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st),
-               "gnm_node_agg_src_fwd")
+                                        _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st)
     stat_h = bn_finalize(sc.partials, nblk.value, N, H, prm.gamma_h, prm.beta_h)
     h_out = torch.empty(N, H, **f32)
-    _lib.check(lib.gnm_node_update_fwd(N, H, _ptr(z), _ptr(stat_h), _ptr(h_in), _ptr(h_out), st),
-               "gnm_node_update_fwd")
+    _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), _ptr(h_in), _ptr(h_out), st)
     saved = None
     if save:
         saved = LayerSaved(h_in=h_in, e_in=e_in, P=P, t=t, stat_e=stat_e, e_out=e_out, hf=hf, inv_f=inv_f,
@@ -221,31 +252,31 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     f32 = dict(dtype=torch.float32, device=dev)
     g: Dict[str, torch.Tensor] = {}
     # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
-    _lib.check(lib.gnm_node_bwd_stats(N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
-                                      C.byref(nblk), st), "gnm_node_bwd_stats")
+    _call("gnm_node_bwd_stats", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
+                                      C.byref(nblk), st)
     bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
     gP = torch.empty(N, 5 * H, **f32)
     Q = torch.empty(N, 4 * H, **f32)
-    _lib.check(lib.gnm_node_bwd_apply(N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
+    _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
                                       _ptr(gh_out), _ptr(s.hf), _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b),
-                                      _ptr(gP), _ptr(Q), st), "gnm_node_bwd_apply")
+                                      _ptr(gP), _ptr(Q), st)
     # by-destination pass: ge <- ge + gsigma*sigma*(1-sigma), gA3h, BatchNorm_e backward statistics
     Ud = torch.empty(N, H, **f32)
     Td = torch.empty(N, H, **f32)
-    _lib.check(lib.gnm_edge_bwd_dst(N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
+    _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
                                     _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud),
-                                    _ptr(Td), _ptr(sc.partials), C.byref(nblk), st), "gnm_edge_bwd_dst")
+                                    _ptr(Td), _ptr(sc.partials), C.byref(nblk), st)
     bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
     # by-source pass: gA2h, gB1h, gB2h
-    _lib.check(lib.gnm_edge_bwd_src(N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+    _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
                                     _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]),
                                     _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
-                                    _ptr(Ud), _ptr(Td), _ptr(gP), st), "gnm_edge_bwd_src")
+                                    _ptr(Ud), _ptr(Td), _ptr(gP), st)
     del Ud, Td, Q
     # gt, B_3 gradients, ge_in = ge_tot + gt W3
     gt = torch.empty(E, H, **f32)
-    _lib.check(lib.gnm_edge_bwd_gt(E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
-                                   _ptr(prm.gamma_e), _ptr(gt), st), "gnm_edge_bwd_gt")
+    _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+                                   _ptr(prm.gamma_e), _ptr(gt), st)
     g["W3"] = torch.empty(H, H, **f32)
     gemm(TN, gt, s.e_in, g["W3"])
     g["b3"] = colsum(gt)
@@ -284,9 +315,8 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     hid = torch.empty(E, HS, **f32)
     gemm(NT, e, W1[:, 2 * H:], hid, bias=b1)
     scores = torch.empty(E, 1, **f32)
-    _lib.check(lib.gnm_predictor_score_fwd(E, HS, _ptr(hid), _ptr(Pn), _ptr(idx["isrc"]), _ptr(idx["idst"]),
-                                           _ptr(W2), _ptr(b2), _ptr(idx["perm"]), _ptr(scores), _stream()),
-               "gnm_predictor_score_fwd")
+    _call("gnm_predictor_score_fwd", E, HS, _ptr(hid), _ptr(Pn), _ptr(idx["isrc"]), _ptr(idx["idst"]),
+                                           _ptr(W2), _ptr(b2), _ptr(idx["perm"]), _ptr(scores), _stream())
     saved = PredSaved(x=x, e=e, hid=hid, W1sd=W1sd) if save else None
     return scores, saved
 
@@ -303,18 +333,18 @@ def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores):
     g = {}
     gscores = _f32c(gscores.reshape(-1))
     ghid = s.hid   # in place
-    _lib.check(lib.gnm_predictor_score_bwd(E, HS, _ptr(ghid), _ptr(gscores), _ptr(W2), _ptr(idx["perm"]),
-                                           _ptr(sc.partials), C.byref(nblk), st), "gnm_predictor_score_bwd")
+    _call("gnm_predictor_score_bwd", E, HS, _ptr(ghid), _ptr(gscores), _ptr(W2), _ptr(idx["perm"]),
+                                           _ptr(sc.partials), C.byref(nblk), st)
     red = torch.empty(2, HS, **f32)
-    _lib.check(lib.gnm_reduce_partials(_ptr(sc.partials), nblk.value, 2, HS, _ptr(red), st), "gnm_reduce_partials")
+    _call("gnm_reduce_partials", _ptr(sc.partials), nblk.value, 2, HS, _ptr(red), st)
     g["W2"] = red[0:1].clone()
     g["b2"] = red[1, 0:1].clone()
     g["b1"] = colsum(ghid)
     gPn = torch.empty(N, 2 * HS, **f32)
-    _lib.check(lib.gnm_seg_sum_rows(N, HS, _ptr(ghid), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]),
-                                    _ptr(gPn), 2 * HS, st), "gnm_seg_sum_rows(src)")
-    _lib.check(lib.gnm_seg_sum_rows(N, HS, _ptr(ghid), _ptr(idx["in_ptr"]), C.c_void_p(0),
-                                    _ptr(gPn[:, HS:]), 2 * HS, st), "gnm_seg_sum_rows(dst)")
+    _call("gnm_seg_sum_rows", N, HS, _ptr(ghid), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]),
+                                    _ptr(gPn), 2 * HS, st)
+    _call("gnm_seg_sum_rows", N, HS, _ptr(ghid), _ptr(idx["in_ptr"]), C.c_void_p(0),
+                                    _ptr(gPn[:, HS:]), 2 * HS, st)
     gW1 = torch.empty(HS, 3 * H, **f32)
     gemm(TN, gPn[:, :HS], s.x, gW1[:, :H])
     gemm(TN, gPn[:, HS:], s.x, gW1[:, H:2 * H])
@@ -366,8 +396,8 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     h = torch.empty(N, H, **f32)
     gemm(NT, pe, P["linear_pe.weight"], h, bias=P["linear_pe.bias"])
     e_int = torch.empty(E, e_raw.shape[1], **f32)
-    _lib.check(lib.gnm_gather_rows_f32(E, e_raw.shape[1], _ptr(e_raw), _ptr(idx["perm"]), _ptr(e_int),
-                                       _stream()), "gnm_gather_rows_f32")
+    _call("gnm_gather_rows_f32", E, e_raw.shape[1], _ptr(e_raw), _ptr(idx["perm"]), _ptr(e_int),
+                                       _stream())
     a1 = torch.empty(E, P["linear1_edge.weight"].shape[0], **f32)
     gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
     e = torch.empty(E, H, **f32)
@@ -417,7 +447,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     G["linear2_edge.bias"] = colsum(ge)
     ga1 = torch.empty_like(ms.a1)
     gemm(NN, ge, P["linear2_edge.weight"], ga1)
-    _lib.check(lib.gnm_relu_mask_f32(ga1.numel(), _ptr(ga1), _ptr(ms.a1), _stream()), "gnm_relu_mask_f32")
+    _call("gnm_relu_mask_f32", ga1.numel(), _ptr(ga1), _ptr(ms.a1), _stream())
     G["linear1_edge.weight"] = torch.empty_like(P["linear1_edge.weight"])
     gemm(TN, ga1, ms.e_int, G["linear1_edge.weight"])
     G["linear1_edge.bias"] = colsum(ga1)
@@ -434,6 +464,6 @@ def bce_with_logits(scores, y, pos_weight: float):
     sc = scratch(x.device)
     loss = torch.empty(1, dtype=torch.float32, device=x.device)
     gs = torch.empty(E, 1, dtype=torch.float32, device=x.device)
-    _lib.check(lib.gnm_bce_fwd_bwd(E, _ptr(x), _ptr(y), float(pos_weight), _ptr(loss), _ptr(gs),
-                                   _ptr(sc.partials), sc.partials.numel() * 8, _stream()), "gnm_bce_fwd_bwd")
+    _call("gnm_bce_fwd_bwd", E, _ptr(x), _ptr(y), float(pos_weight), _ptr(loss), _ptr(gs),
+                                   _ptr(sc.partials), sc.partials.numel() * 8, _stream())
     return loss, gs

@@ -27,7 +27,7 @@ class _LayerFn(torch.autograd.Function):
         N, E, H = graph.num_nodes(), graph.num_edges(), h.shape[1]
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
-        need = any(t.requires_grad for t in (h, e) + tuple(flat))
+        need = any(ctx.needs_input_grad)
         prm = engine.layer_params(P, 0)
         h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h.detach().contiguous(), e_int, need)
         ctx.graph, ctx.saved, ctx.P, ctx.dims = graph, saved, P, (N, E, H)
@@ -118,7 +118,7 @@ class _PredFn(torch.autograd.Function):
         N, E, H = graph.num_nodes(), graph.num_edges(), x.shape[1]
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
-        need = any(t.requires_grad for t in (x, e, W1, b1, W2, b2))
+        need = any(ctx.needs_input_grad)
         scores, saved = engine.predictor_forward(idx, N, E, H, W1.detach(), b1.detach(), W2.detach(), b2.detach(),
                                                  x.detach().contiguous(), e_int, need)
         ctx.graph, ctx.saved, ctx.dims = graph, saved, (N, E, H)

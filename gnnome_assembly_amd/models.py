@@ -16,7 +16,7 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, e, pe, num_layers, names, *flat):
         P = {k: v.detach() for k, v in zip(names, flat)}
-        need = torch.is_grad_enabled() and any(t.requires_grad for t in flat)
+        need = any(ctx.needs_input_grad)
         scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need)
         ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L = graph, saved, P, names, num_layers
         return scores

@@ -71,7 +71,7 @@ def test_gemm_f32(mode, M, N, K):
     bias = rng.standard_normal(N).astype(np.float32)
     R = rng.standard_normal((M, N)).astype(np.float32)
     A64, B64 = A.astype(np.float64), B.astype(np.float64)
-    ref = {0: A64 @ B64.T, 1: A64 @ B64, 2: A64.T @ B64}[mode]
+    ref = (A64 @ B64.T) if mode == 0 else (A64 @ B64) if mode == 1 else (A64.T @ B64)
     dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
     out = torch.full((M, N), float("nan"), device=dev)
     engine.gemm(mode, dA, dB, out)
