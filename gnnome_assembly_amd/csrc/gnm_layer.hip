@@ -360,19 +360,34 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_gt_k(int64_t E, const float* 
 }
 
 // -------------------------------------------------------------------------------------------
-// BatchNorm statistic finalisation (one workgroup)
+// BatchNorm statistic finalisation: parallel fp64 reduction of the per-workgroup partial rows
+// (fixed order -> deterministic), then a tiny per-channel kernel.
 // -------------------------------------------------------------------------------------------
-__global__ void bn_finalize_k(const double* __restrict__ partials, int nblk, double inv_count, int H,
+// out[i] = sum_b partials[b*total + i];  one workgroup per 16 columns, 16 row-groups x 16 columns
+__global__ __launch_bounds__(256) void reduce_rows_f64_k(const double* __restrict__ partials, int nblk,
+                                                          int total, double* __restrict__ out) {
+  __shared__ double red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
+  double acc = 0.0;
+  if (col < total)
+    for (int b = r; b < nblk; b += 16) acc += partials[(size_t)b * total + col];
+  red[r][c] = acc;
+  __syncthreads();
+  if (r == 0 && col < total) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][c];
+    out[col] = s;
+  }
+}
+
+__global__ void bn_finalize_k(const double* __restrict__ sums, double inv_count, int H,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               double eps, float* __restrict__ stat) {
   for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s1 += partials[(size_t)b * 2 * H + c];
-      s2 += partials[(size_t)b * 2 * H + H + c];
-    }
-    const double mean = s1 * inv_count;
-    double var = s2 * inv_count - mean * mean;   // biased variance, exact sums in fp64
+    const double mean = sums[c] * inv_count;
+    double var = sums[H + c] * inv_count - mean * mean;   // biased variance, exact sums in fp64
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + eps));
     const float scale = gamma[c] * rstd;
@@ -383,15 +398,11 @@ __global__ void bn_finalize_k(const double* __restrict__ partials, int nblk, dou
   }
 }
 
-__global__ void bn_bwd_finalize_k(const double* __restrict__ partials, int nblk, double inv_count,
-                                  int H, float* __restrict__ bstat, float* __restrict__ ggamma,
+__global__ void bn_bwd_finalize_k(const double* __restrict__ sums, double inv_count, int H,
+                                  float* __restrict__ bstat, float* __restrict__ ggamma,
                                   float* __restrict__ gbeta) {
   for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s1 += partials[(size_t)b * 2 * H + c];
-      s2 += partials[(size_t)b * 2 * H + H + c];
-    }
+    const double s1 = sums[c], s2 = sums[H + c];
     bstat[c] = (float)(s1 * inv_count);
     bstat[H + c] = (float)(s2 * inv_count);
     gbeta[c] = (float)s1;
@@ -545,11 +556,18 @@ extern "C" int gnm_edge_bwd_gt(int64_t E, int H, const float* ge, const float* t
   return 0;
 }
 
+// The reduced sums live in the row just past the partial rows: the caller's partials buffer
+// holds (gnm_max_partial_blocks() + 1) * 2 * 256 doubles (gnm.h).
 extern "C" int gnm_bn_finalize(const double* partials, int nblk, int64_t count, int H,
                                const float* gamma, const float* beta, float eps, float* stat,
                                void* stream) {
-  GNM_CHECK_ARG(partials && nblk > 0 && count > 0 && H > 0 && gamma && beta && stat, "bn_finalize: bad argument");
-  hipLaunchKernelGGL(bn_finalize_k, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nblk,
+  GNM_CHECK_ARG(partials && nblk > 0 && nblk <= kMaxPartialBlocks && count > 0 && H > 0 && H <= 256 && gamma &&
+                    beta && stat, "bn_finalize: bad argument");
+  double* sums = const_cast<double*>(partials) + (size_t)kMaxPartialBlocks * 2 * 256;
+  hipLaunchKernelGGL(reduce_rows_f64_k, dim3((2 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                     partials, nblk, 2 * H, sums);
+  GNM_LAUNCH_CHECK("bn_finalize reduce");
+  hipLaunchKernelGGL(bn_finalize_k, dim3(1), dim3(256), 0, (hipStream_t)stream, sums,
                      1.0 / (double)count, H, gamma, beta, (double)eps, stat);
   GNM_LAUNCH_CHECK("bn_finalize");
   return 0;
@@ -557,8 +575,13 @@ extern "C" int gnm_bn_finalize(const double* partials, int nblk, int64_t count, 
 
 extern "C" int gnm_bn_bwd_finalize(const double* partials, int nblk, int64_t count, int H,
                                    float* bstat, float* ggamma, float* gbeta, void* stream) {
-  GNM_CHECK_ARG(partials && nblk > 0 && count > 0 && H > 0 && bstat && ggamma && gbeta, "bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nblk,
+  GNM_CHECK_ARG(partials && nblk > 0 && nblk <= kMaxPartialBlocks && count > 0 && H > 0 && H <= 256 && bstat &&
+                    ggamma && gbeta, "bn_bwd_finalize: bad argument");
+  double* sums = const_cast<double*>(partials) + (size_t)kMaxPartialBlocks * 2 * 256;
+  hipLaunchKernelGGL(reduce_rows_f64_k, dim3((2 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                     partials, nblk, 2 * H, sums);
+  GNM_LAUNCH_CHECK("bn_bwd_finalize reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(1), dim3(256), 0, (hipStream_t)stream, sums,
                      1.0 / (double)count, H, bstat, ggamma, gbeta);
   GNM_LAUNCH_CHECK("bn_bwd_finalize");
   return 0;

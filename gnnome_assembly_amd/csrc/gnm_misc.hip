@@ -61,13 +61,23 @@ __global__ __launch_bounds__(kBlock) void predictor_score_bwd_k(
   block_stat_store<HS>(st, lds, partials, chunk);
 }
 
-// out[r][c] = sum_b partials[b][r][c]
-__global__ void reduce_partials_k(const double* __restrict__ partials, int nblk, int total,
-                                  float* __restrict__ out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += partials[(size_t)b * total + i];
-    out[i] = (float)acc;
+// out[i] = sum_b partials[b*total + i] (fp64 -> fp32); one workgroup per 16 columns,
+// 16 row-groups x 16 columns, fixed order -> deterministic
+__global__ __launch_bounds__(256) void reduce_partials_k(const double* __restrict__ partials, int nblk,
+                                                          int total, float* __restrict__ out) {
+  __shared__ double red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
+  double acc = 0.0;
+  if (col < total)
+    for (int b = r; b < nblk; b += 16) acc += partials[(size_t)b * total + col];
+  red[r][c] = acc;
+  __syncthreads();
+  if (r == 0 && col < total) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][c];
+    out[col] = (float)s;
   }
 }
 
@@ -98,17 +108,37 @@ __global__ __launch_bounds__(kBlock) void seg_sum_rows_k(int64_t N, const float*
   }
 }
 
-// stage 1 of column sums: ws[b][c] = sum over the block's row chunk (fp64)
-__global__ __launch_bounds__(kBlock) void colsum_stage1_k(int64_t M, int64_t W,
-                                                          const float* __restrict__ X, int64_t ld,
-                                                          double* __restrict__ ws,
-                                                          int64_t rows_per_block) {
+// stage 1 of column sums: ws[b][c] = sum over the block's row chunk (fp64 accumulation).
+// VEC: W % 4 == 0 and 16-B aligned rows -> one float4 column group per thread, blockDim.x =
+// W/4 column groups x blockDim.y rows; otherwise one column per thread.
+template <bool VEC>
+__global__ void colsum_stage1_k(int64_t M, int64_t W, const float* __restrict__ X, int64_t ld,
+                                double* __restrict__ ws, int64_t rows_per_block) {
+  extern __shared__ double sm[];   // [blockDim.y][W] (VEC only)
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
-  for (int64_t c = threadIdx.x; c < W; c += kBlock) {
-    double acc = 0.0;
-    for (int64_t r = r0; r < r1; ++r) acc += (double)X[r * ld + c];
-    ws[(int64_t)blockIdx.x * W + c] = acc;
+  if (VEC) {
+    const int cg = threadIdx.x, ry = threadIdx.y, ny = blockDim.y;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int64_t r = r0 + ry; r < r1; r += ny) {
+      const float4 v = ld4(X + r * ld + 4 * cg);
+      a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+    double* row = sm + (size_t)ry * W + 4 * cg;
+    row[0] = a0; row[1] = a1; row[2] = a2; row[3] = a3;
+    __syncthreads();
+    const int tid = ry * blockDim.x + cg, nt = blockDim.x * ny;
+    for (int64_t c = tid; c < W; c += nt) {
+      double acc = 0.0;
+      for (int y = 0; y < ny; ++y) acc += sm[(size_t)y * W + c];
+      ws[(int64_t)blockIdx.x * W + c] = acc;
+    }
+  } else {
+    for (int64_t c = threadIdx.x; c < W; c += blockDim.x) {
+      double acc = 0.0;
+      for (int64_t r = r0; r < r1; ++r) acc += (double)X[r * ld + c];
+      ws[(int64_t)blockIdx.x * W + c] = acc;
+    }
   }
 }
 
@@ -219,7 +249,7 @@ extern "C" int gnm_reduce_partials(const double* partials, int nblk, int rows, i
                                    void* stream) {
   GNM_CHECK_ARG(partials && nblk > 0 && rows > 0 && W > 0 && out, "reduce_partials: bad argument");
   const int total = rows * W;
-  hipLaunchKernelGGL(reduce_partials_k, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(reduce_partials_k, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                      partials, nblk, total, out);
   GNM_LAUNCH_CHECK("reduce_partials");
   return 0;
@@ -239,7 +269,7 @@ extern "C" int gnm_seg_sum_rows(int64_t N, int W, const float* X, const int32_t*
 }
 
 static int colsum_blocks(int64_t M) {
-  int64_t b = cdiv(M, 128);
+  int64_t b = cdiv(M, 256);
   if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
   if (b < 1) b = 1;
   return (int)b;
@@ -255,10 +285,20 @@ extern "C" int gnm_colsum_f32(int64_t M, int64_t W, const float* X, int64_t ld, 
   const int nb = colsum_blocks(M);
   GNM_CHECK_ARG(ws && ws_bytes >= (size_t)nb * W * sizeof(double), "colsum_f32: workspace too small");
   const int64_t rpb = cdiv(M, nb);
-  hipLaunchKernelGGL(colsum_stage1_k, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, M, W, X, ld,
-                     (double*)ws, rpb);
+  const bool vec = (W % 4 == 0) && (ld % 4 == 0) && ((uintptr_t)X % 16 == 0) && W / 4 <= 256;
+  if (vec) {
+    const int tx = (int)(W / 4);
+    int ty = 256 / tx;
+    if (ty < 1) ty = 1;
+    if (ty > 8) ty = 8;
+    hipLaunchKernelGGL(colsum_stage1_k<true>, dim3(nb), dim3(tx, ty), (size_t)ty * W * sizeof(double),
+                       (hipStream_t)stream, M, W, X, ld, (double*)ws, rpb);
+  } else {
+    hipLaunchKernelGGL(colsum_stage1_k<false>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, M, W, X, ld,
+                       (double*)ws, rpb);
+  }
   GNM_LAUNCH_CHECK("colsum stage 1");
-  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)((W + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)((W + 15) / 16)), dim3(256), 0,
                      (hipStream_t)stream, (const double*)ws, nb, (int)W, out);
   GNM_LAUNCH_CHECK("colsum stage 2");
   return 0;

@@ -85,7 +85,8 @@ class _Scratch:
         lib = _lib.load()
         self.device = device
         self.max_blocks = lib.gnm_max_partial_blocks()
-        self.partials = torch.empty(self.max_blocks * 2 * 256, dtype=torch.float64, device=device)
+        # (max_blocks + 1) rows: the extra row is the reduction scratch of gnm_bn_*finalize (gnm.h)
+        self.partials = torch.empty((self.max_blocks + 1) * 2 * 256, dtype=torch.float64, device=device)
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=device)
 
     def ws(self, nbytes: int) -> torch.Tensor:

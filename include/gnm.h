@@ -79,6 +79,8 @@ int gnm_relu_mask_f32(int64_t n, float* x, const float* ref, void* stream);
 
 /* ---- BatchNorm1d(track_running_stats=False) statistics: gated_gcn_full.py:122,147 ------
  * partials: double[nblk][2][H] = per-block (sum x, sum x^2) written by the *_stats kernels.
+ *           The buffer must hold (gnm_max_partial_blocks() + 1) * 2 * 256 doubles: the row
+ *           after the last possible partial row is the finalisers' reduction scratch.
  * stat out: float[4][H] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale.      */
 int gnm_bn_finalize(const double* partials, int nblk, int64_t count, int H,
                     const float* gamma, const float* beta, float eps, float* stat, void* stream);
