@@ -1,0 +1,82 @@
+"""CPU, world_size=2, gloo: the data-parallel exchange (gnnome_assembly_amd/dp.py).
+
+DP parity contract: the all-reduced flat gradient equals the MEAN of the
+single-graph gradients.  The per-graph gradients here come from the CPU oracle (the HIP path
+needs a GPU); what is under test is the flat-buffer view logic, the collective and the sharding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _graph_grads(rank):
+    from gnnome_assembly_amd import synth
+    from oracle import gatedgcn_oracle as orc
+    src, dst, n = synth.make_graph(300, seed=rank)
+    inp = synth.make_inputs(src, dst, n, seed=rank)
+    sd = synth.synth_state_dict(32, 2, seed=0)
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
+    s = orc.model_forward(p, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(inp["e"]),
+                          torch.from_numpy(inp["pe"]))
+    orc.bce_loss(s, torch.from_numpy(inp["y"]), float(inp["pos_weight"])).backward()
+    return sd, {k: v.grad for k, v in p.items()}
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import dp
+    r, w = dp.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    sd, grads = _graph_grads(rank)
+    model = G.GraphGatedGCNModel(1, 2, 32, 16, 2, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    flat = dp.FlatGradients(model.parameters())
+    assert flat.flat.numel() == sum(p.numel() for p in model.parameters())
+    flat.zero_()
+    for k, p in model.named_parameters():
+        assert p.grad.data_ptr() >= flat.flat.data_ptr()        # a view of the flat buffer
+        p.grad += grads[k]                                       # what autograd's accumulation does
+    flat.all_reduce_mean()
+    torch.optim.Adam(model.parameters(), lr=1e-3).step()
+    np.save(os.path.join(out_dir, f"flat{rank}.npy"), flat.flat.numpy())
+    np.save(os.path.join(out_dir, f"w{rank}.npy"), torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_is_mean_of_graph_gradients(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    flats = [np.load(tmp_path / f"flat{r}.npy") for r in range(world)]
+    ws = [np.load(tmp_path / f"w{r}.npy") for r in range(world)]
+    assert np.array_equal(flats[0], flats[1]) and np.array_equal(ws[0], ws[1])     # replicas stay in sync
+    import gnnome_assembly_amd as G
+    names = [k for k, _ in G.GraphGatedGCNModel(1, 2, 32, 16, 2, 64, True, 16).named_parameters()]
+    per = [_graph_grads(r)[1] for r in range(world)]
+    want = torch.cat([sum(g[k] for g in per).reshape(-1) / world for k in names]).numpy()
+    assert np.abs(flats[0] - want).max() <= 1e-7 * max(1.0, np.abs(want).max())
+
+
+def test_shard_graphs():
+    from gnnome_assembly_amd import dp
+    sizes = [5, 9, 1, 7, 3, 8, 2, 6]
+    shards = [dp.shard_graphs(8, r, 4, sizes) for r in range(4)]
+    assert sorted(sum(shards, [])) == list(range(8))
+    # size-sorted: the graphs of one step (same position in every shard) are neighbours in size
+    for step in range(2):
+        s = sorted(sizes[sh[step]] for sh in shards)
+        assert s[-1] - s[0] <= 4
+    assert dp.shard_graphs(5, 1, 2) == [1, 3]
