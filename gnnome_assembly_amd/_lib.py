@@ -41,6 +41,13 @@ SIGNATURES = {
     "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_bwd_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_rowtile_workspace_bytes": (_sz, [_i32]),
+    "gnm_edge_t_fused_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),
+    "gnm_node_proj_fwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_node_proj_bwd_workspace_bytes": (_sz, [_i32]),
+    "gnm_node_proj_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_edge_bwd_fused_workspace_bytes": (_sz, []),
+    "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_predictor_score_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_predictor_score_bwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_reduce_partials": (_i32, [_p, _i32, _i32, _i32, _p, _p]),

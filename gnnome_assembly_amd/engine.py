@@ -19,6 +19,7 @@ import torch
 from . import _lib
 
 NT, NN, TN = 0, 1, 2
+FUSED = True    # use the W-stationary fused MFMA kernels where they exist (H = 128); tests flip it
 EPS_BN = 1e-5   # nn.BatchNorm1d default (gated_gcn_full.py:55-56)
 
 LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
@@ -210,14 +211,22 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     st = _stream()
     nblk = C.c_int(0)
     f32 = dict(dtype=torch.float32, device=dev)
-    # dense projections                                                    (:107-113)
     P = torch.empty(N, 5 * H, **f32)
-    gemm(NT, h_in, prm.W5, P, bias=prm.b5)
     t = torch.empty(E, H, **f32)
-    gemm(NT, e_in, prm.W3, t, bias=prm.b3)
-    # t += B1h[src] + B2h[dst], BatchNorm statistics over all E edges       (:120-122)
-    _call("gnm_edge_t_stats_fwd", E, H, _ptr(t), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
-                                        _ptr(sc.partials), C.byref(nblk), st)
+    if H == 128 and FUSED:
+        # W-stationary fused MFMA path: projections, then t + BatchNorm partials in one pass
+        need = lib.gnm_rowtile_workspace_bytes(5 * H)
+        ws = sc.ws(need)
+        _call("gnm_node_proj_fwd", N, H, 5 * H, _ptr(h_in), _ptr(prm.W5), _ptr(prm.b5), _ptr(P), _ptr(ws), need, st)
+        _call("gnm_edge_t_fused_fwd", E, H, _ptr(e_in), _ptr(prm.W3), _ptr(prm.b3), _ptr(P), _ptr(idx["isrc"]),
+              _ptr(idx["idst"]), _ptr(t), _ptr(sc.partials), C.byref(nblk), _ptr(ws), need, st)
+    else:
+        # dense projections                                                    (:107-113)
+        gemm(NT, h_in, prm.W5, P, bias=prm.b5)
+        gemm(NT, e_in, prm.W3, t, bias=prm.b3)
+        # t += B1h[src] + B2h[dst], BatchNorm statistics over all E edges       (:120-122)
+        _call("gnm_edge_t_stats_fwd", E, H, _ptr(t), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
+              _ptr(sc.partials), C.byref(nblk), st)
     stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
@@ -275,20 +284,34 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
                                     _ptr(Ud), _ptr(Td), _ptr(gP), st)
     del Ud, Td, Q
     # gt, B_3 gradients, ge_in = ge_tot + gt W3
-    gt = torch.empty(E, H, **f32)
-    _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
-                                   _ptr(prm.gamma_e), _ptr(gt), st)
     g["W3"] = torch.empty(H, H, **f32)
-    gemm(TN, gt, s.e_in, g["W3"])
-    g["b3"] = colsum(gt)
-    gemm(NN, gt, prm.W3, ge, resid=ge)
-    del gt
+    if H == 128 and FUSED:
+        g["b3"] = torch.empty(H, **f32)
+        need = lib.gnm_edge_bwd_fused_workspace_bytes()
+        ws = sc.ws(need)
+        _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
+              _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need, st)
+    else:
+        gt = torch.empty(E, H, **f32)
+        _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+              _ptr(prm.gamma_e), _ptr(gt), st)
+        gemm(TN, gt, s.e_in, g["W3"])
+        g["b3"] = colsum(gt)
+        gemm(NN, gt, prm.W3, ge, resid=ge)
+        del gt
     # node projections backward
     g["W5"] = torch.empty(5 * H, H, **f32)
-    gemm(TN, gP, s.h_in, g["W5"])
-    g["b5"] = colsum(gP)
     gh_in = torch.empty(N, H, **f32)
-    gemm(NN, gP, prm.W5, gh_in, resid=gh_out)
+    if H == 128 and FUSED:
+        g["b5"] = torch.empty(5 * H, **f32)
+        need = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
+        ws = sc.ws(need)
+        _call("gnm_node_proj_bwd", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(prm.W5), _ptr(gh_out), _ptr(gh_in),
+              _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc.partials), _ptr(ws), need, st)
+    else:
+        gemm(TN, gP, s.h_in, g["W5"])
+        g["b5"] = colsum(gP)
+        gemm(NN, gP, prm.W5, gh_in, resid=gh_out)
     return gh_in, ge, g
 
 

@@ -142,6 +142,33 @@ int gnm_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const floa
 int gnm_edge_bwd_gt(int64_t E, int H, const float* ge, const float* t, const float* stat_e,
                     const float* bstat_e, const float* gamma_e, float* gt, void* stream);
 
+/* ---- fused W-stationary MFMA kernels (H = 128 only; other H use the unfused entry points) ---
+ * edge_t_fused_fwd: t = e_in W3^T + b3 + B1h[isrc] + B2h[idst] and the BatchNorm partials in ONE
+ *                   pass (gemm NT + gnm_edge_t_stats_fwd).            gated_gcn_full.py:113,120-122
+ * node_proj_fwd:    Pout[N,ncols] = h W^T + b, W [ncols,128] row-major, ncols % 128 == 0 (:107-112)
+ * node_proj_bwd:    gh_in = gh_out + gP W;  gW = gP^T h_in;  gb = sum gP   (gP [N,ncols])
+ *                   (gemm NN + gemm TN + colsum).                        autograd of :107-112
+ * edge_bwd_fused:   gt = gamma*rstd*(gu - m1 - that*m2), gu = ge*[t*scale+shift > 0];
+ *                   ge <- ge + gt W3;  gW3 = gt^T e_in;  gb3 = sum gt
+ *                   (gnm_edge_bwd_gt + gemm TN + gemm NN + colsum).  autograd of :113,:122
+ * ws: gnm_rowtile_workspace_bytes(ncols) / gnm_node_proj_bwd_workspace_bytes(ncols) /
+ *     gnm_edge_bwd_fused_workspace_bytes().  partials: the BatchNorm partials buffer.      */
+size_t gnm_rowtile_workspace_bytes(int ncols);
+int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
+                         const float* P, const int32_t* isrc, const int32_t* idst, float* t,
+                         double* partials, int* nblk_out, void* ws, size_t ws_bytes, void* stream);
+int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, const float* W, const float* b,
+                      float* Pout, void* ws, size_t ws_bytes, void* stream);
+size_t gnm_node_proj_bwd_workspace_bytes(int ncols);
+int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
+                      const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,
+                      void* ws, size_t ws_bytes, void* stream);
+size_t gnm_edge_bwd_fused_workspace_bytes(void);
+int gnm_edge_bwd_fused(int64_t E, int H, float* ge, const float* t, const float* e_in,
+                       const float* stat_e, const float* bstat_e, const float* gamma_e,
+                       const float* W3, float* gW3, float* gb3, double* partials, void* ws,
+                       size_t ws_bytes, void* stream);
+
 /* ---- ScorePredictor (score_predictor.py:12-25), split-W1 form ---------------------------
  * hid[j] += Ps[isrc j] + Pd[idst j] (hid holds e*W1e^T+b1 on entry; Pn=[Ps|Pd] is [N,2*HS]);
  * score[perm j] = W2 . relu(hid[j]) + b2                                                 */
