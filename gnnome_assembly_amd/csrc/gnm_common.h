@@ -18,6 +18,9 @@ constexpr float kEpsDen = 1e-6f;      // gated_gcn_full.py:130,143
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);   // records message, returns (int)e
 int num_cus();
+// out[i] = sum_b partials[b*row_stride + off + i], i < n (gnm_misc.hip)
+int reduce_partials_strided(const double* partials, int nblk, int row_stride, int off, int n, float* out,
+                            void* stream);
 
 #define GNM_CHECK_ARG(cond, ...)                     \
   do {                                               \

@@ -53,14 +53,17 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, int64_t l
                                           int64_t ilim, int64_t k0, int64_t klim, bool aligned,
                                           float4 (&r)[4]) {
   const int tid = threadIdx.x;
-  const bool FAST = aligned && (i0 + BM <= ilim) && (k0 + BK <= klim);
+  // VEC: float4 granularity is safe (aligned operand, full k-range, i-limit a multiple of 4 for
+  // the column image); rows / column quads beyond the i-limit are zero-filled without touching
+  // memory.  Otherwise per-element bounds checks (workgroup-uniform choice).
+  const bool VEC = aligned && (k0 + BK <= klim) && (ROWL || (ilim % 4 == 0));
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     if (ROWL) {
       const int row = (tid >> 3) + 32 * it, kq = (tid & 7) * 4;
       const int64_t i = i0 + row, k = k0 + kq;
-      if (FAST) {
-        r[it] = ld4(X + i * ld + k);
+      if (VEC) {
+        r[it] = (i < ilim) ? ld4(X + i * ld + k) : f4(0.f);
       } else {
         float v[4];
 #pragma unroll
@@ -70,8 +73,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, int64_t l
     } else {
       const int krow = (tid >> 5) + 8 * it, iq = (tid & 31) * 4;
       const int64_t k = k0 + krow, i = i0 + iq;
-      if (FAST) {
-        r[it] = ld4(X + k * ld + i);
+      if (VEC) {
+        r[it] = (i < ilim) ? ld4(X + k * ld + i) : f4(0.f);
       } else {
         float v[4];
 #pragma unroll

@@ -64,13 +64,15 @@ __global__ __launch_bounds__(kBlock) void predictor_score_bwd_k(
 // out[i] = sum_b partials[b*total + i] (fp64 -> fp32); one workgroup per 16 columns,
 // 16 row-groups x 16 columns, fixed order -> deterministic
 __global__ __launch_bounds__(256) void reduce_partials_k(const double* __restrict__ partials, int nblk,
-                                                          int total, float* __restrict__ out) {
+                                                          int total, float* __restrict__ out,
+                                                          int64_t stride = -1, int off = 0) {
   __shared__ double red[16][17];
   const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + c;
+  if (stride < 0) stride = total;          // dense rows
   double acc = 0.0;
   if (col < total)
-    for (int b = r; b < nblk; b += 16) acc += partials[(size_t)b * total + col];
+    for (int b = r; b < nblk; b += 16) acc += partials[(size_t)b * stride + off + col];
   red[r][c] = acc;
   __syncthreads();
   if (r == 0 && col < total) {
@@ -250,8 +252,18 @@ extern "C" int gnm_reduce_partials(const double* partials, int nblk, int rows, i
   GNM_CHECK_ARG(partials && nblk > 0 && rows > 0 && W > 0 && out, "reduce_partials: bad argument");
   const int total = rows * W;
   hipLaunchKernelGGL(reduce_partials_k, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream,
-                     partials, nblk, total, out);
+                     partials, nblk, total, out, (int64_t)-1, 0);
   GNM_LAUNCH_CHECK("reduce_partials");
+  return 0;
+}
+
+// out[i] = sum_b partials[b*row_stride + off + i], i < n (a column slice of wider partial rows)
+int gnm::reduce_partials_strided(const double* partials, int nblk, int row_stride, int off, int n, float* out,
+                                 void* stream) {
+  GNM_CHECK_ARG(partials && nblk > 0 && n > 0 && out && row_stride >= off + n, "reduce_partials_strided: bad argument");
+  hipLaunchKernelGGL(reduce_partials_k, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nblk, n,
+                     out, (int64_t)row_stride, off);
+  GNM_LAUNCH_CHECK("reduce_partials_strided");
   return 0;
 }
 
@@ -299,7 +311,7 @@ extern "C" int gnm_colsum_f32(int64_t M, int64_t W, const float* X, int64_t ld, 
   }
   GNM_LAUNCH_CHECK("colsum stage 1");
   hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)((W + 15) / 16)), dim3(256), 0,
-                     (hipStream_t)stream, (const double*)ws, nb, (int)W, out);
+                     (hipStream_t)stream, (const double*)ws, nb, (int)W, out, (int64_t)-1, 0);
   GNM_LAUNCH_CHECK("colsum stage 2");
   return 0;
 }

@@ -390,6 +390,7 @@ class ModelSaved:
     pe: torch.Tensor = None
     e_int: torch.Tensor = None
     a1: torch.Tensor = None
+    e_raw: torch.Tensor = None
     layers: List[LayerSaved] = field(default_factory=list)
     pred: PredSaved = None
 
@@ -419,14 +420,21 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     # encoders                                                            (full_graph.py:23-26)
     h = torch.empty(N, H, **f32)
     gemm(NT, pe, P["linear_pe.weight"], h, bias=P["linear_pe.bias"])
-    e_int = torch.empty(E, e_raw.shape[1], **f32)
-    _call("gnm_gather_rows_f32", E, e_raw.shape[1], _ptr(e_raw), _ptr(idx["perm"]), _ptr(e_int),
-                                       _stream())
-    a1 = torch.empty(E, P["linear1_edge.weight"].shape[0], **f32)
-    gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
+    Fe, Q = e_raw.shape[1], P["linear1_edge.weight"].shape[0]
+    fused_enc = FUSED and H == 128 and Fe == 2 and Q == 16
     e = torch.empty(E, H, **f32)
-    gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
-    ms = ModelSaved(pe=pe, e_int=e_int, a1=a1) if save else None
+    e_int = a1 = None
+    if fused_enc:
+        _call("gnm_edge_encoder_fwd", E, H, Fe, Q, _ptr(e_raw), _ptr(idx["perm"]), _ptr(P["linear1_edge.weight"]),
+              _ptr(P["linear1_edge.bias"]), _ptr(P["linear2_edge.weight"]), _ptr(P["linear2_edge.bias"]),
+              _ptr(e), _stream())
+    else:
+        e_int = torch.empty(E, Fe, **f32)
+        _call("gnm_gather_rows_f32", E, Fe, _ptr(e_raw), _ptr(idx["perm"]), _ptr(e_int), _stream())
+        a1 = torch.empty(E, Q, **f32)
+        gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
+        gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
+    ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw) if save else None
     for i in range(num_layers):
         h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save)
         if save:
@@ -467,14 +475,24 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     gemm(TN, gh, ms.pe, G["linear_pe.weight"])
     G["linear_pe.bias"] = colsum(gh)
     G["linear2_edge.weight"] = torch.empty_like(P["linear2_edge.weight"])
-    gemm(TN, ge, ms.a1, G["linear2_edge.weight"])
-    G["linear2_edge.bias"] = colsum(ge)
-    ga1 = torch.empty_like(ms.a1)
-    gemm(NN, ge, P["linear2_edge.weight"], ga1)
-    _call("gnm_relu_mask_f32", ga1.numel(), _ptr(ga1), _ptr(ms.a1), _stream())
     G["linear1_edge.weight"] = torch.empty_like(P["linear1_edge.weight"])
-    gemm(TN, ga1, ms.e_int, G["linear1_edge.weight"])
-    G["linear1_edge.bias"] = colsum(ga1)
+    if ms.a1 is None:      # fused encoder: every encoder gradient from one pass over ge
+        G["linear2_edge.bias"] = torch.empty_like(P["linear2_edge.bias"])
+        G["linear1_edge.bias"] = torch.empty_like(P["linear1_edge.bias"])
+        need = lib.gnm_edge_encoder_bwd_workspace_bytes()
+        ws = scratch(dev).ws(need)
+        _call("gnm_edge_encoder_bwd", E, H, ms.e_raw.shape[1], P["linear1_edge.weight"].shape[0], _ptr(ge),
+              _ptr(ms.e_raw), _ptr(idx["perm"]), _ptr(P["linear1_edge.weight"]), _ptr(P["linear1_edge.bias"]),
+              _ptr(P["linear2_edge.weight"]), _ptr(G["linear1_edge.weight"]), _ptr(G["linear1_edge.bias"]),
+              _ptr(G["linear2_edge.weight"]), _ptr(G["linear2_edge.bias"]), _ptr(ws), need, _stream())
+    else:
+        gemm(TN, ge, ms.a1, G["linear2_edge.weight"])
+        G["linear2_edge.bias"] = colsum(ge)
+        ga1 = torch.empty_like(ms.a1)
+        gemm(NN, ge, P["linear2_edge.weight"], ga1)
+        _call("gnm_relu_mask_f32", ga1.numel(), _ptr(ga1), _ptr(ms.a1), _stream())
+        gemm(TN, ga1, ms.e_int, G["linear1_edge.weight"])
+        G["linear1_edge.bias"] = colsum(ga1)
     return G
 
 

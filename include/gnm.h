@@ -169,6 +169,20 @@ int gnm_edge_bwd_fused(int64_t E, int H, float* ge, const float* t, const float*
                        const float* W3, float* gW3, float* gb3, double* partials, void* ws,
                        size_t ws_bytes, void* stream);
 
+/* ---- edge-feature encoder (full_graph.py:24-26), H = 128, edge_features F = 2, hidden Q = 16 ----
+ * fwd: e0[j] = W2 relu(W1 e_raw[perm j] + b1) + b2, internal order, one pass writing [E,H]
+ *      (gnm_gather_rows + 2 gemm NT).
+ * bwd: from ge0 [E,H]: gW2 [H,Q], gb2 [H], gW1 [Q,F], gb1 [Q] in one pass reading ge0 once
+ *      (2 gemm TN + gemm NN + relu mask + 2 colsum).  ws: gnm_edge_encoder_bwd_workspace_bytes(). */
+int gnm_edge_encoder_fwd(int64_t E, int H, int F, int Q, const float* e_raw, const int32_t* perm,
+                         const float* W1, const float* b1, const float* W2, const float* b2,
+                         float* e0, void* stream);
+size_t gnm_edge_encoder_bwd_workspace_bytes(void);
+int gnm_edge_encoder_bwd(int64_t E, int H, int F, int Q, const float* ge0, const float* e_raw,
+                         const int32_t* perm, const float* W1, const float* b1, const float* W2,
+                         float* gW1, float* gb1, float* gW2, float* gb2, void* ws, size_t ws_bytes,
+                         void* stream);
+
 /* ---- ScorePredictor (score_predictor.py:12-25), split-W1 form ---------------------------
  * hid[j] += Ps[isrc j] + Pd[idst j] (hid holds e*W1e^T+b1 on entry; Pn=[Ps|Pd] is [N,2*HS]);
  * score[perm j] = W2 . relu(hid[j]) + b2                                                 */
