@@ -52,32 +52,37 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(op: str, N: int, E: int, H: int):
-    """Compulsory HBM bytes of ONE launch of `op` (fp32, perfect reuse of gathered node rows):
-    the [E,H] / [N,H] streams it must read or write once.  None for ops not modelled."""
+def op_model(op: str, N: int, E: int, H: int):
+    """(algorithmic HBM bytes, MFMA flops) of ONE launch of `op` (fp32).  Bytes = the [E,H] / [N,H]
+    streams it must read or write once, assuming perfect reuse of gathered node rows (DESIGN.md
+    section 3).  (None, None) for ops not modelled."""
     eh, nh = 4.0 * E * H, 4.0 * N * H
     table = {
-        "gnm_edge_t_stats_fwd": 2 * eh + 2 * nh,            # t in/out, B1h/B2h rows
-        "gnm_edge_gate_fwd": 3 * eh + 3 * nh,               # t, e_in in; e_out out; A2h in; hf, inv_f out
-        "gnm_node_agg_src_fwd": 1 * eh + 6 * nh,            # e_out in; A1h, A3h, hf in; hb, inv_b, z out
-        "gnm_edge_bwd_dst": 4 * eh + 9 * nh,                # e_out, t, ge in; ge out; Q(4) A2h A3h in; gA3h Ud Td out
-        "gnm_edge_bwd_src": 3 * eh + 6 * nh,                # e_out, t, ge in; Qf Ud Td in; gA2h gB1h gB2h out
-        "gnm_edge_bwd_gt": 3 * eh,                          # ge, t in; gt out
+        "gnm_edge_t_stats_fwd": (2 * eh + 2 * nh, 0.0),       # t in/out, B1h/B2h rows
+        "gnm_edge_gate_fwd": (3 * eh + 3 * nh, 0.0),          # t, e_in in; e_out out; A2h in; hf, inv_f out
+        "gnm_node_agg_src_fwd": (1 * eh + 6 * nh, 0.0),       # e_out in; A1h, A3h, hf in; hb, inv_b, z out
+        "gnm_edge_bwd_dst": (4 * eh + 9 * nh, 0.0),           # e_out, t, ge in; ge out; Q(4) A2h A3h in; gA3h Ud Td out
+        "gnm_edge_bwd_src": (3 * eh + 6 * nh, 0.0),           # e_out, t, ge in; Qf Ud Td in; gA2h gB1h gB2h out
+        "gnm_edge_bwd_gt": (3 * eh, 0.0),                     # ge, t in; gt out
+        "gnm_edge_t_fused_fwd": (2 * eh + 2 * nh, 2.0 * E * H * H),        # e_in in, t out, B1h/B2h rows
+        "gnm_edge_bwd_fused": (4 * eh, 4.0 * E * H * H),                   # ge in/out, t, e_in; NN + TN
+        "gnm_node_proj_fwd": (6 * nh, 2.0 * N * H * 5 * H),                # h in, P out
+        "gnm_node_proj_bwd": (8 * nh, 4.0 * N * H * 5 * H),                # gP, h_in, gh_out in; gh_in out; NN + TN
+        "gnm_edge_encoder_fwd": (eh, 0.0),
+        "gnm_edge_encoder_bwd": (eh, 0.0),
+        "gnm_node_bwd_apply": (11 * nh, 0.0),
+        "gnm_node_update_fwd": (3 * nh, 0.0),
     }
     if op in table:
         return table[op]
     if op.startswith("gemm_"):
         kind = op[5:7]
         M, Nn, K = (int(x) for x in op[op.index("[") + 1:-1].split("x"))
+        fl = 2.0 * M * Nn * K
         if kind == "TN":
-            return 4.0 * K * (M + Nn)                        # both operands stream over the contraction
-        return 4.0 * M * (K + Nn) + (4.0 * M * Nn if kind == "NN" else 0.0)   # A in, C out (+resid in)
-    return None
-
-
-def gemm_flops(op: str):
-    M, Nn, K = (int(x) for x in op[op.index("[") + 1:-1].split("x"))
-    return 2.0 * M * Nn * K
+            return 4.0 * K * (M + Nn), fl                    # both operands stream over the contraction
+        return 4.0 * M * (K + Nn) + (4.0 * M * Nn if kind == "NN" else 0.0), fl   # A in, C out (+resid in)
+    return None, None
 
 
 def usable_cores():
@@ -160,6 +165,11 @@ def cpu_baseline_subprocess(args, timeout_s=120):
                 "sample": f"timed out after {timeout_s} s"}
 
 
+def dbg(msg):
+    if os.environ.get("GNM_BENCH_DEBUG"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -173,12 +183,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    # GNM_BENCH_DEVICE / GNM_BENCH_BACKEND exist only to exercise the N>1 code path on a 1-GPU box
+    # (all ranks on one device, gloo); the driver's multi-GPU runs use one device per rank and RCCL.
+    local = int(os.environ.get("GNM_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import synth, engine, dp
     if world > 1:
-        dp.init_process_group("nccl")
+        dp.init_process_group(os.environ.get("GNM_BENCH_BACKEND", "nccl"))
+        dbg("process group up")
 
     H, L, R = args.hidden, args.layers, args.reads
     src, dst, n = synth.make_graph(R, seed=rank)
@@ -208,9 +222,11 @@ def main():
         opt.step()
         return loss
 
+    dbg(f"setup done E={E}")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    dbg("warmup done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -222,6 +238,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dbg(f"timed region done {dt:.3f}s")
     tt = torch.tensor([dt, float(E)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tt[0:1].clone()
@@ -234,26 +251,38 @@ def main():
     ms = dt / args.steps * 1e3
     value = total_edges * args.steps / dt
 
+    # per-op timing of ONE extra (untimed) step: HIP events on the launch stream.  Every rank runs
+    # the step (it contains the gradient all-reduce); only rank 0 records and reports.
+    if rank == 0:
+        engine.profile_ops(True)
+    step()
+    ops = engine.profile_ops(False) if rank == 0 else None
+    dbg("profile step done")
     res = None
     if rank == 0:
-        # per-op timing of ONE extra (untimed) step: HIP events on the launch stream
-        engine.profile_ops(True)
-        step()
-        ops = engine.profile_ops(False)
         tot = sum(t for _, t in ops.values())
         ranked = sorted(ops.items(), key=lambda kv: -kv[1][1])
         dom, (dc, dt_ms) = ranked[0]
-        ab = algorithmic_bytes(dom, n, E, H)
+        ab, fl = op_model(dom, n, E, H)
         avg_s = dt_ms / dc / 1e3
-        if dom.startswith("gemm_") and ab is not None and gemm_flops(dom) / ab > F32_MFMA_PEAK / HBM_PEAK:
-            fl = gemm_flops(dom)
+        t_hbm = (ab or 0.0) / HBM_PEAK            # time the launch would take at the HBM roofline
+        t_mfma = (fl or 0.0) / F32_MFMA_PEAK      # ... at the fp32 matrix-core roofline
+        if t_mfma > t_hbm:
             roof = {"kernel": dom, "bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": F32_MFMA_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": fl / avg_s / F32_MFMA_PEAK, "traffic": None,
-                    "launches_per_step": dc, "avg_launch_ms": avg_s * 1e3}
+                    "unit": "TFLOP/s", "frac": t_mfma / avg_s, "traffic": None}
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": (ab or 0.0) / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": (ab or 0.0) / avg_s / HBM_PEAK, "traffic": None,
-                    "launches_per_step": dc, "avg_launch_ms": avg_s * 1e3}
+                    "unit": "GB/s", "frac": t_hbm / avg_s, "traffic": None}
+        roof.update({"launches_per_step": dc, "avg_launch_ms": avg_s * 1e3,
+                     "algorithmic_gb_per_launch": (ab or 0.0) / 1e9, "hbm_frac": t_hbm / avg_s,
+                     "mfma_frac": t_mfma / avg_s})
+        # the dominant HBM-bound (gather / scatter / normalise) kernel, for the north_star's evidence
+        for k, (c, tms) in ranked:
+            kb, kf = op_model(k, n, E, H)
+            if kb and not kf:
+                roof["top_hbm_kernel"] = {"kernel": k, "achieved_gbps": kb / (tms / c / 1e3) / 1e9,
+                                          "frac": kb / (tms / c / 1e3) / HBM_PEAK, "avg_launch_ms": tms / c}
+                break
         per_edge = (12 if args.inference else 32) * H * L
         step_frac = per_edge * total_edges / world / (ms / 1e3) / HBM_PEAK
         res = {

@@ -20,14 +20,13 @@ class _LayerFn(torch.autograd.Function):
     """One GatedGCN_1d.forward with edge-id-order e at the boundary."""
 
     @staticmethod
-    def forward(ctx, graph, h, e, *flat):
+    def forward(ctx, graph, need, h, e, *flat):
         names = _LAYER_KEYS
         P = {"gnn.convs.0." + k: v for k, v in zip(names, flat)}
         idx = graph.index(h.device)
         N, E, H = graph.num_nodes(), graph.num_edges(), h.shape[1]
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
-        need = any(ctx.needs_input_grad)
         prm = engine.layer_params(P, 0)
         h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h.detach().contiguous(), e_int, need)
         ctx.graph, ctx.saved, ctx.P, ctx.dims = graph, saved, P, (N, E, H)
@@ -50,7 +49,7 @@ class _LayerFn(torch.autograd.Function):
         for j, k in enumerate(engine.LIN5):
             grads += [g["W5"][j * H:(j + 1) * H], g["b5"][j * H:(j + 1) * H]]
         grads += [g["W3"], g["b3"], g["gamma_h"], g["beta_h"], g["gamma_e"], g["beta_e"]]
-        return (None, gh_in, ge_user) + tuple(grads)
+        return (None, None, gh_in, ge_user) + tuple(grads)
 
 
 _LAYER_KEYS = tuple(f"{k}.{w}" for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3") for w in ("weight", "bias")) + \
@@ -93,7 +92,9 @@ class GatedGCN_1d(nn.Module):
 
     def forward(self, g, h, e):
         P = dict(self.named_parameters())
-        return _LayerFn.apply(g, h, e, *[P[k] for k in _LAYER_KEYS])
+        flat = [P[k] for k in _LAYER_KEYS]
+        need = torch.is_grad_enabled() and any(t.requires_grad for t in [h, e] + flat)
+        return _LayerFn.apply(g, need, h, e, *flat)
 
 
 class GraphGatedGCN(nn.Module):
@@ -113,12 +114,11 @@ class GraphGatedGCN(nn.Module):
 
 class _PredFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, graph, x, e, W1, b1, W2, b2):
+    def forward(ctx, graph, need, x, e, W1, b1, W2, b2):
         idx = graph.index(x.device)
         N, E, H = graph.num_nodes(), graph.num_edges(), x.shape[1]
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
-        need = any(ctx.needs_input_grad)
         scores, saved = engine.predictor_forward(idx, N, E, H, W1.detach(), b1.detach(), W2.detach(), b2.detach(),
                                                  x.detach().contiguous(), e_int, need)
         ctx.graph, ctx.saved, ctx.dims = graph, saved, (N, E, H)
@@ -134,7 +134,7 @@ class _PredFn(torch.autograd.Function):
         ctx.saved = None
         ge_user = torch.empty_like(ge)
         ge_user.index_copy_(0, perm, ge)
-        return None, gx, ge_user, g["W1"], g["b1"], g["W2"], g["b2"]
+        return None, None, gx, ge_user, g["W1"], g["b1"], g["W2"], g["b2"]
 
 
 class ScorePredictor(nn.Module):
@@ -146,7 +146,9 @@ class ScorePredictor(nn.Module):
         self.W2 = nn.Linear(hidden_edge_scores, 1)
 
     def forward(self, graph, x, e):
-        return _PredFn.apply(graph, x, e, self.W1.weight, self.W1.bias, self.W2.weight, self.W2.bias)
+        ts = (x, e, self.W1.weight, self.W1.bias, self.W2.weight, self.W2.bias)
+        need = torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+        return _PredFn.apply(graph, need, *ts)
 
 
 class NodeEncoder(nn.Module):

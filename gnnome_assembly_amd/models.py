@@ -14,9 +14,10 @@ class _ModelFn(torch.autograd.Function):
     to the predictor, activations are released layer by layer in backward."""
 
     @staticmethod
-    def forward(ctx, graph, e, pe, num_layers, names, *flat):
+    def forward(ctx, graph, e, pe, num_layers, names, need, *flat):
+        # `need` (grad mode on and some parameter requires grad) is decided by the caller: inside
+        # Function.forward grad mode is always off, and needs_input_grad stays set under no_grad.
         P = {k: v.detach() for k, v in zip(names, flat)}
-        need = any(ctx.needs_input_grad)
         scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need)
         ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L = graph, saved, P, names, num_layers
         return scores
@@ -27,7 +28,7 @@ class _ModelFn(torch.autograd.Function):
             raise RuntimeError("GraphGatedGCNModel: backward called twice or forward ran without grad")
         G = engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores)
         ctx.saved = None
-        return (None, None, None, None, None) + tuple(G[k] for k in ctx.names)
+        return (None, None, None, None, None, None) + tuple(G[k] for k in ctx.names)
 
 
 class GraphGatedGCNModel(nn.Module):
@@ -48,7 +49,8 @@ class GraphGatedGCNModel(nn.Module):
 
     def forward(self, graph, x, e, pe):
         names, flat = zip(*self.named_parameters())
-        return _ModelFn.apply(graph, e, pe, self.num_layers, names, *flat)
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in flat)
+        return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, *flat)
 
 
 class _BCEFn(torch.autograd.Function):

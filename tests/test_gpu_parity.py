@@ -423,3 +423,30 @@ def test_chr19_scale_step_is_finite_and_self_consistent():
     pred = -eps * gn2
     print(f"directional: dL={l2 - loss.item():.4e} predicted={pred:.4e}")
     assert (l2 - loss.item()) < 0 and abs((l2 - loss.item()) - pred) <= 0.25 * abs(pred) + 2e-6
+
+
+def test_no_grad_forward_keeps_no_activations():
+    """inference.py:444-453 runs the model under torch.no_grad(): nothing may be saved for backward
+    (peak memory of a forward-only pass must stay far below that of a training step)."""
+    import gnnome_assembly_amd as G
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(100000, 128, 8, 1, dev)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    pe = torch.from_numpy(inp["pe"]).to(dev)
+    e = torch.from_numpy(inp["e"]).to(dev)
+    g.index()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        s1 = model(g, None, e, pe)
+    torch.cuda.synchronize()
+    peak_inf = torch.cuda.max_memory_allocated() - base
+    torch.cuda.reset_peak_memory_stats()
+    s2 = model(g, None, e, pe)
+    torch.cuda.synchronize()
+    peak_train = torch.cuda.max_memory_allocated() - base
+    assert torch.equal(s1, s2.detach())
+    eh = src.size * 128 * 4
+    print(f"peak forward memory: no_grad {peak_inf / eh:.1f} [E,H] units, grad {peak_train / eh:.1f}")
+    assert peak_inf < 8 * eh and peak_train > 2 * peak_inf
