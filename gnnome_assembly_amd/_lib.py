@@ -41,6 +41,11 @@ SIGNATURES = {
     "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_bwd_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_ln_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_ln_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "gnm_ln_node_bwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_ln_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_ln_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_rowtile_workspace_bytes": (_sz, [_i32]),
     "gnm_edge_t_fused_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),
     "gnm_node_proj_fwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),

@@ -202,7 +202,7 @@ class LayerSaved:
     stat_h: torch.Tensor = None
 
 
-def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool):
+def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True):
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
     Returns (h_out, e_out, LayerSaved or None)."""
     lib = _lib.load()
@@ -227,23 +227,32 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
         # t += B1h[src] + B2h[dst], BatchNorm statistics over all E edges       (:120-122)
         _call("gnm_edge_t_stats_fwd", E, H, _ptr(t), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
               _ptr(sc.partials), C.byref(nblk), st)
-    stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
     inv_f = torch.empty(N, H, **f32)
-    _call("gnm_edge_gate_fwd", N, E, H, _ptr(t), _ptr(e_in), _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
-                                     _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
+    if batch_norm:
+        stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
+        _call("gnm_edge_gate_fwd", N, E, H, _ptr(t), _ptr(e_in), _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
+              _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
+    else:       # LayerNorm: row statistics inside the kernel, no barrier
+        stat_e = None
+        _call("gnm_ln_edge_gate_fwd", N, E, H, _ptr(t), _ptr(e_in), _ptr(prm.gamma_e), _ptr(prm.beta_e), _ptr(P),
+              _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
     # by-source gated mean on the same gate, z, BatchNorm statistics over N (:133-147)
     hb = torch.empty(N, H, **f32)
     inv_b = torch.empty(N, H, **f32)
     z = torch.empty(N, H, **f32)
     _call("gnm_node_agg_src_fwd", N, E, H, _ptr(e_out), _ptr(P), _ptr(idx["out_ptr"]),
-                                        _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(hf), _ptr(hb),
-                                        _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st)
-    stat_h = bn_finalize(sc.partials, nblk.value, N, H, prm.gamma_h, prm.beta_h)
+          _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(hf), _ptr(hb),
+          _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st)
     h_out = torch.empty(N, H, **f32)
-    _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), _ptr(h_in), _ptr(h_out), st)
+    if batch_norm:
+        stat_h = bn_finalize(sc.partials, nblk.value, N, H, prm.gamma_h, prm.beta_h)
+        _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), _ptr(h_in), _ptr(h_out), st)
+    else:
+        stat_h = None
+        _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(h_in), _ptr(h_out), st)
     saved = None
     if save:
         saved = LayerSaved(h_in=h_in, e_in=e_in, P=P, t=t, stat_e=stat_e, e_out=e_out, hf=hf, inv_f=inv_f,
@@ -251,7 +260,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     return h_out, e_out, saved
 
 
-def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge):
+def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True):
     """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
     and is OVERWRITTEN with d loss / d e_in.  Returns (gh_in, ge, grads dict)."""
     lib = _lib.load()
@@ -261,44 +270,60 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     nblk = C.c_int(0)
     f32 = dict(dtype=torch.float32, device=dev)
     g: Dict[str, torch.Tensor] = {}
-    # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
-    _call("gnm_node_bwd_stats", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
-                                      C.byref(nblk), st)
-    bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
     gP = torch.empty(N, 5 * H, **f32)
     Q = torch.empty(N, 4 * H, **f32)
-    _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
-                                      _ptr(gh_out), _ptr(s.hf), _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b),
-                                      _ptr(gP), _ptr(Q), st)
-    # by-destination pass: ge <- ge + gsigma*sigma*(1-sigma), gA3h, BatchNorm_e backward statistics
-    Ud = torch.empty(N, H, **f32)
-    Td = torch.empty(N, H, **f32)
-    _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
-                                    _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud),
-                                    _ptr(Td), _ptr(sc.partials), C.byref(nblk), st)
-    bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
-    # by-source pass: gA2h, gB1h, gB2h
-    _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
-                                    _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]),
-                                    _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
-                                    _ptr(Ud), _ptr(Td), _ptr(gP), st)
-    del Ud, Td, Q
-    # gt, B_3 gradients, ge_in = ge_tot + gt W3
     g["W3"] = torch.empty(H, H, **f32)
-    if H == 128 and FUSED:
-        g["b3"] = torch.empty(H, **f32)
-        need = lib.gnm_edge_bwd_fused_workspace_bytes()
-        ws = sc.ws(need)
-        _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
-              _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need, st)
-    else:
+    if not batch_norm:
+        # ---- LayerNorm mode: no global barriers, gt is produced by the by-destination pass ----
+        _call("gnm_ln_node_bwd", N, H, _ptr(s.z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(gh_out), _ptr(s.hf),
+              _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), _ptr(sc.partials), C.byref(nblk), st)
+        _, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
         gt = torch.empty(E, H, **f32)
-        _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
-              _ptr(prm.gamma_e), _ptr(gt), st)
+        _call("gnm_ln_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(prm.gamma_e), _ptr(prm.beta_e),
+              _ptr(ge), _ptr(s.P), _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt),
+              _ptr(sc.partials), C.byref(nblk), st)
+        _, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
+        _call("gnm_ln_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q), _ptr(idx["out_ptr"]),
+              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
+        del Q
         gemm(TN, gt, s.e_in, g["W3"])
         g["b3"] = colsum(gt)
         gemm(NN, gt, prm.W3, ge, resid=ge)
         del gt
+    else:
+        # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
+        _call("gnm_node_bwd_stats", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
+              C.byref(nblk), st)
+        bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
+        _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
+              _ptr(gh_out), _ptr(s.hf), _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
+        # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
+        Ud = torch.empty(N, H, **f32)
+        Td = torch.empty(N, H, **f32)
+        _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
+              _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+              _ptr(sc.partials), C.byref(nblk), st)
+        bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
+        # by-source pass: gA2h, gB1h, gB2h
+        _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+              _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
+              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), st)
+        del Ud, Td, Q
+        # gt, B_3 gradients, ge_in = ge_tot + gt W3
+        if H == 128 and FUSED:
+            g["b3"] = torch.empty(H, **f32)
+            need = lib.gnm_edge_bwd_fused_workspace_bytes()
+            ws = sc.ws(need)
+            _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
+                  _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need, st)
+        else:
+            gt = torch.empty(E, H, **f32)
+            _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+                  _ptr(prm.gamma_e), _ptr(gt), st)
+            gemm(TN, gt, s.e_in, g["W3"])
+            g["b3"] = colsum(gt)
+            gemm(NN, gt, prm.W3, ge, resid=ge)
+            del gt
     # node projections backward
     g["W5"] = torch.empty(5 * H, H, **f32)
     gh_in = torch.empty(N, H, **f32)
@@ -405,7 +430,7 @@ def layer_params(P: Dict[str, torch.Tensor], i: int) -> LayerParams:
         gamma_h=P[p + "bn_h.weight"], beta_h=P[p + "bn_h.bias"])
 
 
-def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int, save: bool):
+def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int, save: bool, batch_norm: bool = True):
     """GraphGatedGCNModel.forward.  e_raw [E,edge_features] in edge-id order, pe [N,nb_pos_enc+2].
     Returns (scores [E,1] in edge-id order, ModelSaved or None)."""
     lib = _lib.load()
@@ -436,7 +461,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw) if save else None
     for i in range(num_layers):
-        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save)
+        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm)
         if save:
             ms.layers.append(ls)
     scores, ps = predictor_forward(idx, N, E, H, P["predictor.W1.weight"], P["predictor.W1.bias"],
@@ -446,7 +471,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     return scores, ms
 
 
-def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores):
+def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores, batch_norm: bool = True):
     """Gradients of every parameter (keys = state_dict keys) from d loss / d scores."""
     dev = ms.pe.device
     idx = graph.index(dev)
@@ -461,7 +486,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     ms.pred = None
     for i in reversed(range(num_layers)):
         p = f"gnn.convs.{i}."
-        gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge)
+        gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm)
         ms.layers[i] = None     # release this layer's activations
         for j, k in enumerate(LIN5):
             G[p + k + ".weight"] = gl["W5"][j * H:(j + 1) * H]

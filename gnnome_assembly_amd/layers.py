@@ -20,7 +20,7 @@ class _LayerFn(torch.autograd.Function):
     """One GatedGCN_1d.forward with edge-id-order e at the boundary."""
 
     @staticmethod
-    def forward(ctx, graph, need, h, e, *flat):
+    def forward(ctx, graph, need, batch_norm, h, e, *flat):
         names = _LAYER_KEYS
         P = {"gnn.convs.0." + k: v for k, v in zip(names, flat)}
         idx = graph.index(h.device)
@@ -28,8 +28,8 @@ class _LayerFn(torch.autograd.Function):
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
         prm = engine.layer_params(P, 0)
-        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h.detach().contiguous(), e_int, need)
-        ctx.graph, ctx.saved, ctx.P, ctx.dims = graph, saved, P, (N, E, H)
+        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h.detach().contiguous(), e_int, need, batch_norm)
+        ctx.graph, ctx.saved, ctx.P, ctx.dims, ctx.bn = graph, saved, P, (N, E, H), batch_norm
         out_e = torch.empty_like(e_out)
         out_e.index_copy_(0, perm, e_out)
         return h_out, out_e
@@ -41,7 +41,7 @@ class _LayerFn(torch.autograd.Function):
         perm = idx["perm"].long()
         prm = engine.layer_params(ctx.P, 0)
         ge = ge_out.index_select(0, perm).contiguous()        # fresh buffer, overwritten below
-        gh_in, ge_in, g = engine.layer_backward(idx, N, E, H, prm, ctx.saved, gh_out.contiguous(), ge)
+        gh_in, ge_in, g = engine.layer_backward(idx, N, E, H, prm, ctx.saved, gh_out.contiguous(), ge, ctx.bn)
         ctx.saved = None
         ge_user = torch.empty_like(ge_in)
         ge_user.index_copy_(0, perm, ge_in)
@@ -49,7 +49,7 @@ class _LayerFn(torch.autograd.Function):
         for j, k in enumerate(engine.LIN5):
             grads += [g["W5"][j * H:(j + 1) * H], g["b5"][j * H:(j + 1) * H]]
         grads += [g["W3"], g["b3"], g["gamma_h"], g["beta_h"], g["gamma_e"], g["beta_e"]]
-        return (None, None, gh_in, ge_user) + tuple(grads)
+        return (None, None, None, gh_in, ge_user) + tuple(grads)
 
 
 _LAYER_KEYS = tuple(f"{k}.{w}" for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3") for w in ("weight", "bias")) + \
@@ -57,8 +57,9 @@ _LAYER_KEYS = tuple(f"{k}.{w}" for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3
 
 
 class _Norm(nn.Module):
-    """Parameter holder with BatchNorm1d(track_running_stats=False)'s state_dict (weight, bias;
-    no running buffers: gated_gcn_full.py:55-56)."""
+    """Parameter holder with the state_dict of BatchNorm1d(track_running_stats=False) /
+    LayerNorm (weight, bias; no running buffers: gated_gcn_full.py:55-59).  Which of the two the
+    layer applies is GatedGCN_1d.batch_norm."""
 
     def __init__(self, n):
         super().__init__()
@@ -76,10 +77,6 @@ class GatedGCN_1d(nn.Module):
             # the reference silently drops the residual (gated_gcn_full.py:41-42); the model never
             # builds such a layer (processor.py:11-12) and the HIP path does not implement it.
             raise NotImplementedError("GatedGCN_1d: in_channels != out_channels is outside the hot path")
-        if not batch_norm:
-            raise NotImplementedError(
-                "GatedGCN_1d(batch_norm=False) (LayerNorm, gated_gcn_full.py:57-59) is not built yet; "
-                "every BASELINE config uses batch_norm=True")
         if dropout != 0:
             raise NotImplementedError("dropout != 0 is never used by the reference (processor.py:12)")
         self.dropout = dropout
@@ -94,7 +91,7 @@ class GatedGCN_1d(nn.Module):
         P = dict(self.named_parameters())
         flat = [P[k] for k in _LAYER_KEYS]
         need = torch.is_grad_enabled() and any(t.requires_grad for t in [h, e] + flat)
-        return _LayerFn.apply(g, need, h, e, *flat)
+        return _LayerFn.apply(g, need, bool(self.batch_norm), h, e, *flat)
 
 
 class GraphGatedGCN(nn.Module):

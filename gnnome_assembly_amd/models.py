@@ -14,21 +14,21 @@ class _ModelFn(torch.autograd.Function):
     to the predictor, activations are released layer by layer in backward."""
 
     @staticmethod
-    def forward(ctx, graph, e, pe, num_layers, names, need, *flat):
+    def forward(ctx, graph, e, pe, num_layers, names, need, batch_norm, *flat):
         # `need` (grad mode on and some parameter requires grad) is decided by the caller: inside
         # Function.forward grad mode is always off, and needs_input_grad stays set under no_grad.
         P = {k: v.detach() for k, v in zip(names, flat)}
-        scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need)
-        ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L = graph, saved, P, names, num_layers
+        scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need, batch_norm)
+        ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L, ctx.bn = graph, saved, P, names, num_layers, batch_norm
         return scores
 
     @staticmethod
     def backward(ctx, gscores):
         if ctx.saved is None:
             raise RuntimeError("GraphGatedGCNModel: backward called twice or forward ran without grad")
-        G = engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores)
+        G = engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores, ctx.bn)
         ctx.saved = None
-        return (None, None, None, None, None, None) + tuple(G[k] for k in ctx.names)
+        return (None, None, None, None, None, None, None) + tuple(G[k] for k in ctx.names)
 
 
 class GraphGatedGCNModel(nn.Module):
@@ -46,11 +46,12 @@ class GraphGatedGCNModel(nn.Module):
         self.gnn = layers.GraphGatedGCN(num_layers, hidden_features, batch_norm)
         self.predictor = layers.ScorePredictor(hidden_features, hidden_edge_scores)
         self.num_layers = num_layers
+        self.batch_norm = bool(batch_norm)
 
     def forward(self, graph, x, e, pe):
         names, flat = zip(*self.named_parameters())
         need = torch.is_grad_enabled() and any(p.requires_grad for p in flat)
-        return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, *flat)
+        return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, self.batch_norm, *flat)
 
 
 class _BCEFn(torch.autograd.Function):

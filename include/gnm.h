@@ -142,6 +142,33 @@ int gnm_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const floa
 int gnm_edge_bwd_gt(int64_t E, int H, const float* ge, const float* t, const float* stat_e,
                     const float* bstat_e, const float* gamma_e, float* gt, void* stream);
 
+/* ---- LayerNorm mode (batch_norm=False: nn.LayerNorm(H) for bn_h / bn_e, gated_gcn_full.py:57-59) ---
+ * Row-wise normalisation, no global barrier.  The projections, t (gnm_edge_t_stats_fwd or the fused
+ * form) and gnm_node_agg_src_fwd are shared with BatchNorm mode (their column partials are unused).
+ * ln_edge_gate_fwd   e_out = relu(LN(t)*gamma+beta) + e_in, sigma, by-destination gated mean
+ * ln_node_update_fwd h_out = relu(LN(z)*gamma+beta) + h_in
+ * ln_node_bwd        gz -> gP[:,0:H], Q[N,4H]; partials (sum gw, sum gw*zhat) -> gnm_bn_bwd_finalize
+ * ln_edge_bwd_dst    ge <- ge + gsigma*sigma'; gt = LNbwd(ge*[u>0]) -> gt[E,H]; gP[:,2H:3H] = sum
+ *                    sigma*Qb[s]; gP[:,4H:5H] = sum_dst gt; partials (sum gu, sum gu*that)
+ * ln_edge_bwd_src    gP[:,H:2H] = sum_src sigma*Qf[d]; gP[:,3H:4H] = sum_src gt
+ * (B_3 gradients and ge_in then come from gnm_gemm_f32 TN/NN + gnm_colsum_f32 on gt.)          */
+int gnm_ln_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in,
+                         const float* gamma, const float* beta, const float* P, const int32_t* isrc,
+                         const int32_t* in_ptr, float* e_out, float* hf, float* inv_f, void* stream);
+int gnm_ln_node_update_fwd(int64_t N, int H, const float* z, const float* gamma, const float* beta,
+                           const float* h_in, float* h_out, void* stream);
+int gnm_ln_node_bwd(int64_t N, int H, const float* z, const float* gamma, const float* beta,
+                    const float* gh_out, const float* hf, const float* inv_f, const float* hb,
+                    const float* inv_b, float* gP, float* Q, double* partials, int* nblk_out,
+                    void* stream);
+int gnm_ln_edge_bwd_dst(int64_t N, int64_t E, int H, const float* e_out, const float* t,
+                        const float* gamma, const float* beta, float* ge, const float* P, const float* Q,
+                        const int32_t* isrc, const int32_t* in_ptr, float* gP, float* gt,
+                        double* partials, int* nblk_out, void* stream);
+int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const float* gt, const float* Q,
+                        const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
+                        float* gP, void* stream);
+
 /* ---- fused W-stationary MFMA kernels (H = 128 only; other H use the unfused entry points) ---
  * edge_t_fused_fwd: t = e_in W3^T + b3 + B1h[isrc] + B2h[idst] and the BatchNorm partials in ONE
  *                   pass (gemm NT + gnm_edge_t_stats_fwd).            gated_gcn_full.py:113,120-122

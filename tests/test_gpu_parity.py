@@ -31,11 +31,11 @@ def _grad_ok(r_ours, r_ref32, max_abs, floor):
     return r_ours <= GRAD_L2 or r_ours <= NOISE_X * r_ref32 + 1e-6 or max_abs <= floor
 
 
-def _oracle_grads(z, sd, dtype):
+def _oracle_grads(z, sd, dtype, batch_norm=True):
     from oracle import gatedgcn_oracle as orc
     p = sd_to_torch(sd, dtype, requires_grad=True)
     s = orc.model_forward(p, torch.from_numpy(z["src"]), torch.from_numpy(z["dst"]), int(z["n"]),
-                          torch.from_numpy(z["e_raw"]).to(dtype), torch.from_numpy(z["pe"]).to(dtype))
+                          torch.from_numpy(z["e_raw"]).to(dtype), torch.from_numpy(z["pe"]).to(dtype), batch_norm)
     orc.bce_loss(s, torch.from_numpy(z["y"]).to(dtype), float(z["pos_weight"])).backward()
     return {k: v.grad.double().numpy() for k, v in p.items()}
 
@@ -188,7 +188,7 @@ def test_layer_kernels_vs_oracle(fname):
 
 def _run_model(z, sd, H, L, dev, loss_kind="fused"):
     import gnnome_assembly_amd as G
-    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, bool(z["batch_norm"]), 16)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.to(dev)
     graph = G.AssemblyGraph(z["src"], z["dst"], int(z["n"])).to(dev)
@@ -204,7 +204,7 @@ def _run_model(z, sd, H, L, dev, loss_kind="fused"):
     return model, graph, x, e, pe, y, crit
 
 
-@pytest.mark.parametrize("fname", [f for f in golden_files() if "ln" not in f])
+@pytest.mark.parametrize("fname", golden_files())
 def test_model_matches_golden(fname):
     dev = _dev()
     z, sd, H, L, bn = load_case(fname)
@@ -222,7 +222,7 @@ def test_model_matches_golden(fname):
     print(f"{fname}: logits rel_l2 ours={ours:.2e} reference-fp32={ref_noise:.2e}")
     assert abs(loss.item() - float(z["loss64"])) <= 1e-5 * max(1.0, abs(float(z["loss64"])))
     stride = int(z["grad_stride"]) if H == 128 else 1
-    g32 = _oracle_grads(z, sd, torch.float32)      # the reference arithmetic in fp32: noise level
+    g32 = _oracle_grads(z, sd, torch.float32, bn)  # the reference arithmetic in fp32: noise level
     rows, bad = [], []
     gmax = max(float(np.linalg.norm(z["grad/" + k])) for k, _ in model.named_parameters())
     for k, prm in model.named_parameters():

@@ -91,8 +91,9 @@ def test_module_surface_and_state_dict_schema():
     assert G.layers.GraphGatedGCN(2, 32, True).convs[1].A_1.weight.shape == (32, 32)
     assert G.layers.ScorePredictor(32, 64).W1.weight.shape == (64, 96)
     G.layers.NodeEncoder(1, 8), G.layers.EdgeEncoder(2, 8)
+    assert G.layers.GatedGCN_1d(32, 32, False).batch_norm is False     # LayerNorm mode exists
     with pytest.raises(NotImplementedError):
-        G.layers.GatedGCN_1d(32, 32, False)
+        G.layers.GatedGCN_1d(32, 64, True)
 
 
 def test_product_path_has_no_cpu_fallback():
