@@ -85,6 +85,33 @@ def op_model(op: str, N: int, E: int, H: int):
     return None, None
 
 
+# C-ABI op -> HIP kernel whose PMC traffic (profiles/r01_b_traffic.json) belongs to it
+OP_KERNEL = {
+    "gnm_edge_bwd_fused": "edge_bwd_fused_k", "gnm_edge_bwd_dst": "edge_bwd_dst_k<128>",
+    "gnm_edge_bwd_src": "edge_bwd_src_k<128>", "gnm_edge_gate_fwd": "edge_gate_fwd_k<128>",
+    "gnm_node_agg_src_fwd": "node_agg_src_fwd_k<128>", "gnm_edge_t_fused_fwd": "rowtile_nt_k<true, 1>",
+    "gnm_node_proj_fwd": "rowtile_nt_k<false, 5>", "gnm_node_bwd_apply": "node_bwd_apply_k<128>",
+}
+
+
+def measured_traffic(op, N, E, H):
+    """Per-launch HBM bytes of `op` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), if they were taken on this workload."""
+    path = os.path.join(REPO, "profiles", "r01_b_traffic.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = d.get("workload", {})
+    if (w.get("edges"), w.get("nodes"), w.get("hidden")) != (E, N, H):
+        return None
+    if op == "gnm_node_proj_bwd":       # two kernels behind one entry point
+        ks = [d["per_launch"].get("rowtile_nn_acc_k"), d["per_launch"].get("tn_colgroup_k")]
+        return sum(k["total_gb"] for k in ks) * 1e9 if all(ks) else None
+    k = d["per_launch"].get(OP_KERNEL.get(op, ""))
+    return k["total_gb"] * 1e9 if k else None
+
+
 def usable_cores():
     try:
         n = len(os.sched_getaffinity(0))
@@ -273,6 +300,7 @@ def main():
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": (ab or 0.0) / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": t_hbm / avg_s, "traffic": None}
+        roof["traffic"] = measured_traffic(dom, n, E, H)
         roof.update({"launches_per_step": dc, "avg_launch_ms": avg_s * 1e3,
                      "algorithmic_gb_per_launch": (ab or 0.0) / 1e9, "hbm_frac": t_hbm / avg_s,
                      "mfma_frac": t_mfma / avg_s})
@@ -281,7 +309,9 @@ def main():
             kb, kf = op_model(k, n, E, H)
             if kb and not kf:
                 roof["top_hbm_kernel"] = {"kernel": k, "achieved_gbps": kb / (tms / c / 1e3) / 1e9,
-                                          "frac": kb / (tms / c / 1e3) / HBM_PEAK, "avg_launch_ms": tms / c}
+                                          "frac": kb / (tms / c / 1e3) / HBM_PEAK, "avg_launch_ms": tms / c,
+                                          "algorithmic_gb_per_launch": kb / 1e9,
+                                          "traffic": measured_traffic(k, n, E, H)}
                 break
         per_edge = (12 if args.inference else 32) * H * L
         step_frac = per_edge * total_edges / world / (ms / 1e3) / HBM_PEAK

@@ -1,0 +1,14 @@
+#!/bin/bash
+# HBM traffic per kernel launch from the TCC PMC counters (run on the GPU box via gpurun).
+# Two separate rocprofv3 passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: they do not fit
+# together), kernel-trace only, as MI355X_MICROARCH.md prescribes.  Output: gpurun_out/traffic/*.csv
+set -e
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out/traffic
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic -o $c -- \
+      python $R/tools/microbench.py --iters 2 > $R/gpurun_out/traffic/$c.log 2>&1
+done
+ls $R/gpurun_out/traffic

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/collect_traffic.sh into per-launch HBM bytes.
+
+Units and corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB
+(hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); on gfx950 FETCH_SIZE reports exactly half of the
+bytes of a wide (16 B/lane) coalesced streaming read, so the read side is doubled.  WRITE_SIZE is
+taken as is.  Writes profiles/<name>.json: {kernel: {fetch_gb, write_gb, total_gb, launches}}."""
+import collections, csv, json, sys
+d, out = sys.argv[1], sys.argv[2]
+res = collections.defaultdict(lambda: {"fetch_kib": 0.0, "write_kib": 0.0, "n_f": 0, "n_w": 0})
+for c, key, nk in (("FETCH_SIZE", "fetch_kib", "n_f"), ("WRITE_SIZE", "write_kib", "n_w")):
+    for r in csv.DictReader(open(f"{d}/{c}_counter_collection.csv")):
+        if r["Counter_Name"] != c:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void gnm::", "").replace("gnm::", "")
+        res[k][key] += float(r["Counter_Value"])
+        res[k][nk] += 1
+table = {}
+for k, v in res.items():
+    if not v["n_f"] or not v["n_w"]:
+        continue
+    f = 2.0 * v["fetch_kib"] * 1024 / v["n_f"]     # gfx950: FETCH_SIZE counts 64 B per 128-B request
+    w = v["write_kib"] * 1024 / v["n_w"]
+    table[k] = {"fetch_gb": f / 1e9, "write_gb": w / 1e9, "total_gb": (f + w) / 1e9, "launches": v["n_f"]}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py "
+                     "(one layer fwd+bwd, E=7540278, N=1500000, H=128); FETCH_SIZE doubled (gfx950)",
+           "per_launch": table}, open(out, "w"), indent=1, sort_keys=True)
+for k, v in sorted(table.items(), key=lambda kv: -kv[1]["total_gb"])[:20]:
+    print(f"{k:40s} fetch={v['fetch_gb']:7.2f} GB write={v['write_gb']:7.2f} GB total={v['total_gb']:7.2f} GB")
