@@ -52,7 +52,7 @@ SIGNATURES = {
     "gnm_node_proj_bwd_workspace_bytes": (_sz, [_i32]),
     "gnm_node_proj_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_bwd_fused_workspace_bytes": (_sz, []),
-    "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_encoder_fwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_encoder_bwd_workspace_bytes": (_sz, []),
     "gnm_edge_encoder_bwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
 // fused edge backward: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
-    int64_t E, float* __restrict__ ge, const float* __restrict__ t, const float* __restrict__ e_in,
+    int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
     const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
     const float* __restrict__ Wp,                    // W3 packed NN
     float* __restrict__ slab,                        // [grid][128][128] partial gW3
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
     for (int it = 0; it < 8; ++it) {
       const int row = lrow + 8 * it;
       const int64_t grow = r0 + row;
-      if (FULL || grow < E) st4(ge + grow * FH + lc4, ld4(gs + row * FP + lc4) + gk[it]);
+      if (FULL || grow < E) st4(ge_out + grow * FH + lc4, ld4(gs + row * FP + lc4) + gk[it]);
     }
     __syncthreads();   // gs is rewritten by the next tile's phase 0
   };
@@ -589,12 +589,12 @@ extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void) {
   return gnm_rowtile_workspace_bytes(FH) + (size_t)kMaxPartialBlocks * FH * FH * sizeof(float);
 }
 
-extern "C" int gnm_edge_bwd_fused(int64_t E, int H, float* ge, const float* t, const float* e_in,
+extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const float* t, const float* e_in,
                                   const float* stat_e, const float* bstat_e, const float* gamma_e,
                                   const float* W3, float* gW3, float* gb3, double* partials, void* ws,
                                   size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(H == FH, "edge_bwd_fused: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(E > 0 && ge && t && e_in && stat_e && bstat_e && gamma_e && W3 && gW3 && gb3 && partials,
+  GNM_CHECK_ARG(E > 0 && ge && ge_out && t && e_in && stat_e && bstat_e && gamma_e && W3 && gW3 && gb3 && partials,
                 "edge_bwd_fused: null/neg argument");
   const int64_t ntiles = cdiv_(E, FTR);
   const int grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k>());
@@ -605,7 +605,7 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, float* ge, const float* t, c
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
   hipLaunchKernelGGL(pack_w_k, dim3(16), dim3(256), 0, st, W3, (int64_t)FH, FH / 32, 1, wp);
   GNM_LAUNCH_CHECK("pack_w (NN)");
-  hipLaunchKernelGGL(edge_bwd_fused_k, dim3(grid), dim3(kBlock), 0, st, E, ge, t, e_in, stat_e, bstat_e,
+  hipLaunchKernelGGL(edge_bwd_fused_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
                      gamma_e, (const float*)wp, slab, partials, cdiv_(ntiles, grid));
   GNM_LAUNCH_CHECK("edge_bwd_fused");
   hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);

@@ -314,7 +314,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             g["b3"] = torch.empty(H, **f32)
             need = lib.gnm_edge_bwd_fused_workspace_bytes()
             ws = sc.ws(need)
-            _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
+            _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need, st)
         else:
             gt = torch.empty(E, H, **f32)

@@ -176,7 +176,7 @@ int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const f
  * node_proj_bwd:    gh_in = gh_out + gP W;  gW = gP^T h_in;  gb = sum gP   (gP [N,ncols])
  *                   (gemm NN + gemm TN + colsum).                        autograd of :107-112
  * edge_bwd_fused:   gt = gamma*rstd*(gu - m1 - that*m2), gu = ge*[t*scale+shift > 0];
- *                   ge <- ge + gt W3;  gW3 = gt^T e_in;  gb3 = sum gt
+ *                   ge_out = ge + gt W3 (ge_out may alias ge);  gW3 = gt^T e_in;  gb3 = sum gt
  *                   (gnm_edge_bwd_gt + gemm TN + gemm NN + colsum).  autograd of :113,:122
  * ws: gnm_rowtile_workspace_bytes(ncols) / gnm_node_proj_bwd_workspace_bytes(ncols) /
  *     gnm_edge_bwd_fused_workspace_bytes().  partials: the BatchNorm partials buffer.      */
@@ -191,7 +191,7 @@ int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float*
                       const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,
                       void* ws, size_t ws_bytes, void* stream);
 size_t gnm_edge_bwd_fused_workspace_bytes(void);
-int gnm_edge_bwd_fused(int64_t E, int H, float* ge, const float* t, const float* e_in,
+int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const float* t, const float* e_in,
                        const float* stat_e, const float* bstat_e, const float* gamma_e,
                        const float* W3, float* gW3, float* gb3, double* partials, void* ws,
                        size_t ws_bytes, void* stream);
