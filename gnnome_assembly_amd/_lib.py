@@ -60,6 +60,9 @@ SIGNATURES = {
     "gnm_predictor_score_bwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_reduce_partials": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
     "gnm_seg_sum_rows": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
+    "gnm_pagerank_pe_workspace_bytes": (_sz, [_i64]),
+    "gnm_pagerank_pe": (_i32, [_i64, _i64, _p, _p, _p, _i32, C.c_double, _p, _p, _sz, _p]),
+    "gnm_edge_feats_zscore": (_i32, [_i64, _p, _p, _p, _p, _sz, _p]),
     "gnm_bce_fwd_bwd": (_i32, [_i64, _p, _p, _f32, _p, _p, _p, _sz, _p]),
 }
 

@@ -1,0 +1,170 @@
+"""Training-harness counterpart of the reference's full-graph branch (train.py:115-533 with
+batch_size_train <= 1): per-graph Adam steps, validation under no_grad/eval, ReduceLROnPlateau,
+best-model + checkpoint files with the reference's key schema.  SURVEY.md section 8f row 2.
+
+Differences from the reference, all deliberate:
+  * graphs, features and the index stay resident on the device (the reference re-uploads every
+    step, train.py:245-251);
+  * TP/TN/FP/FN are accumulated on the device and read back once per epoch (the reference's
+    utils.calculate_tfpn forces four .item() syncs per graph, utils.py:217-223);
+  * under torch.distributed (one process per GPU) the W graphs of a step contribute the MEAN of
+    their gradients through one RCCL all-reduce (dp.FlatGradients); single-process runs reproduce the
+    reference's one-step-per-graph sequence;
+  * wandb, METIS mini-batching and the data pipeline are out of scope.
+`calculate_metrics` keeps the reference's naming, in which "precision" and "recall" are swapped
+(utils.py:227-234)."""
+from __future__ import annotations
+
+import copy
+import os
+import random
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import dp, models
+
+__all__ = ["get_hyperparameters", "GraphSample", "tfpn_counts", "calculate_metrics", "train", "save_checkpoint"]
+
+
+def get_hyperparameters() -> Dict:
+    """hyperparameters.py:3-34 with the full-graph branch selected (batch_size_* = 1)."""
+    return {
+        "seed": 0, "lr": 1e-3, "num_epochs": 100, "dim_latent": 256, "node_features": 1, "edge_features": 2,
+        "hidden_edge_features": 16, "hidden_edge_scores": 64, "num_gnn_layers": 16, "nb_pos_enc": 16,
+        "batch_size_train": 1, "batch_size_eval": 1, "patience": 2, "decay": 0.95, "batch_norm": True,
+    }
+
+
+@dataclass
+class GraphSample:
+    """One training graph resident on the device: what train.py:245-254 pulls out of a DGLGraph."""
+    graph: object                 # AssemblyGraph on the device
+    e: torch.Tensor               # [E,2] z-scored edge features (edge-id order)
+    pe: torch.Tensor              # [N, nb_pos_enc+2] = in_deg | out_deg | pe
+    y: torch.Tensor               # [E] float labels
+    x: Optional[torch.Tensor] = None
+
+
+def tfpn_counts(edge_predictions: torch.Tensor, edge_labels: torch.Tensor) -> torch.Tensor:
+    """[TP, TN, FP, FN] as a device int64 tensor (utils.calculate_tfpn without the .item() syncs)."""
+    p = torch.round(torch.sigmoid(edge_predictions))
+    return torch.stack([((p == 1) & (edge_labels == 1)).sum(), ((p == 0) & (edge_labels == 0)).sum(),
+                        ((p == 1) & (edge_labels == 0)).sum(), ((p == 0) & (edge_labels == 1)).sum()])
+
+
+def calculate_metrics(TP, TN, FP, FN):
+    """utils.calculate_metrics (utils.py:226-240), including its swapped precision/recall names."""
+    recall = TP / (TP + FP) if (TP + FP) else 0
+    precision = TP / (TP + FN) if (TP + FN) else 0
+    f1 = TP / (TP + 0.5 * (FP + FN)) if (TP + 0.5 * (FP + FN)) else 0
+    accuracy = (TP + TN) / (TP + TN + FP + FN)
+    return accuracy, precision, recall, f1
+
+
+def save_checkpoint(epoch, model, optimizer, loss_train, loss_valid, out, directory="checkpoints"):
+    """train.py:28-58: same dict keys, same file name."""
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, f"{out}.pt")
+    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optim_state_dict": optimizer.state_dict(),
+                "loss_train": loss_train, "loss_valid": loss_valid}, path)
+    return path
+
+
+def pos_to_neg_ratio(samples: Sequence[GraphSample]) -> float:
+    """train.py:181: dataset mean of #(y==1)/#(y==0)."""
+    r = [((s.y == 1).sum() / (s.y == 0).sum()) for s in samples]
+    return float(torch.stack(r).mean().item())
+
+
+@dataclass
+class History:
+    loss_train: List[float] = field(default_factory=list)
+    loss_valid: List[float] = field(default_factory=list)
+    lr: List[float] = field(default_factory=list)
+    metrics_train: List[tuple] = field(default_factory=list)
+    metrics_valid: List[tuple] = field(default_factory=list)
+
+
+def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSample], out: str = "model",
+          hyperparameters: Optional[Dict] = None, workdir: str = ".", verbose: bool = True):
+    """Full-graph training loop (train.py:232-281,379-529).  Returns (model, best_state_dict, History).
+    Under torch.distributed every rank passes ITS shard of the training graphs (dp.shard_graphs)."""
+    hp = dict(get_hyperparameters())
+    hp.update(hyperparameters or {})
+    seed = hp["seed"]
+    random.seed(seed)
+    torch.manual_seed(seed)                                                     # utils.set_seed
+    dev = train_samples[0].pe.device
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    ratio = pos_to_neg_ratio(train_samples)                                     # train.py:181
+    if world > 1:
+        t = torch.tensor([ratio * len(train_samples), float(len(train_samples))], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        ratio = float(t[0] / t[1])
+    model = models.GraphGatedGCNModel(hp["node_features"], hp["edge_features"], hp["dim_latent"],
+                                      hp["hidden_edge_features"], hp["num_gnn_layers"], hp["hidden_edge_scores"],
+                                      hp["batch_norm"], hp["nb_pos_enc"]).to(dev)                # train.py:195-198
+    if world > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    best_state = copy.deepcopy(model.state_dict())                                              # train.py:203
+    flat = dp.FlatGradients(model.parameters())
+    optimizer = torch.optim.Adam(model.parameters(), lr=hp["lr"])                               # train.py:209
+    criterion = models.BCEWithLogitsLoss(pos_weight=1.0 / ratio)                                # train.py:210-211
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=hp["decay"],
+                                                           patience=hp["patience"])             # train.py:212
+    hist = History()
+    order = list(range(len(train_samples)))
+    model_path = os.path.join(workdir, "pretrained", f"model_{out}.pt")
+    for epoch in range(hp["num_epochs"]):
+        random.shuffle(order)                                                                   # train.py:238
+        model.train()
+        loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
+        counts = torch.zeros(4, device=dev, dtype=torch.int64)
+        for gi in order:
+            s = train_samples[gi]
+            flat.zero_()
+            pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)                                   # train.py:252-253
+            loss = criterion(pred, s.y)
+            loss.backward()
+            flat.all_reduce_mean()
+            optimizer.step()                                                                    # train.py:256-258
+            loss_sum += loss.detach().double()
+            counts += tfpn_counts(pred.detach(), s.y)
+        n_train = torch.tensor(float(len(order)), device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(loss_sum); dist.all_reduce(n_train); dist.all_reduce(counts)        # noqa: E702
+        train_loss = float(loss_sum / n_train)
+        hist.loss_train.append(train_loss)
+        hist.metrics_train.append(calculate_metrics(*[int(c) for c in counts.tolist()]))
+        # ---- validation (train.py:385-511): eval mode, no_grad, no activations kept ----
+        model.eval()
+        vloss = torch.zeros((), device=dev, dtype=torch.float64)
+        vcounts = torch.zeros(4, device=dev, dtype=torch.int64)
+        with torch.no_grad():
+            for s in valid_samples:
+                pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)
+                vloss += criterion(pred, s.y).double()
+                vcounts += tfpn_counts(pred, s.y)
+        n_val = torch.tensor(float(len(valid_samples)), device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(vloss); dist.all_reduce(n_val); dist.all_reduce(vcounts)            # noqa: E702
+        val_loss = float(vloss / n_val.clamp(min=1))
+        hist.loss_valid.append(val_loss)
+        hist.metrics_valid.append(calculate_metrics(*[int(c) for c in vcounts.tolist()]) if int(vcounts.sum()) else None)
+        hist.lr.append(optimizer.param_groups[0]["lr"])
+        if len(hist.loss_valid) > 1 and hist.loss_valid[-1] < min(hist.loss_valid[:-1]):        # train.py:525-527
+            best_state = copy.deepcopy(model.state_dict())
+            if rank == 0:
+                os.makedirs(os.path.dirname(model_path), exist_ok=True)
+                torch.save(best_state, model_path)
+        if rank == 0:
+            save_checkpoint(epoch, model, optimizer, train_loss, val_loss, out, os.path.join(workdir, "checkpoints"))
+        scheduler.step(val_loss)                                                                # train.py:529
+        if verbose and rank == 0:
+            print(f"epoch {epoch}: train loss {train_loss:.4f}  valid loss {val_loss:.4f}  lr {hist.lr[-1]:.2e}")
+    return model, best_state, hist

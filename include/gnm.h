@@ -226,6 +226,18 @@ int gnm_reduce_partials(const double* partials, int nblk, int rows, int W, float
 int gnm_seg_sum_rows(int64_t N, int W, const float* X, const int32_t* ptr, const int32_t* pos,
                      float* out, int64_t ldo, void* stream);
 
+/* ---- input feature preparation ("next" row: utils.py:67-74, 97-138; train.py:245-251) -------------
+ * pagerank_pe: pe[N, 2+pe_dim] = in_deg | out_deg | pe_dim PageRank steps (alpha = 0.95 in the
+ *              reference), fp64 iterate, from the graph index.  ws: gnm_pagerank_pe_workspace_bytes(N).
+ * edge_feats_zscore: e[E,2] = z-scored (overlap_length, overlap_similarity), unbiased std, in the
+ *              caller's edge-id order.  ws: 4 * gnm_max_partial_blocks() doubles.                    */
+size_t gnm_pagerank_pe_workspace_bytes(int64_t N);
+int gnm_pagerank_pe(int64_t N, int64_t E, const int32_t* isrc, const int32_t* in_ptr,
+                    const int32_t* out_ptr, int pe_dim, double alpha, float* pe, void* ws,
+                    size_t ws_bytes, void* stream);
+int gnm_edge_feats_zscore(int64_t E, const float* overlap_length, const float* overlap_similarity,
+                          float* e, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- loss (train.py:210-211,253-255): BCEWithLogitsLoss(pos_weight), mean ---------------
  * loss_out[0] = mean_k(pw*y*softplus(-x) + (1-y)*softplus(x)); gscore = dloss/dx.
  * ws: double[gnm_max_partial_blocks()] */

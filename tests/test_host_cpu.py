@@ -115,3 +115,18 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.replace("CPU oracle", ""), f
+
+
+def test_harness_metrics_match_reference_definitions():
+    """tfpn_counts == utils.calculate_tfpn, calculate_metrics keeps the reference's (swapped) naming
+    (utils.py:217-240); golden TP/TN/FP/FN of the reference run are in the fixtures."""
+    import numpy as np
+    from gnnome_assembly_amd import train as T
+    z = np.load(os.path.join(REPO, "tests", "golden", "tiny_h64l1_s0.npz"))
+    pred = torch.from_numpy(z["scores64"]).reshape(-1)
+    y = torch.from_numpy(z["y"]).double()
+    assert T.tfpn_counts(pred, y).tolist() == [int(v) for v in z["tfpn"]]
+    TP, TN, FP, FN = (int(v) for v in z["tfpn"])
+    assert np.allclose(T.calculate_metrics(TP, TN, FP, FN), z["metrics"])
+    assert T.calculate_metrics(0, 5, 0, 0) == (1.0, 0, 0, 0)
+    assert abs(T.get_hyperparameters()["decay"] - 0.95) < 1e-12
