@@ -169,9 +169,16 @@ def _bn_bwd(gy, xh, w, rstd):
     return gx, gg, gb
 
 
-def manual_forward_backward(sd, src, dst, n, e_raw, pe, y, pos_weight, keep=False):
+def manual_forward_backward(sd, src, dst, n, e_raw, pe, y, pos_weight, keep=False, masks=None):
     """Forward + hand-derived backward (BatchNorm mode).  Returns (scores, loss, grads[, dbg])
-    with grads keyed like the state_dict.  Mirrors SURVEY.md section 8a row 8."""
+    with grads keyed like the state_dict.  Mirrors SURVEY.md section 8a row 8.
+
+    `masks` (optional) overrides the relu branch decisions of the backward pass:
+    {"u": [L x bool[E,H]], "w": [L x bool[N,H]], "hid": bool[E,HS], "a1": bool[E,Q]} in edge-id /
+    node order.  The network is piecewise linear in those branches; an fp32 evaluation may land on
+    the other side of a kink for pre-activations within rounding distance of zero, and then the
+    exact gradient OF THE BRANCH TAKEN is the meaningful reference (tests pass the device's own
+    decisions here)."""
     src = src.long()
     dst = dst.long()
     L = num_layers_of(sd)
@@ -218,7 +225,7 @@ def manual_forward_backward(sd, src, dst, n, e_raw, pe, y, pos_weight, keep=Fals
     gs = ((-pos_weight * y * (1.0 - pr) + (1.0 - y) * pr) / E).reshape(-1, 1)   # dloss/dlogit
     g["predictor.W2.weight"] = gs.t() @ r
     g["predictor.W2.bias"] = gs.sum(0)
-    ghid = (gs @ sd["predictor.W2.weight"]) * (hid > 0)
+    ghid = (gs @ sd["predictor.W2.weight"]) * (masks["hid"] if masks else (hid > 0))
     g["predictor.W1.bias"] = ghid.sum(0)
     gPs = _seg_sum(src, ghid, n)
     gPd = _seg_sum(dst, ghid, n)
@@ -228,7 +235,7 @@ def manual_forward_backward(sd, src, dst, n, e_raw, pe, y, pos_weight, keep=Fals
     for i in reversed(range(L)):
         p = f"gnn.convs.{i}."
         s = saved[i]
-        gw = gh * (s["w"] > 0)
+        gw = gh * (masks["w"][i] if masks else (s["w"] > 0))
         gz, g[p + "bn_h.weight"], g[p + "bn_h.bias"] = _bn_bwd(gw, s["zh"], sd[p + "bn_h.weight"], s["rstd_h"])
         Qf = gz * s["inv_f"]
         Rf = Qf * s["hf"]
@@ -239,7 +246,7 @@ def manual_forward_backward(sd, src, dst, n, e_raw, pe, y, pos_weight, keep=Fals
         gA2h = _seg_sum(src, sig * Qf[dst], n)
         gA3h = _seg_sum(dst, sig * Qb[src], n)
         ge_tot = ge + gsig * sig * (1.0 - sig)
-        gu = ge_tot * (s["u"] > 0)
+        gu = ge_tot * (masks["u"][i] if masks else (s["u"] > 0))
         gt, g[p + "bn_e.weight"], g[p + "bn_e.bias"] = _bn_bwd(gu, s["th"], sd[p + "bn_e.weight"], s["rstd_e"])
         gB1h = _seg_sum(src, gt, n)
         gB2h = _seg_sum(dst, gt, n)
@@ -261,7 +268,7 @@ def manual_forward_backward(sd, src, dst, n, e_raw, pe, y, pos_weight, keep=Fals
     g["linear_pe.bias"] = gh.sum(0)
     g["linear2_edge.weight"] = ge.t() @ a1
     g["linear2_edge.bias"] = ge.sum(0)
-    ga1 = (ge @ sd["linear2_edge.weight"]) * (a1_pre > 0)
+    ga1 = (ge @ sd["linear2_edge.weight"]) * (masks["a1"] if masks else (a1_pre > 0))
     g["linear1_edge.weight"] = ga1.t() @ e_raw
     g["linear1_edge.bias"] = ga1.sum(0)
     if keep:
