@@ -34,6 +34,7 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 F32_MFMA_PEAK = 157.3e12   # FLOP/s
+BF16_MFMA_PEAK = 2516.6e12 # FLOP/s dense; the bf16x3 mode spends 6 bf16 MACs per fp32 MAC
 
 
 def parse():
@@ -48,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-reads", type=int, default=75_000)
     ap.add_argument("--inference", action="store_true", help="forward only under no_grad (config 5)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
+    ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3"],
+                    help="fused-kernel matmul mode (default: GNM_MATMUL or f32); see include/gnm.h")
+    ap.add_argument("--no-alt-matmul", action="store_true", help="skip the extra bf16x3-mode measurement")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores)")
     return ap.parse_args()
 
@@ -217,6 +221,8 @@ def main():
     dev = torch.device("cuda", local)
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import synth, engine, dp
+    if args.matmul:
+        G._lib.set_matmul_mode(args.matmul)
     if world > 1:
         dp.init_process_group(os.environ.get("GNM_BENCH_BACKEND", "nccl"))
         dbg("process group up")
@@ -254,27 +260,30 @@ def main():
         step()
     torch.cuda.synchronize()
     dbg("warmup done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def timed_run(nsteps):
+        """EXACTLY nsteps steps between barrier + synchronize on both sides; max over ranks."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        tt = torch.tensor([dt_, float(E)], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = tt[0:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            esum = tt[1:2].clone()
+            dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+            return float(tmax.item()), float(esum.item())
+        return dt_, float(E)
+
+    dt, total_edges = timed_run(args.steps)
     dbg(f"timed region done {dt:.3f}s")
-    tt = torch.tensor([dt, float(E)], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = tt[0:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        esum = tt[1:2].clone()
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
-        dt, total_edges = float(tmax.item()), float(esum.item())
-    else:
-        total_edges = float(E)
     ms = dt / args.steps * 1e3
     value = total_edges * args.steps / dt
 
@@ -285,6 +294,18 @@ def main():
     step()
     ops = engine.profile_ops(False) if rank == 0 else None
     dbg("profile step done")
+    # the opt-in split-precision matmul mode (include/gnm.h), measured the same way right after the
+    # default run; reported beside `value`, never as `value`
+    alt = None
+    if args.matmul is None and G._lib.get_matmul_mode() == "f32" and H == 128 and not args.no_alt_matmul:
+        G._lib.set_matmul_mode("bf16x3")
+        step()
+        adt, aedges = timed_run(args.steps)
+        G._lib.set_matmul_mode("f32")
+        alt = {"matmul": "bf16x3", "ms_per_step": adt / args.steps * 1e3, "value": aedges * args.steps / adt,
+               "unit": "edges/s", "note": "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, "
+                                          "fp32 accumulate; same parity bars (tests/test_gpu_bf16x3.py)"}
+        dbg("alt matmul run done")
     res = None
     if rank == 0:
         tot = sum(t for _, t in ops.values())
@@ -293,9 +314,10 @@ def main():
         ab, fl = op_model(dom, n, E, H)
         avg_s = dt_ms / dc / 1e3
         t_hbm = (ab or 0.0) / HBM_PEAK            # time the launch would take at the HBM roofline
-        t_mfma = (fl or 0.0) / F32_MFMA_PEAK      # ... at the fp32 matrix-core roofline
+        mm_peak = BF16_MFMA_PEAK / 6 if G._lib.get_matmul_mode() == "bf16x3" else F32_MFMA_PEAK
+        t_mfma = (fl or 0.0) / mm_peak            # ... at the matrix-core roofline of the matmul mode
         if t_mfma > t_hbm:
-            roof = {"kernel": dom, "bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": F32_MFMA_PEAK / 1e12,
+            roof = {"kernel": dom, "bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": mm_peak / 1e12,
                     "unit": "TFLOP/s", "frac": t_mfma / avg_s, "traffic": None}
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": (ab or 0.0) / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
@@ -325,7 +347,8 @@ def main():
                                    f"E={E} edges, hidden={H}, layers={L}, BCE fwd+bwd + Adam"
                                    + (", RCCL grad all-reduce" if world > 1 else ""),
                        "reads": R, "nodes": n, "edges": E, "hidden": H, "layers": L,
-                       "parallelism": f"dp{world}", "edge_layers_per_s": value * L},
+                       "parallelism": f"dp{world}", "edge_layers_per_s": value * L,
+                       "matmul": G._lib.get_matmul_mode()},
             "roofline": roof,
             "step_hbm_roofline_frac": step_frac,
             "algorithmic_bytes_per_edge_step": per_edge,
@@ -333,6 +356,8 @@ def main():
             "op_total_ms": round(tot, 3),
             "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         }
+        if alt:
+            res["alt_matmul"] = alt
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(res), flush=True)

@@ -47,6 +47,8 @@ SIGNATURES = {
     "gnm_ln_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_ln_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_rowtile_workspace_bytes": (_sz, [_i32]),
+    "gnm_set_matmul_mode": (_i32, [_i32]),
+    "gnm_get_matmul_mode": (_i32, []),
     "gnm_edge_t_fused_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),
     "gnm_node_proj_fwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_workspace_bytes": (_sz, [_i32]),
@@ -92,7 +94,26 @@ def load():
     if v != 1:
         raise GnmError(f"libgnm.so ABI version {v}, expected 1")
     _lib = lib
+    mode = os.environ.get("GNM_MATMUL", "").strip().lower()
+    if mode:                                     # opt-in split-precision matmul (see gnm.h)
+        if mode not in MATMUL_MODES:
+            raise GnmError(f"GNM_MATMUL={mode!r}: expected one of {sorted(MATMUL_MODES)}")
+        check(lib.gnm_set_matmul_mode(MATMUL_MODES[mode]), "gnm_set_matmul_mode")
     return lib
+
+
+MATMUL_MODES = {"f32": 0, "fp32": 0, "bf16x3": 1}
+
+
+def set_matmul_mode(mode: str) -> None:
+    """'f32' (default: fp32 MFMA) or 'bf16x3' (exact 3-way bf16 split, six bf16 MFMAs per product)."""
+    if mode not in MATMUL_MODES:
+        raise GnmError(f"matmul mode {mode!r}: expected one of {sorted(MATMUL_MODES)}")
+    check(load().gnm_set_matmul_mode(MATMUL_MODES[mode]), "gnm_set_matmul_mode")
+
+
+def get_matmul_mode() -> str:
+    return "bf16x3" if load().gnm_get_matmul_mode() == 1 else "f32"
 
 
 def check(rc: int, what: str = ""):

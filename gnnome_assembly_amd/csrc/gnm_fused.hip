@@ -129,24 +129,286 @@ __device__ __forceinline__ void acc_to_lds(float* __restrict__ o, const floatx16
 __device__ __forceinline__ int64_t clampi(int64_t r, int64_t hi) { return r < hi ? r : hi; }
 
 // ------------------------------------------------------------------------------------------
+// Matmul policies of the row-tile kernels (how a 64 x 128 fp32 tile meets a 128 x 32 weight block)
+//
+//   MmF32   v_mfma_f32_32x32x2_f32 on the fp32 tile image (the default).
+//   MmB3    fp32 x fp32 as SIX bf16 MFMAs (v_mfma_f32_32x32x16_bf16, 8x the fp32 rate):
+//           x = x1 + x2 + x3 exactly, with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+//           (3 x 8 significand bits = fp32's 24), every product x_i * w_j is exact in the fp32
+//           accumulator, and the three products below 2^-24 |x w| (x2 w3, x3 w2, x3 w3) are
+//           dropped -- the same order as ONE fp32 rounding of the product.  Accumulation stays
+//           fp32.  Opt-in (gnm_set_matmul_mode(1)); inf inputs give NaN (inf - inf in the split).
+// A policy stages tile rows into its LDS image(s), keeps this wave's weight block as fragments in
+// VGPRs, and accumulates rows 0-31 / 32-63 of the tile into acc0 / acc1.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BP = FH + 8;          // bf16 image row pitch (272 B): ds_read_b128 fragment reads conflict-free
+constexpr int BIMG = FTR * BP;      // elements per bf16 image
+constexpr int BKC = FH / 16;        // 8 k-chunks of 16
+
+struct MmF32 {
+  static constexpr int kImgBytes = FTR * FP * 4;
+  static constexpr bool kSplit = false;
+  static constexpr size_t kPackBytes = (size_t)FKQ * 64 * 16;        // per 32-column weight block
+  static constexpr int kTnBytes = 2 * FTR * FP * 4;                  // TN operands: two fp32 row images
+  // tile row of the it-th float4 of thread-row lrow in the coalesced image
+  static __device__ __forceinline__ int row(int lrow, int it) { return lrow + 8 * it; }
+  struct Frag { float4 w[FKQ]; };
+  static __device__ __forceinline__ void load_w(Frag& f, const void* Wp, int blk, int lane) {
+    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)blk * FKQ) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < FKQ; ++q) f.w[q] = p[q * 64];
+  }
+  static __device__ __forceinline__ void stage(void* img, int row, int c4, const float4& v) {
+    st4(reinterpret_cast<float*>(img) + row * FP + c4, v);
+  }
+  static __device__ __forceinline__ void mma(const void* img, const Frag& f, floatx16& acc0, floatx16& acc1,
+                                             int li, int lg) {
+    mma_tile64(reinterpret_cast<const float*>(img), f.w, acc0, acc1, li, lg);
+  }
+};
+
+__device__ __forceinline__ void split3(const float4& v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r1 = x[j] - (float)h;      // exact
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;        // exact, fits 8 bits
+    hi[j] = h;
+    mid[j] = m;
+    lo[j] = (__bf16)r2;
+  }
+}
+
+__device__ __forceinline__ void mfb(floatx16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+struct MmB3 {
+  static constexpr int kImgBytes = 3 * BIMG * 2;
+  static constexpr bool kSplit = true;
+  static constexpr size_t kPackBytes = (size_t)BKC * 3 * 64 * 16;
+  static constexpr int kTnBytes = 2 * 3 * (FH * (FTR + 8)) * 2;      // TN operands: two transposed split images
+  static __device__ __forceinline__ int row(int lrow, int it) { return 8 * lrow + it; }   // see stage_cols
+  struct Frag { bf16x8 w[BKC][3]; };
+  static __device__ __forceinline__ void load_w(Frag& f, const void* Wp, int blk, int lane) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(Wp) + ((int64_t)blk * BKC * 3) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < BKC; ++c)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) f.w[c][s] = p[(c * 3 + s) * 64];
+  }
+  static __device__ __forceinline__ void stage(void* img, int row, int c4, const float4& v) {
+    bf16x4 hi, mid, lo;
+    split3(v, hi, mid, lo);
+    __bf16* b = reinterpret_cast<__bf16*>(img) + row * BP + c4;
+    *reinterpret_cast<bf16x4*>(b) = hi;
+    *reinterpret_cast<bf16x4*>(b + BIMG) = mid;
+    *reinterpret_cast<bf16x4*>(b + 2 * BIMG) = lo;
+  }
+  // lane (i, g) of chunk c holds k = 16c + 8g .. +7 of row i (A) / of weight column i (B)
+  static __device__ __forceinline__ void mma(const void* img, const Frag& f, floatx16& acc0, floatx16& acc1,
+                                             int li, int lg) {
+    const __bf16* p0 = reinterpret_cast<const __bf16*>(img) + li * BP + 8 * lg;
+    const __bf16* p1 = p0 + 32 * BP;
+    bf16x8 a0[3], a1[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      a0[s] = *reinterpret_cast<const bf16x8*>(p0 + s * BIMG);
+      a1[s] = *reinterpret_cast<const bf16x8*>(p1 + s * BIMG);
+    }
+#pragma unroll
+    for (int c = 0; c < BKC; ++c) {
+      bf16x8 n0[3], n1[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        n0[s] = a0[s];
+        n1[s] = a1[s];
+        if (c + 1 < BKC) {
+          n0[s] = *reinterpret_cast<const bf16x8*>(p0 + s * BIMG + 16 * (c + 1));
+          n1[s] = *reinterpret_cast<const bf16x8*>(p1 + s * BIMG + 16 * (c + 1));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+      mfb(acc0, a0[2], f.w[c][0]); mfb(acc1, a1[2], f.w[c][0]);
+      mfb(acc0, a0[0], f.w[c][2]); mfb(acc1, a1[0], f.w[c][2]);
+      mfb(acc0, a0[1], f.w[c][1]); mfb(acc1, a1[1], f.w[c][1]);
+      mfb(acc0, a0[1], f.w[c][0]); mfb(acc1, a1[1], f.w[c][0]);
+      mfb(acc0, a0[0], f.w[c][1]); mfb(acc1, a1[0], f.w[c][1]);
+      mfb(acc0, a0[0], f.w[c][0]); mfb(acc1, a1[0], f.w[c][0]);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { a0[s] = n0[s]; a1[s] = n1[s]; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// ---- split TN: C[n][c] += sum_row A[row][n] B[row][c], both operands transposed into bf16 images ----
+// A thread of the coalesced tile image owns rows 8*lrow .. +7 x columns lc4 .. +3 (MmB3::row), i.e. for
+// each of its 4 columns 8 CONSECUTIVE contraction indices = one bf16x8 = one ds_write_b128 into the
+// column-major image T[s][slot][row], pitch TP = 72 (9 sixteen-byte units: 16 neighbouring slots hit 16
+// different bank groups).  Neighbouring lanes of the tile image are 4 columns apart, so column c is
+// kept in slot 32*(c & 3) + (c >> 2): the j-th write of lanes 0..31 then goes to 32 consecutive slots
+// (conflict-free; measured 2.5x faster than slot = column), and a fragment read of slots
+// 32*blk .. +31 is conflict-free too.  The price is only a permuted result: MFMA block blk, index i
+// stands for column 4*i + blk (tn_store_slab).
+constexpr int TP = FTR + 8;
+constexpr int TIMG = FH * TP;
+
+struct Split8 { bf16x4 hi[8], mid[8], lo[8]; };   // 8 rows x 4 columns, split
+
+__device__ __forceinline__ void split_rows(const float4 (&v)[8], Split8& s) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) split3(v[it], s.hi[it], s.mid[it], s.lo[it]);
+}
+__device__ __forceinline__ void stage_rows(void* img, int lrow, int lc4, const Split8& s) {
+  __bf16* b = reinterpret_cast<__bf16*>(img) + (8 * lrow) * BP + lc4;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    *reinterpret_cast<bf16x4*>(b + it * BP) = s.hi[it];
+    *reinterpret_cast<bf16x4*>(b + it * BP + BIMG) = s.mid[it];
+    *reinterpret_cast<bf16x4*>(b + it * BP + 2 * BIMG) = s.lo[it];
+  }
+}
+__device__ __forceinline__ void stage_cols(void* timg, int lrow, int lc4, const Split8& s) {
+  __bf16* b = reinterpret_cast<__bf16*>(timg) + (lc4 >> 2) * TP + 8 * lrow;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { h[it] = s.hi[it][j]; m[it] = s.mid[it][j]; l[it] = s.lo[it][j]; }
+    *reinterpret_cast<bf16x8*>(b + j * 32 * TP) = h;
+    *reinterpret_cast<bf16x8*>(b + j * 32 * TP + TIMG) = m;
+    *reinterpret_cast<bf16x8*>(b + j * 32 * TP + 2 * TIMG) = l;
+  }
+}
+// this wave's 64 x 64 block (wn, wc) of the 128 x 128 result, contraction over the tile's 64 rows
+template <bool PIPE>
+__device__ __forceinline__ void mma_tn64_b3(const void* ta, const void* tb, floatx16 (&tn)[2][2], int wn, int wc,
+                                            int li, int lg) {
+  const __bf16* pa = reinterpret_cast<const __bf16*>(ta) + ((2 * wn) * 32 + li) * TP + 8 * lg;
+  const __bf16* pb = reinterpret_cast<const __bf16*>(tb) + ((2 * wc) * 32 + li) * TP + 8 * lg;
+  bf16x8 a[2][3], b[2][3];
+  auto load = [&](int kc, bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        fa[x][s_] = *reinterpret_cast<const bf16x8*>(pa + s_ * TIMG + x * 32 * TP + 16 * kc);
+        fb[x][s_] = *reinterpret_cast<const bf16x8*>(pb + s_ * TIMG + x * 32 * TP + 16 * kc);
+      }
+  };
+  load(0, a, b);
+#pragma unroll
+  for (int kc = 0; kc < FTR / 16; ++kc) {
+    bf16x8 na[2][3], nb[2][3];
+    if (PIPE && kc + 1 < FTR / 16) load(kc + 1, na, nb);   // PIPE: next chunk's fragments under these MFMAs (+48 VGPRs)
+    if (!PIPE && kc > 0) load(kc, a, b);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t_ = 0; t_ < 6; ++t_) {
+      // (A part, B part): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+      const int sa = t_ == 0 ? 2 : (t_ == 2 || t_ == 3) ? 1 : 0;
+      const int sb = t_ == 1 ? 2 : (t_ == 2 || t_ == 4) ? 1 : 0;
+      mfb(tn[0][0], a[0][sa], b[0][sb]);
+      mfb(tn[0][1], a[0][sa], b[1][sb]);
+      mfb(tn[1][0], a[1][sa], b[0][sb]);
+      mfb(tn[1][1], a[1][sa], b[1][sb]);
+    }
+    if (PIPE && kc + 1 < FTR / 16) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) { a[x][s_] = na[x][s_]; b[x][s_] = nb[x][s_]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// this wave's 64 x 64 block of the TN result -> sl[n][c] (128 x 128, row-major)
+template <class MM>
+__device__ __forceinline__ void tn_store_slab(float* __restrict__ sl, const floatx16 (&tn)[2][2], int wn, int wc,
+                                              int li, int lg) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * lg;
+        const int n = MM::kSplit ? 4 * i + (2 * wn + a) : (2 * wn + a) * 32 + i;     // see stage_cols
+        const int c = MM::kSplit ? 4 * li + (2 * wc + b) : (2 * wc + b) * 32 + li;
+        sl[n * FH + c] = tn[a][b][e];
+      }
+}
+
+// Split-bf16 fragment pack: Wp3[cb][c][s][lane] (bf16x8), s = hi/mid/lo;
+//   NT: element j of lane (i,g) = W[(cb*32 + i) * ld + 16c + 8g + j];  NN: W[(16c + 8g + j) * ld + cb*32 + i]
+__global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int nn, bf16x8* __restrict__ Wp) {
+  const int total = ncb * BKC * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % BKC, cb = idx / (64 * BKC);
+    const int i = lane & 31, g = lane >> 5;
+    bf16x8 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * c + 8 * g + j;
+      const float x = nn ? W[(int64_t)k * ld + cb * 32 + i] : W[(int64_t)(cb * 32 + i) * ld + k];
+      const __bf16 h = (__bf16)x;
+      const float r1 = x - (float)h;
+      const __bf16 m = (__bf16)r1;
+      hi[j] = h;
+      mid[j] = m;
+      lo[j] = (__bf16)(r1 - (float)m);
+    }
+    bf16x8* o = Wp + ((int64_t)(cb * BKC + c) * 3) * 64 + lane;
+    o[0] = hi;
+    o[64] = mid;
+    o[128] = lo;
+  }
+}
+
+static int g_matmul_mode = 0;   // 0: exact fp32 MFMA, 1: bf16x3 split
+constexpr size_t kPackBytesPerBlk = MmB3::kPackBytes;   // workspace sizing: the larger of the two
+
+template <class MM>
+static void launch_pack(const float* W, int64_t ld, int ncb, int nn, void* wp, hipStream_t st) {
+  if (MM::kSplit) hipLaunchKernelGGL(pack_w3_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (bf16x8*)wp);
+  else hipLaunchKernelGGL(pack_w_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (float*)wp);
+}
+
+// ------------------------------------------------------------------------------------------
 // Y[:, cg*128 + c] = X W_cg^T + bias   (+ gathers and column statistics when EDGE)
 // One workgroup per CU = one wave per SIMD with the whole 512-entry register file.
 // ------------------------------------------------------------------------------------------
 // NCG (number of 128-column groups) is a template parameter so that the column-group loop unrolls:
 // a loop with a run-time trip count around the stores would defeat the vmcnt counting below.
-template <bool EDGE, int NCG>
-__global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
-    int64_t M, const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
+template <class MM, bool EDGE, int NCG>
+__global__ __launch_bounds__(kBlock, (MM::kSplit && !EDGE && NCG == 1) ? 2 : 1) void rowtile_nt_k(
+    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ Y, int64_t ldy, const float* __restrict__ P,
     const int32_t* __restrict__ isrc, const int32_t* __restrict__ idst, double* __restrict__ partials,
-    int64_t tiles_per_block) {
-  __shared__ float xs[FTR * FP];
-  __shared__ float ys[EDGE ? 4 : FTR * FP];   // node mode: output image (X is reused by 5 column groups)
+    int64_t tiles_per_block, int ncgs) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];   // X tile image(s)
+  constexpr bool INPLACE = EDGE || NCG == 1;  // the output image may overwrite the X image
+  __shared__ float ys[INPLACE ? 4 : FTR * FP];   // node mode: output image (X is reused by 5 column groups)
   __shared__ int sd[2 * FTR];
+  float* xs = reinterpret_cast<float*>(xraw);   // edge mode: reused as the fp32 output image
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
-  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  // ncgs > 1: the output's 128-column groups are spread over workgroups (weights stay in VGPRs for
+  // the whole run); the ncgs workgroups of a row range sit on one XCD and share the X tiles in its L2.
+  int chunk = xcd_chunk(blockIdx.x, gridDim.x), cgb = 0;
+  if (ncgs > 1) {
+    const int xcd = blockIdx.x % kXcds, j = blockIdx.x / kXcds;
+    cgb = j % ncgs;
+    chunk = xcd * (gridDim.x / ncgs / kXcds) + j / ncgs;
+  }
   const int64_t ntiles = (M + FTR - 1) / FTR;
   const int64_t tb0 = (int64_t)chunk * tiles_per_block;
   const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
@@ -154,12 +416,8 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
   const int lrow = tid >> 5, lc4 = (tid & 31) * 4;   // this thread's slot in the coalesced tile image
   const int64_t Mlast = M - 1;
 
-  float4 wf[FKQ];
-  auto load_w = [&](int cg) __attribute__((always_inline)) {
-    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)(cg * 4 + wave) * FKQ) * 64 + lane;
-#pragma unroll
-    for (int q = 0; q < FKQ; ++q) wf[q] = p[q * 64];
-  };
+  typename MM::Frag wf;
+  auto load_w = [&](int cg) __attribute__((always_inline)) { MM::load_w(wf, Wp, (cgb + cg) * 4 + wave, lane); };
   constexpr int ncg = NCG;
   if (ncg == 1) load_w(0);
 
@@ -182,7 +440,7 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
     constexpr bool FULL = decltype(tag)::value;
     __syncthreads();   // everyone is done with the previous tile's LDS images
 #pragma unroll
-    for (int it = 0; it < 8; ++it) st4(xs + (lrow + 8 * it) * FP + lc4, pre[it]);
+    for (int it = 0; it < 8; ++it) MM::stage(xraw, lrow + 8 * it, lc4, pre[it]);
     if (EDGE && tid < 2 * FTR) sd[tid] = pre_idx;
     __syncthreads();
     const int64_t r0 = tile * FTR;
@@ -204,13 +462,13 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
       floatx16 acc0, acc1;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-      mma_tile64(xs, wf, acc0, acc1, li, lg);
-      float* os = EDGE ? xs : ys;
-      if (EDGE) __syncthreads();            // all waves are done reading the X image
+      MM::mma(xraw, wf, acc0, acc1, li, lg);
+      float* os = INPLACE ? xs : ys;
+      if (INPLACE) __syncthreads();         // all waves are done reading the X image
       else if (cg > 0) __syncthreads();     // previous column group's epilogue is done with ys
       acc_to_lds(os, acc0, acc1, wave, li, lg);
       __syncthreads();
-      const float4 b4 = ld4(bias + cg * FH + lc4);
+      const float4 b4 = ld4(bias + (cgb + cg) * FH + lc4);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = lrow + 8 * it;
@@ -218,7 +476,7 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
         float4 v = ld4(os + row * FP + lc4) + b4;
         if (EDGE) v = v + g1[it] + g2[it];
         if (FULL || grow < M) {
-          st4(Y + grow * ldy + cg * FH + lc4, v);
+          st4(Y + grow * ldy + (cgb + cg) * FH + lc4, v);
           if (EDGE) st.add_prod(v, v);
         }
       }
@@ -230,7 +488,7 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
     // throw-away stores behind the first prefetch (same addresses the first epilogue rewrites):
     // they make the loop-entry scoreboard equal to the back edge's, see edge_bwd_fused_k
 #pragma unroll
-    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * ldy + lc4, f4(0.f));
+    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * ldy + cgb * FH + lc4, f4(0.f));
     for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
   }
   if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
@@ -243,16 +501,23 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nt_k(
 // ------------------------------------------------------------------------------------------
 // fused edge backward: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
 // ------------------------------------------------------------------------------------------
+template <class MM>
 __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
     int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
     const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
-    const float* __restrict__ Wp,                    // W3 packed NN
+    const void* __restrict__ Wp,                     // W3 packed NN
     float* __restrict__ slab,                        // [grid][128][128] partial gW3
     double* __restrict__ partials,                   // [grid][128]: per-workgroup column sums of gt
     int64_t tiles_per_block) {
-  __shared__ float gs[FTR * FP];       // gt tile, later the transposed output image
-  __shared__ float es[FTR * FP];       // e_in tile
-  __shared__ float cs[7 * FH];         // mu, rstd, scale, shift, m1, m2, c = gamma*rstd
+  // fp32 mode:  [gt row image | e_in row image]                      (the gt image doubles as the NN operand)
+  // split mode: [gt split row images (NN) | gt transposed split | e_in transposed split]   = 159 KB
+  constexpr int kNnBytes = MM::kSplit ? MM::kImgBytes : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kNnBytes + MM::kTnBytes];
+  float* gs = reinterpret_cast<float*>(raw + kNnBytes);          // fp32 mode
+  float* es = gs + FTR * FP;
+  unsigned char* tg = raw + kNnBytes;                            // split mode
+  unsigned char* te = tg + MM::kTnBytes / 2;
+  float* os = reinterpret_cast<float*>(raw);                     // transposed output image (after the MFMAs)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -265,21 +530,12 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
   const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
   const int64_t Elast = E - 1;
 
-  for (int c = tid; c < FH; c += kBlock) {
-    cs[c] = stat[c];
-    cs[FH + c] = stat[FH + c];
-    cs[2 * FH + c] = stat[2 * FH + c];
-    cs[3 * FH + c] = stat[3 * FH + c];
-    cs[4 * FH + c] = bstat[c];
-    cs[5 * FH + c] = bstat[FH + c];
-    cs[6 * FH + c] = gamma[c] * stat[FH + c];
-  }
-  float4 wf[FKQ];
-  {
-    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)wave * FKQ) * 64 + lane;
-#pragma unroll
-    for (int q = 0; q < FKQ; ++q) wf[q] = p[q * 64];
-  }
+  // per-column constants of this thread's 4 columns: mu, rstd, scale, shift, m1, m2, c = gamma*rstd
+  const float4 mu = ld4(stat + lc4), rs = ld4(stat + FH + lc4), sc = ld4(stat + 2 * FH + lc4),
+               sh = ld4(stat + 3 * FH + lc4), m1 = ld4(bstat + lc4), m2 = ld4(bstat + FH + lc4),
+               cc = ld4(gamma + lc4) * rs;
+  typename MM::Frag wf;
+  MM::load_w(wf, Wp, wave, lane);
   floatx16 tn[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -288,7 +544,6 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
 #pragma unroll
       for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
   double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;   // column sums of gt for columns lc4..lc4+3
-  __syncthreads();
 
   // ge / t / e_in rows of a tile are prefetched one tile ahead (96 VGPRs), under the MFMA phases
   float4 pg[8], pt[8], pe_[8];
@@ -296,7 +551,7 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
     const int64_t r0 = tile * FTR;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int64_t o = clampi(r0 + lrow + 8 * it, Elast) * FH + lc4;
+      const int64_t o = clampi(r0 + MM::row(lrow, it), Elast) * FH + lc4;
       pg[it] = ld4(ge + o);
       pt[it] = ld4(t + o);
       pe_[it] = ld4(e_in + o);
@@ -306,46 +561,59 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
   auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(tag)::value;
     const int64_t r0 = tile * FTR;
-    // ---- phase 0: gt tile and e_in tile into LDS (coalesced float4 image) ----
+    // ---- phase 0: gt tile and e_in tile into LDS ----
     float4 gk[8];   // this tile's ge rows, kept for the residual add in the epilogue
     {
-      const float4 mu = ld4(cs + lc4), rs = ld4(cs + FH + lc4), sc = ld4(cs + 2 * FH + lc4),
-                   sh = ld4(cs + 3 * FH + lc4), m1 = ld4(cs + 4 * FH + lc4), m2 = ld4(cs + 5 * FH + lc4),
-                   cc = ld4(cs + 6 * FH + lc4);
+      float4 gtv[8], evv[8];
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int row = lrow + 8 * it;
-        const bool ok = FULL || (r0 + row < E);
+        const bool ok = FULL || (r0 + MM::row(lrow, it) < E);
         gk[it] = pg[it];
         const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
         float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
         float4 ev = pe_[it];
         if (!ok) { gt = f4(0.f); ev = f4(0.f); }
         cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
-        st4(gs + row * FP + lc4, gt);
-        st4(es + row * FP + lc4, ev);
+        gtv[it] = gt;
+        evv[it] = ev;
+      }
+      if (MM::kSplit) {
+        Split8 sp;
+        split_rows(gtv, sp);
+        stage_rows(raw, lrow, lc4, sp);
+        stage_cols(tg, lrow, lc4, sp);
+        split_rows(evv, sp);
+        stage_cols(te, lrow, lc4, sp);
+      } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          st4(gs + MM::row(lrow, it) * FP + lc4, gtv[it]);
+          st4(es + MM::row(lrow, it) * FP + lc4, evv[it]);
+        }
       }
     }
     __syncthreads();
     prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // in flight under the MFMAs below
-    // ---- phase 1: acc = gt W3   (this wave: output columns wave*32 .. +31) ----
+    // ---- MFMA phases: acc = gt W3 (this wave: output columns wave*32 .. +31) and
+    //      gW3[n][c] += sum_rows gt[row][n] e_in[row][c] (this wave: 64 x 64 block).  Split mode runs
+    //      the TN part first so that acc is not live across it (register budget). ----
     floatx16 acc0, acc1;
+    if (MM::kSplit) mma_tn64_b3<false>(tg, te, tn, wn, wc, li, lg);
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-    mma_tile64(gs, wf, acc0, acc1, li, lg);
-    // ---- phase 2: gW3[n][c] += sum_rows gt[row][n] e_in[row][c]  (this wave: 64 x 64 block) ----
-    mma_tn64(gs, es, tn, wn, wc, li, lg);
-    __syncthreads();   // gt / e_in images are dead: reuse gs as the transposed output image
-    acc_to_lds(gs, acc0, acc1, wave, li, lg);
+    MM::mma(MM::kSplit ? (const void*)raw : (const void*)gs, wf, acc0, acc1, li, lg);
+    if (!MM::kSplit) mma_tn64(gs, es, tn, wn, wc, li, lg);
+    __syncthreads();   // operand images are dead: reuse the front of the buffer as the output image
+    acc_to_lds(os, acc0, acc1, wave, li, lg);
     __syncthreads();
     // ---- ge_in = ge + gt W3, whole 512-byte rows, one float4 per lane ----
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int row = lrow + 8 * it;
+      const int row = MM::row(lrow, it);
       const int64_t grow = r0 + row;
-      if (FULL || grow < E) st4(ge_out + grow * FH + lc4, ld4(gs + row * FP + lc4) + gk[it]);
+      if (FULL || grow < E) st4(ge_out + grow * FH + lc4, ld4(os + row * FP + lc4) + gk[it]);
     }
-    __syncthreads();   // gs is rewritten by the next tile's phase 0
+    __syncthreads();   // the buffer is rewritten by the next tile's phase 0
   };
 
   if (tb0 < tb1) prefetch(tb0);
@@ -360,18 +628,9 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
 
   // ---- write the partial gW3 slab and the column sums ----
   float* sl = slab + (size_t)chunk * FH * FH;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = (2 * wn + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-        const int c = (2 * wc + b) * 32 + li;
-        sl[n * FH + c] = tn[a][b][e];
-      }
-  // 8 row-slots (lrow) x 128 columns -> 128 column sums (the gt tile's LDS is free now)
-  double* red = reinterpret_cast<double*>(gs);
+  tn_store_slab<MM>(sl, tn, wn, wc, li, lg);
+  // 8 row-slots (lrow) x 128 columns -> 128 column sums (the tile images are free now)
+  double* red = reinterpret_cast<double*>(raw);
   red[lrow * FH + lc4 + 0] = cg0;
   red[lrow * FH + lc4 + 1] = cg1;
   red[lrow * FH + lc4 + 2] = cg2;
@@ -390,10 +649,12 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
 //   rowtile_nn_acc_k   gh_in = gh_out + gP W5            (K = 5*128, accumulated over 5 groups)
 //   tn_colgroup_k      gW5[cg] = gP[:,cg]^T h_in, gb5[cg] = sum gP[:,cg]   (5 workgroup classes)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock, 2) void rowtile_nn_acc_k(
-    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const float* __restrict__ Wp,
+template <class MM>
+__global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void rowtile_nn_acc_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const void* __restrict__ Wp,
     const float* __restrict__ R, float* __restrict__ Y, int64_t tiles_per_block) {
-  __shared__ float xs[FTR * FP];
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -420,19 +681,15 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_acc_k(
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
     for (int cg = 0; cg < ncg; ++cg) {
-      float4 wf[FKQ];
-      {
-        const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)(cg * 4 + wave) * FKQ) * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < FKQ; ++q) wf[q] = p[q * 64];
-      }
+      typename MM::Frag wf;
+      MM::load_w(wf, Wp, cg * 4 + wave, lane);
       __syncthreads();   // previous chunk's fragment reads are done
 #pragma unroll
-      for (int it = 0; it < 8; ++it) st4(xs + (lrow + 8 * it) * FP + lc4, pre[it]);
+      for (int it = 0; it < 8; ++it) MM::stage(xraw, lrow + 8 * it, lc4, pre[it]);
       __syncthreads();
       if (cg + 1 < ncg) prefetch(tile, cg + 1);
       else prefetch(tile + 1 < tb1 ? tile + 1 : tile, 0);
-      mma_tile64(xs, wf, acc0, acc1, li, lg);
+      MM::mma(xraw, wf, acc0, acc1, li, lg);
     }
     __syncthreads();
     acc_to_lds(xs, acc0, acc1, wave, li, lg);
@@ -453,18 +710,97 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_acc_k(
   if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
 }
 
+// Split-mode variant: the weight fragments of a column group (96 VGPRs) are loaded once per GROUP of
+// T row tiles whose accumulators stay in registers -- in split mode the MFMAs are cheap enough that
+// re-reading 5 x 96 KB of fragments from L2 for every 64-row tile was the bound.
+template <class MM, int T>
+__global__ __launch_bounds__(kBlock, 1) void rowtile_nn_group_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const void* __restrict__ Wp,
+    const float* __restrict__ R, float* __restrict__ Y, int64_t groups_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ngroups = (M + FTR * T - 1) / (FTR * T);
+  const int64_t g0 = (int64_t)chunk * groups_per_block;
+  const int64_t g1 = min(ngroups, g0 + groups_per_block);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  // Two steps (tile, column group) of rows in flight: with cheap MFMAs one step is shorter than the
+  // HBM latency.  T is even, so the buffer parity of a step is its tile index within the group.
+  static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
+  float4 pre[2][8];
+  auto prefetch = [&](float4 (&buf)[8], int64_t g, int cg, int tl) __attribute__((always_inline)) {
+    if (tl >= T) { tl -= T; ++cg; }
+    if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
+    const int64_t r0 = (g * T + tl) * FTR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) buf[it] = ld4(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  if (g0 < g1) {
+    prefetch(pre[0], g0, 0, 0);
+    prefetch(pre[1], g0, 0, 1);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t t0 = g * T;
+    floatx16 acc[T][2];
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[tl][0][e] = 0.f; acc[tl][1][e] = 0.f; }
+    for (int cg = 0; cg < ncg; ++cg) {
+      typename MM::Frag wf;
+      MM::load_w(wf, Wp, cg * 4 + wave, lane);
+#pragma unroll
+      for (int tl = 0; tl < T; ++tl) {
+        __syncthreads();   // previous fragment reads are done
+#pragma unroll
+        for (int it = 0; it < 8; ++it) MM::stage(xraw, lrow + 8 * it, lc4, pre[tl & 1][it]);
+        __syncthreads();
+        prefetch(pre[tl & 1], g, cg, tl + 2);
+        MM::mma(xraw, wf, acc[tl][0], acc[tl][1], li, lg);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) {
+      const int64_t r0 = (t0 + tl) * FTR;
+      float4 rr[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) rr[it] = ld4(R + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+      __syncthreads();
+      acc_to_lds(xs, acc[tl][0], acc[tl][1], wave, li, lg);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        if (grow < M) st4(Y + grow * FH + lc4, ld4(xs + row * FP + lc4) + rr[it]);
+      }
+    }
+  }
+}
+
 // slab[(cg*nslot + slot)][n][c] = sum over the slot's rows of A[row][cg*128+n] * B[row][c];
 // partials[(cg*nslot + slot)][128] = column sums of A[:, cg*128 ..]
-__global__ __launch_bounds__(kBlock, 2) void tn_colgroup_k(
+template <class MM>
+__global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void tn_colgroup_k(
     int64_t M, const float* __restrict__ A, int64_t lda, int ncg, const float* __restrict__ B,
     float* __restrict__ slab, double* __restrict__ partials, int nslot, int64_t tiles_per_slot) {
-  __shared__ float as[FTR * FP];
-  __shared__ float bs[FTR * FP];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[MM::kTnBytes];
+  float* as = reinterpret_cast<float*>(raw);             // fp32 mode: two row images
+  float* bs = as + FTR * FP;
+  unsigned char* ta = raw;                               // split mode: two transposed images
+  unsigned char* tb = raw + MM::kTnBytes / 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
   const int wn = wave >> 1, wc = wave & 1;
-  const int cg = blockIdx.x % ncg, slot = blockIdx.x / ncg;
+  // The ncg workgroups of a slot read the same B rows: keep them on one XCD (workgroup b runs on XCD
+  // b % 8) so that the tile comes out of that XCD's L2 instead of HBM ncg times.  nslot % 8 == 0.
+  const int xcd = blockIdx.x % kXcds, j = blockIdx.x / kXcds;
+  const int cg = j % ncg, slot = xcd * (nslot / kXcds) + j / ncg;
   const int64_t ntiles = (M + FTR - 1) / FTR;
   const int64_t tb0 = (int64_t)slot * tiles_per_slot;
   const int64_t tb1 = min(ntiles, tb0 + tiles_per_slot);
@@ -478,46 +814,60 @@ __global__ __launch_bounds__(kBlock, 2) void tn_colgroup_k(
 #pragma unroll
       for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-  float4 pa[8], pb[8];
-  // loads only (no stores in the loop): clamped and branch-free, rows past the end are zeroed below
-  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
-    const int64_t r0 = tile * FTR;
+  // loads only (no stores in the loop): clamped and branch-free, rows past the end are zeroed below.
+  // (Two tiles in flight were tried for split mode: hipcc then waits vmcnt(0) on the newer prefetch
+  // and the kernel gets slower; DEPTH stays 1.)
+  constexpr int DEPTH = 1;
+  float4 pa[DEPTH][8], pb[DEPTH][8];
+  auto prefetch = [&](float4 (&qa)[8], float4 (&qb)[8], int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * FTR;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int64_t r = clampi(r0 + lrow + 8 * it, Mlast);
-      pa[it] = ld4(A + r * lda + cg * FH + lc4);
-      pb[it] = ld4(B + r * FH + lc4);
+      const int64_t r = clampi(r0 + MM::row(lrow, it), Mlast);
+      qa[it] = ld4(A + r * lda + cg * FH + lc4);
+      qb[it] = ld4(B + r * FH + lc4);
     }
   };
-  if (tb0 < tb1) prefetch(tb0);
-  for (int64_t tile = tb0; tile < tb1; ++tile) {
+  auto step = [&](float4 (&qa)[8], float4 (&qb)[8], int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = tile * FTR;
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const bool ok = r0 + lrow + 8 * it < M;
-      const float4 av = ok ? pa[it] : f4(0.f);
-      st4(as + (lrow + 8 * it) * FP + lc4, av);
-      st4(bs + (lrow + 8 * it) * FP + lc4, pb[it]);
+      const bool ok = r0 + MM::row(lrow, it) < M;
+      if (!ok) qa[it] = f4(0.f);
+      const float4 av = qa[it];
       c0 += (double)av.x; c1 += (double)av.y; c2 += (double)av.z; c3 += (double)av.w;
+      if (!MM::kSplit) {
+        st4(as + MM::row(lrow, it) * FP + lc4, av);
+        st4(bs + MM::row(lrow, it) * FP + lc4, qb[it]);
+      }
+    }
+    if (MM::kSplit) {
+      Split8 sp;
+      split_rows(qa, sp);
+      stage_cols(ta, lrow, lc4, sp);
+      split_rows(qb, sp);
+      stage_cols(tb, lrow, lc4, sp);
     }
     __syncthreads();
-    prefetch(tile + 1 < tb1 ? tile + 1 : tile);
-    mma_tn64(as, bs, tn, wn, wc, li, lg);
+    prefetch(qa, qb, tile + DEPTH);
+    if (MM::kSplit) mma_tn64_b3<true>(ta, tb, tn, wn, wc, li, lg);
+    else mma_tn64(as, bs, tn, wn, wc, li, lg);
+  };
+  if (tb0 < tb1) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) prefetch(pa[d], pb[d], tb0 + d);
+    int64_t tile = tb0;
+    for (; tile + DEPTH <= tb1; tile += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) step(pa[d], pb[d], tile + d);
+    }
+    if (DEPTH == 2 && tile < tb1) step(pa[0], pb[0], tile);
   }
   float* sl = slab + (size_t)(cg * nslot + slot) * FH * FH;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = (2 * wn + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-        const int c = (2 * wc + b) * 32 + li;
-        sl[n * FH + c] = tn[a][b][e];
-      }
+  tn_store_slab<MM>(sl, tn, wn, wc, li, lg);
   __syncthreads();
-  double* red = reinterpret_cast<double*>(as);
+  double* red = reinterpret_cast<double*>(raw);
   red[lrow * FH + lc4 + 0] = c0;
   red[lrow * FH + lc4 + 1] = c1;
   red[lrow * FH + lc4 + 2] = c2;
@@ -547,7 +897,30 @@ using namespace gnm;
 static inline int64_t cdiv_(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // workspace: packed weights (ncb * 16 * 64 float4)
-extern "C" size_t gnm_rowtile_workspace_bytes(int ncols) { return (size_t)(ncols / 32) * FKQ * 64 * 16; }
+extern "C" size_t gnm_rowtile_workspace_bytes(int ncols) { return (size_t)(ncols / 32) * kPackBytesPerBlk; }
+
+extern "C" int gnm_set_matmul_mode(int mode) {
+  GNM_CHECK_ARG(mode == 0 || mode == 1, "set_matmul_mode: mode %d (0 = fp32 MFMA, 1 = bf16x3 split)", mode);
+  g_matmul_mode = mode;
+  return 0;
+}
+extern "C" int gnm_get_matmul_mode(void) { return g_matmul_mode; }
+
+template <class MM>
+static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, const float* b3, const float* P,
+                             const int32_t* isrc, const int32_t* idst, float* t, double* partials, int* nblk_out,
+                             void* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  launch_pack<MM>(W3, FH, FH / 32, 0, ws, st);
+  GNM_LAUNCH_CHECK("pack_w (NT)");
+  const int64_t ntiles = cdiv_(E, FTR);
+  const int grid = persistent_grid(ntiles, 4, occ_blocks<rowtile_nt_k<MM, true, 1>>());
+  hipLaunchKernelGGL((rowtile_nt_k<MM, true, 1>), dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t,
+                     (int64_t)FH, P, isrc, idst, partials, cdiv_(ntiles, grid), 1);
+  GNM_LAUNCH_CHECK("edge_t_fused_fwd");
+  *nblk_out = grid;
+  return 0;
+}
 
 extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
                                     const float* P, const int32_t* isrc, const int32_t* idst, float* t,
@@ -555,15 +928,33 @@ extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const f
   GNM_CHECK_ARG(H == FH, "edge_t_fused_fwd: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(E > 0 && e_in && W3 && b3 && P && isrc && idst && t && partials && nblk_out, "edge_t_fused_fwd: null/neg argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(FH), "edge_t_fused_fwd: workspace too small");
+  return g_matmul_mode ? edge_t_fused_impl<MmB3>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream)
+                       : edge_t_fused_impl<MmF32>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream);
+}
+
+template <class MM>
+static int node_proj_fwd_impl(int64_t N, int ncols, const float* h, const float* W, const float* b, float* Pout,
+                              void* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pack_w_k, dim3(16), dim3(256), 0, st, W3, (int64_t)FH, FH / 32, 0, (float*)ws);
-  GNM_LAUNCH_CHECK("pack_w (NT)");
-  const int64_t ntiles = cdiv_(E, FTR);
-  const int grid = persistent_grid(ntiles, 4, occ_blocks<rowtile_nt_k<true, 1>>());
-  hipLaunchKernelGGL((rowtile_nt_k<true, 1>), dim3(grid), dim3(kBlock), 0, st, E, e_in, (const float*)ws, b3, t,
-                     (int64_t)FH, P, isrc, idst, partials, cdiv_(ntiles, grid));
-  GNM_LAUNCH_CHECK("edge_t_fused_fwd");
-  *nblk_out = grid;
+  launch_pack<MM>(W, FH, ncols / 32, 0, ws, st);
+  GNM_LAUNCH_CHECK("pack_w (NT, node)");
+  const int64_t ntiles = cdiv_(N, FTR);
+  if constexpr (MM::kSplit) {
+    // HBM-bound in split mode: column groups over workgroups, weights stationary (no reload per tile)
+    const int ncg = ncols / FH;
+    int nslot = (num_cus() * occ_blocks<rowtile_nt_k<MM, false, 1>>()) / ncg / kXcds * kXcds;
+    if (nslot > (int)((ntiles + kXcds - 1) / kXcds * kXcds)) nslot = (int)((ntiles + kXcds - 1) / kXcds * kXcds);
+    if (nslot < kXcds) nslot = kXcds;
+    hipLaunchKernelGGL((rowtile_nt_k<MM, false, 1>), dim3(nslot * ncg), dim3(kBlock), 0, st, N, h, (const void*)ws, b,
+                       Pout, (int64_t)ncols, (const float*)nullptr, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (double*)nullptr, cdiv_(ntiles, nslot), ncg);
+  } else {
+    const int grid = persistent_grid(ntiles, 2, occ_blocks<rowtile_nt_k<MM, false, 5>>());
+    hipLaunchKernelGGL((rowtile_nt_k<MM, false, 5>), dim3(grid), dim3(kBlock), 0, st, N, h, (const void*)ws, b, Pout,
+                       (int64_t)ncols, (const float*)nullptr, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (double*)nullptr, cdiv_(ntiles, grid), 1);
+  }
+  GNM_LAUNCH_CHECK("node_proj_fwd");
   return 0;
 }
 
@@ -572,21 +963,31 @@ extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, co
   GNM_CHECK_ARG(H == FH, "node_proj_fwd: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(N > 0 && ncols == 5 * FH && h && W && b && Pout, "node_proj_fwd: bad argument (ncols must be 5*128)");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pack_w_k, dim3(16 * ncols / FH), dim3(256), 0, st, W, (int64_t)FH, ncols / 32, 0, (float*)ws);
-  GNM_LAUNCH_CHECK("pack_w (NT, node)");
-  const int64_t ntiles = cdiv_(N, FTR);
-  const int grid = persistent_grid(ntiles, 2, occ_blocks<rowtile_nt_k<false, 5>>());
-  hipLaunchKernelGGL((rowtile_nt_k<false, 5>), dim3(grid), dim3(kBlock), 0, st, N, h, (const float*)ws, b, Pout,
-                     (int64_t)ncols, (const float*)nullptr, (const int32_t*)nullptr,
-                     (const int32_t*)nullptr, (double*)nullptr, cdiv_(ntiles, grid));
-  GNM_LAUNCH_CHECK("node_proj_fwd");
-  return 0;
+  return g_matmul_mode ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
+                       : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
 }
 
 extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void) {
   // packed W3 + one 128x128 slab per possible workgroup
   return gnm_rowtile_workspace_bytes(FH) + (size_t)kMaxPartialBlocks * FH * FH * sizeof(float);
+}
+
+template <class MM>
+static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in,
+                               const float* stat_e, const float* bstat_e, const float* gamma_e, const float* W3,
+                               float* gW3, float* gb3, double* partials, void* ws, void* stream) {
+  const int64_t ntiles = cdiv_(E, FTR);
+  const int grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k<MM>>());
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  launch_pack<MM>(W3, FH, FH / 32, 1, ws, st);
+  GNM_LAUNCH_CHECK("pack_w (NN)");
+  hipLaunchKernelGGL(edge_bwd_fused_k<MM>, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
+                     gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
+  GNM_LAUNCH_CHECK("edge_bwd_fused");
+  hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
+  GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
+  return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
 }
 
 extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const float* t, const float* e_in,
@@ -596,27 +997,39 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
   GNM_CHECK_ARG(H == FH, "edge_bwd_fused: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(E > 0 && ge && ge_out && t && e_in && stat_e && bstat_e && gamma_e && W3 && gW3 && gb3 && partials,
                 "edge_bwd_fused: null/neg argument");
-  const int64_t ntiles = cdiv_(E, FTR);
-  const int grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k>());
-  const size_t need = gnm_rowtile_workspace_bytes(FH) + (size_t)grid * FH * FH * sizeof(float);
-  GNM_CHECK_ARG(ws && ws_bytes >= need, "edge_bwd_fused: workspace %zu < %zu", ws_bytes, need);
-  hipStream_t st = (hipStream_t)stream;
-  float* wp = (float*)ws;
-  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
-  hipLaunchKernelGGL(pack_w_k, dim3(16), dim3(256), 0, st, W3, (int64_t)FH, FH / 32, 1, wp);
-  GNM_LAUNCH_CHECK("pack_w (NN)");
-  hipLaunchKernelGGL(edge_bwd_fused_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
-                     gamma_e, (const float*)wp, slab, partials, cdiv_(ntiles, grid));
-  GNM_LAUNCH_CHECK("edge_bwd_fused");
-  hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
-  GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
-  return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "edge_bwd_fused: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  return g_matmul_mode ? edge_bwd_fused_impl<MmB3>(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, gW3, gb3, partials, ws, stream)
+                       : edge_bwd_fused_impl<MmF32>(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, gW3, gb3, partials, ws, stream);
 }
 
 // gh_in = gh_out + gP W  (W [ncols,128] row-major, ncols % 128 == 0);  gW = gP^T h_in;  gb = sum gP.
 // ws: packed W (ncols/32 fragment blocks) + slabs [ncg][nslot][128][128]; partials double[ncg*nslot][128]
 extern "C" size_t gnm_node_proj_bwd_workspace_bytes(int ncols) {
   return gnm_rowtile_workspace_bytes(ncols) + (size_t)kMaxPartialBlocks * FH * FH * sizeof(float);
+}
+
+template <class MM>
+static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* W, const float* gh_out, float* gh_in,
+                            void* ws, hipStream_t st) {
+  const int ncg = ncols / FH;
+  for (int cg = 0; cg < ncg; ++cg)   // W rows cg*128.. form the [k=128, c=128] block of group cg
+    launch_pack<MM>(W + (size_t)cg * FH * FH, FH, FH / 32, 1, (char*)ws + (size_t)cg * 4 * MM::kPackBytes, st);
+  GNM_LAUNCH_CHECK("pack_w (NN, node)");
+  if constexpr (MM::kSplit) {
+    constexpr int T = 4;
+    const int64_t ngroups = cdiv_(N, FTR * T);
+    const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn_group_k<MM, T>>());
+    hipLaunchKernelGGL((rowtile_nn_group_k<MM, T>), dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
+                       (const void*)ws, gh_out, gh_in, cdiv_(ngroups, grid));
+  } else {
+    const int64_t ntiles = cdiv_(N, FTR);
+    const int grid = persistent_grid(ntiles, 2, occ_blocks<rowtile_nn_acc_k<MM>>());
+    hipLaunchKernelGGL(rowtile_nn_acc_k<MM>, dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
+                       (const void*)ws, gh_out, gh_in, cdiv_(ntiles, grid));
+  }
+  GNM_LAUNCH_CHECK("node_proj_bwd (NN)");
+  return 0;
 }
 
 extern "C" int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
@@ -628,27 +1041,24 @@ extern "C" int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, c
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_node_proj_bwd_workspace_bytes(ncols), "node_proj_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int ncg = ncols / FH;
-  float* wp = (float*)ws;
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(ncols));
-  for (int cg = 0; cg < ncg; ++cg) {   // W rows cg*128.. form the [k=128, c=128] block of group cg
-    hipLaunchKernelGGL(pack_w_k, dim3(16), dim3(256), 0, st, W + (size_t)cg * FH * FH, (int64_t)FH, FH / 32, 1,
-                       wp + (size_t)cg * 4 * FKQ * 64 * 4);
-  }
-  GNM_LAUNCH_CHECK("pack_w (NN, node)");
   const int64_t ntiles = cdiv_(N, FTR);
+  if (g_matmul_mode ? node_proj_bwd_nn<MmB3>(N, ncols, gP, W, gh_out, gh_in, ws, st)
+                    : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st))
+    return -2;
   {
-    const int grid = persistent_grid(ntiles, 2, occ_blocks<rowtile_nn_acc_k>());
-    hipLaunchKernelGGL(rowtile_nn_acc_k, dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
-                       (const float*)wp, gh_out, gh_in, cdiv_(ntiles, grid));
-    GNM_LAUNCH_CHECK("node_proj_bwd (NN)");
-  }
-  {
-    int nslot = (num_cus() * occ_blocks<tn_colgroup_k>()) / ncg;
+    const int occ = g_matmul_mode ? occ_blocks<tn_colgroup_k<MmB3>>() : occ_blocks<tn_colgroup_k<MmF32>>();
+    int nslot = (num_cus() * occ) / ncg;
     if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
     if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
-    if (nslot < 1) nslot = 1;
-    hipLaunchKernelGGL(tn_colgroup_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg, h_in,
-                       slab, partials, nslot, cdiv_(ntiles, nslot));
+    nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
+    if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
+    if (g_matmul_mode)
+      hipLaunchKernelGGL(tn_colgroup_k<MmB3>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg, h_in,
+                         slab, partials, nslot, cdiv_(ntiles, nslot));
+    else
+      hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg, h_in,
+                         slab, partials, nslot, cdiv_(ntiles, nslot));
     GNM_LAUNCH_CHECK("node_proj_bwd (TN)");
     for (int cg = 0; cg < ncg; ++cg) {
       hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cg * nslot * FH * FH,

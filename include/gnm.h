@@ -181,6 +181,14 @@ int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const f
  * ws: gnm_rowtile_workspace_bytes(ncols) / gnm_node_proj_bwd_workspace_bytes(ncols) /
  *     gnm_edge_bwd_fused_workspace_bytes().  partials: the BatchNorm partials buffer.      */
 size_t gnm_rowtile_workspace_bytes(int ncols);
+/* How the fused kernels multiply a fp32 tile by a fp32 weight block (process-wide, default 0):
+ *   0  v_mfma_f32_32x32x2_f32 -- fp32 operands on the matrix cores;
+ *   1  "bf16x3": each fp32 operand is split EXACTLY into three bf16 terms (3 x 8 = 24 significand
+ *      bits) and the product is formed from six v_mfma_f32_32x32x16_bf16 (all partial products
+ *      above 2^-24 |x w|), accumulated in fp32 -- fp32-class accuracy at 8/6 x 2 the MFMA rate.
+ * Applies to the NT / NN contractions of edge_t_fused_fwd, node_proj_fwd/bwd, edge_bwd_fused.   */
+int gnm_set_matmul_mode(int mode);
+int gnm_get_matmul_mode(void);
 int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
                          const float* P, const int32_t* isrc, const int32_t* idst, float* t,
                          double* partials, int* nblk_out, void* ws, size_t ws_bytes, void* stream);

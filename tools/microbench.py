@@ -17,10 +17,12 @@ def main():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--unfused", action="store_true")
+    ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3"])
     a = ap.parse_args()
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import synth, engine
     engine.FUSED = not a.unfused
+    G._lib.set_matmul_mode(a.matmul)
     dev = torch.device("cuda:0")
     H = a.hidden
     src, dst, n = synth.make_graph(a.reads, 0)
