@@ -60,6 +60,11 @@ SIGNATURES = {
     "gnm_edge_encoder_bwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_predictor_score_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_predictor_score_bwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_predictor_fused_workspace_bytes": (_sz, []),
+    "gnm_predictor_fused_fwd": (_i32, [_i64, _i32, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_predictor_fused_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_tn128_workspace_bytes": (_sz, []),
+    "gnm_tn128": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_reduce_partials": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
     "gnm_seg_sum_rows": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "gnm_pagerank_pe_workspace_bytes": (_sz, [_i64]),

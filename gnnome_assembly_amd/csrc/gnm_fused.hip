@@ -1003,6 +1003,32 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
                        : edge_bwd_fused_impl<MmF32>(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, gW3, gb3, partials, ws, stream);
 }
 
+static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,
+                        double* partials, float* slab, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = cdiv_(N, FTR);
+  const int occ = g_matmul_mode ? occ_blocks<tn_colgroup_k<MmB3>>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  int nslot = (num_cus() * occ) / ncg;
+  if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
+  if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
+  nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
+  if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
+  if (g_matmul_mode)
+    hipLaunchKernelGGL(tn_colgroup_k<MmB3>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
+                       nslot, cdiv_(ntiles, nslot));
+  else
+    hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
+                       nslot, cdiv_(ntiles, nslot));
+  GNM_LAUNCH_CHECK("tn_colgroup");
+  for (int cg = 0; cg < ncg; ++cg) {
+    hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cg * nslot * FH * FH,
+                       nslot, FH * FH, gW + (size_t)cg * FH * FH);
+    if (gnm_reduce_partials(partials + (size_t)cg * nslot * FH, nslot, 1, FH, gb + cg * FH, stream)) return -3;
+  }
+  GNM_LAUNCH_CHECK("tn_colgroup reduce");
+  return 0;
+}
+
 // gh_in = gh_out + gP W  (W [ncols,128] row-major, ncols % 128 == 0);  gW = gP^T h_in;  gb = sum gP.
 // ws: packed W (ncols/32 fragment blocks) + slabs [ncg][nslot][128][128]; partials double[ncg*nslot][128]
 extern "C" size_t gnm_node_proj_bwd_workspace_bytes(int ncols) {
@@ -1042,30 +1068,21 @@ extern "C" int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, c
   hipStream_t st = (hipStream_t)stream;
   const int ncg = ncols / FH;
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(ncols));
-  const int64_t ntiles = cdiv_(N, FTR);
   if (g_matmul_mode ? node_proj_bwd_nn<MmB3>(N, ncols, gP, W, gh_out, gh_in, ws, st)
                     : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st))
     return -2;
-  {
-    const int occ = g_matmul_mode ? occ_blocks<tn_colgroup_k<MmB3>>() : occ_blocks<tn_colgroup_k<MmF32>>();
-    int nslot = (num_cus() * occ) / ncg;
-    if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
-    if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
-    nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
-    if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
-    if (g_matmul_mode)
-      hipLaunchKernelGGL(tn_colgroup_k<MmB3>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg, h_in,
-                         slab, partials, nslot, cdiv_(ntiles, nslot));
-    else
-      hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg, h_in,
-                         slab, partials, nslot, cdiv_(ntiles, nslot));
-    GNM_LAUNCH_CHECK("node_proj_bwd (TN)");
-    for (int cg = 0; cg < ncg; ++cg) {
-      hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cg * nslot * FH * FH,
-                         nslot, FH * FH, gW + (size_t)cg * FH * FH);
-      if (gnm_reduce_partials(partials + (size_t)cg * nslot * FH, nslot, 1, FH, gb + cg * FH, stream)) return -3;
-    }
-    GNM_LAUNCH_CHECK("node_proj_bwd reduce");
-  }
+  return tn_colgroups(N, gP, ncols, ncg, h_in, gW, gb, partials, slab, stream);
+}
+
+// out[cg*128 + n][c] = sum_rows A[row][cg*128 + n] * B[row][c];  colsum[cg*128 + n] = sum_rows A[row][cg*128 + n]
+// (A [M, lda >= ncg*128], B [M,128]): the weight-gradient shape of every Linear whose input is 128 wide.
+extern "C" size_t gnm_tn128_workspace_bytes(void) { return (size_t)kMaxPartialBlocks * FH * FH * sizeof(float); }
+
+extern "C" int gnm_tn128(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* out, float* colsum,
+                         double* partials, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(M > 0 && A && B && out && colsum && partials && ncg > 0 && lda >= (int64_t)ncg * FH && ncg <= 16,
+                "tn128: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128: workspace too small");
+  return tn_colgroups(M, A, lda, ncg, B, out, colsum, partials, (float*)ws, stream);
   return 0;
 }

@@ -361,11 +361,21 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     W1sd = torch.cat((W1[:, :H], W1[:, H:2 * H]), 0).contiguous()     # [2HS, H]
     Pn = torch.empty(N, 2 * HS, **f32)
     gemm(NT, x, W1sd, Pn)
-    hid = torch.empty(E, HS, **f32)
-    gemm(NT, e, W1[:, 2 * H:], hid, bias=b1)
     scores = torch.empty(E, 1, **f32)
-    _call("gnm_predictor_score_fwd", E, HS, _ptr(hid), _ptr(Pn), _ptr(idx["isrc"]), _ptr(idx["idst"]),
-                                           _ptr(W2), _ptr(b2), _ptr(idx["perm"]), _ptr(scores), _stream())
+    if H == 128 and HS == 64 and FUSED:
+        # one pass over e: hid GEMM + gathers + relu + W2 dot; hid is only written when backward needs it
+        hid = torch.empty(E, HS, **f32) if save else None
+        need = lib.gnm_predictor_fused_workspace_bytes()
+        ws = scratch(dev).ws(need)
+        W1e = W1[:, 2 * H:]
+        _call("gnm_predictor_fused_fwd", E, H, HS, _ptr(e), _ptr(W1e), W1.stride(0), _ptr(b1), _ptr(Pn),
+              _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["perm"]), _ptr(W2), _ptr(b2), _ptr(hid), _ptr(scores),
+              _ptr(ws), need, _stream())
+    else:
+        hid = torch.empty(E, HS, **f32)
+        gemm(NT, e, W1[:, 2 * H:], hid, bias=b1)
+        _call("gnm_predictor_score_fwd", E, HS, _ptr(hid), _ptr(Pn), _ptr(idx["isrc"]), _ptr(idx["idst"]),
+                                               _ptr(W2), _ptr(b2), _ptr(idx["perm"]), _ptr(scores), _stream())
     saved = PredSaved(x=x, e=e, hid=hid, W1sd=W1sd) if save else None
     return scores, saved
 
@@ -382,27 +392,53 @@ def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores):
     g = {}
     gscores = _f32c(gscores.reshape(-1))
     ghid = s.hid   # in place
-    _call("gnm_predictor_score_bwd", E, HS, _ptr(ghid), _ptr(gscores), _ptr(W2), _ptr(idx["perm"]),
-                                           _ptr(sc.partials), C.byref(nblk), st)
-    red = torch.empty(2, HS, **f32)
-    _call("gnm_reduce_partials", _ptr(sc.partials), nblk.value, 2, HS, _ptr(red), st)
-    g["W2"] = red[0:1].clone()
-    g["b2"] = red[1, 0:1].clone()
-    g["b1"] = colsum(ghid)
+    fused = H == 128 and HS == 64 and FUSED
+    gW1 = torch.empty(HS, 3 * H, **f32)
+    if fused:
+        # one pass: ghid (in place), ge = ghid W1e, gW1e, and the gW2 / gb1 / gb2 column sums
+        ge = torch.empty(E, H, **f32)
+        gW1e = torch.empty(HS, H, **f32)
+        gsums = torch.empty(3 * HS, **f32)
+        need = lib.gnm_predictor_fused_workspace_bytes()
+        ws = sc.ws(need)
+        _call("gnm_predictor_fused_bwd", E, H, HS, _ptr(ghid), _ptr(gscores), _ptr(idx["perm"]), _ptr(W2), _ptr(s.e),
+              _ptr(W1[:, 2 * H:]), W1.stride(0), _ptr(ge), _ptr(gW1e), _ptr(gsums), _ptr(sc.partials), _ptr(ws), need, st)
+        g["W2"] = gsums[0:HS].reshape(1, HS).clone()
+        g["b1"] = gsums[HS:2 * HS].clone()
+        g["b2"] = gsums[2 * HS:2 * HS + 1].clone()
+        gW1[:, 2 * H:] = gW1e
+    else:
+        _call("gnm_predictor_score_bwd", E, HS, _ptr(ghid), _ptr(gscores), _ptr(W2), _ptr(idx["perm"]),
+                                               _ptr(sc.partials), C.byref(nblk), st)
+        red = torch.empty(2, HS, **f32)
+        _call("gnm_reduce_partials", _ptr(sc.partials), nblk.value, 2, HS, _ptr(red), st)
+        g["W2"] = red[0:1].clone()
+        g["b2"] = red[1, 0:1].clone()
+        g["b1"] = colsum(ghid)
     gPn = torch.empty(N, 2 * HS, **f32)
     _call("gnm_seg_sum_rows", N, HS, _ptr(ghid), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]),
                                     _ptr(gPn), 2 * HS, st)
     _call("gnm_seg_sum_rows", N, HS, _ptr(ghid), _ptr(idx["in_ptr"]), C.c_void_p(0),
                                     _ptr(gPn[:, HS:]), 2 * HS, st)
-    gW1 = torch.empty(HS, 3 * H, **f32)
-    gemm(TN, gPn[:, :HS], s.x, gW1[:, :H])
-    gemm(TN, gPn[:, HS:], s.x, gW1[:, H:2 * H])
-    gemm(TN, ghid, s.e, gW1[:, 2 * H:])
+    if fused:
+        # [x^T gPs | x^T gPd] in one W-free TN pass (x is the 128-wide operand), then transpose the 128 x 128 result
+        xt = torch.empty(H, 2 * HS, **f32)
+        junk = torch.empty(H, **f32)
+        need = lib.gnm_tn128_workspace_bytes()
+        ws = sc.ws(need)
+        _call("gnm_tn128", N, _ptr(s.x), H, 1, _ptr(gPn), _ptr(xt), _ptr(junk), _ptr(sc.partials), _ptr(ws), need, st)
+        gW1[:, :H] = xt[:, :HS].t()
+        gW1[:, H:2 * H] = xt[:, HS:].t()
+    else:
+        gemm(TN, gPn[:, :HS], s.x, gW1[:, :H])
+        gemm(TN, gPn[:, HS:], s.x, gW1[:, H:2 * H])
+        gemm(TN, ghid, s.e, gW1[:, 2 * H:])
     g["W1"] = gW1
     gx = torch.empty(N, H, **f32)
     gemm(NN, gPn, s.W1sd, gx)
-    ge = torch.empty(E, H, **f32)
-    gemm(NN, ghid, W1[:, 2 * H:], ge)
+    if not fused:
+        ge = torch.empty(E, H, **f32)
+        gemm(NN, ghid, W1[:, 2 * H:], ge)
     return gx, ge, g
 
 

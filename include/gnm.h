@@ -228,6 +228,26 @@ int gnm_predictor_score_fwd(int64_t E, int HS, float* hid, const float* Pn, cons
  * partials double[nblk][2][HS]: (sum gscore*relu(hid)) -> gW2, and [.,1,0] = sum gscore -> gb2 */
 int gnm_predictor_score_bwd(int64_t E, int HS, float* hid, const float* gscore, const float* W2,
                             const int32_t* perm, double* partials, int* nblk_out, void* stream);
+/* Fused single-pass forms for H = 128, HS = 64 (fp32 MFMA, W1e stationary in registers):
+ * fwd: hid = e W1e^T + b1 + Ps[isrc] + Pd[idst] (written only if hid != NULL), score[perm j] = W2 . relu(hid[j]) + b2.
+ *      W1e = &W1[0][2H] with row stride ldw (= 3H): the e-columns of predictor.W1 (score_predictor.py:15-17).
+ * bwd: ghid = gscore[perm j] W2 [hid>0] (in place over hid), ge = ghid W1e, gW1e[HS,H] = ghid^T e,
+ *      gsums[0:HS] = gW2, gsums[HS:2HS] = gb1, gsums[2HS] = gb2 (gsums holds 3*HS floats).
+ *      partials: the BatchNorm partials buffer.  ws: gnm_predictor_fused_workspace_bytes().          */
+size_t gnm_predictor_fused_workspace_bytes(void);
+int gnm_predictor_fused_fwd(int64_t E, int H, int HS, const float* e, const float* W1e, int64_t ldw,
+                            const float* b1, const float* Pn, const int32_t* isrc, const int32_t* idst,
+                            const int32_t* perm, const float* W2, const float* b2, float* hid,
+                            float* scores, void* ws, size_t ws_bytes, void* stream);
+int gnm_predictor_fused_bwd(int64_t E, int H, int HS, float* hid, const float* gscore,
+                            const int32_t* perm, const float* W2, const float* e, const float* W1e,
+                            int64_t ldw, float* ge, float* gW1e, float* gsums, double* partials,
+                            void* ws, size_t ws_bytes, void* stream);
+/* Weight-gradient shape of a Linear with a 128-wide input: out[cg*128+n][c] = sum_r A[r][cg*128+n] B[r][c],
+ * colsum[cg*128+n] = sum_r A[r][cg*128+n];  A [M, lda >= ncg*128], B [M,128], ncg <= 16.              */
+size_t gnm_tn128_workspace_bytes(void);
+int gnm_tn128(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* out, float* colsum,
+              double* partials, void* ws, size_t ws_bytes, void* stream);
 /* reduce double partials [nblk][rows][W] -> float out[rows][W] */
 int gnm_reduce_partials(const double* partials, int nblk, int rows, int W, float* out, void* stream);
 /* out[v*ldo + c] = sum_{m in [ptr[v],ptr[v+1])} X[(pos ? pos[m] : m)*W + c], c < W        */
