@@ -388,7 +388,7 @@ static void launch_pack(const float* W, int64_t ld, int ncb, int nn, void* wp, h
 // NCG (number of 128-column groups) is a template parameter so that the column-group loop unrolls:
 // a loop with a run-time trip count around the stores would defeat the vmcnt counting below.
 template <class MM, bool EDGE, int NCG>
-__global__ __launch_bounds__(kBlock, (MM::kSplit && !EDGE && NCG == 1) ? 2 : 1) void rowtile_nt_k(
+__global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE && !MM::kSplit)) ? 2 : 1) void rowtile_nt_k(
     int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ Y, int64_t ldy, const float* __restrict__ P,
     const int32_t* __restrict__ isrc, const int32_t* __restrict__ idst, double* __restrict__ partials,
@@ -445,8 +445,11 @@ __global__ __launch_bounds__(kBlock, (MM::kSplit && !EDGE && NCG == 1) ? 2 : 1) 
     __syncthreads();
     const int64_t r0 = tile * FTR;
     // gathers of this tile's B1h[src] / B2h[dst] rows: issued now, consumed in the epilogue
+    // (two workgroups per CU in the fp32 edge kernel: the gathers are issued after the MFMAs instead,
+    //  the other workgroup's MFMAs cover their latency, and the kernel fits 256 VGPRs)
+    constexpr bool LATE = EDGE && !MM::kSplit;
     float4 g1[8], g2[8];
-    if (EDGE) {
+    if (EDGE && !LATE) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = lrow + 8 * it;
@@ -463,6 +466,15 @@ __global__ __launch_bounds__(kBlock, (MM::kSplit && !EDGE && NCG == 1) ? 2 : 1) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
       MM::mma(xraw, wf, acc0, acc1, li, lg);
+      if (LATE) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = lrow + 8 * it;
+          const int64_t s_ = sd[row], d_ = sd[FTR + row];
+          g1[it] = ld4(P + s_ * (5 * FH) + 3 * FH + lc4);
+          g2[it] = ld4(P + d_ * (5 * FH) + 4 * FH + lc4);
+        }
+      }
       float* os = INPLACE ? xs : ys;
       if (INPLACE) __syncthreads();         // all waves are done reading the X image
       else if (cg > 0) __syncthreads();     // previous column group's epilogue is done with ys

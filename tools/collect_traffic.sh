@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/traffic
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic -o $c -- \
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic -o $c -- \
       python $R/tools/microbench.py --iters 2 > $R/gpurun_out/traffic/$c.log 2>&1
 done
 ls $R/gpurun_out/traffic

@@ -24,6 +24,7 @@ for k, v in res.items():
     table[k] = {"fetch_gb": f / 1e9, "write_gb": w / 1e9, "total_gb": (f + w) / 1e9, "launches": v["n_f"]}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py "
                      "(one layer fwd+bwd, E=7540278, N=1500000, H=128); FETCH_SIZE doubled (gfx950)",
+           "workload": {"edges": 7540278, "nodes": 1500000, "hidden": 128},   # microbench defaults (R=750k, seed 0)
            "per_launch": table}, open(out, "w"), indent=1, sort_keys=True)
 for k, v in sorted(table.items(), key=lambda kv: -kv[1]["total_gb"])[:20]:
     print(f"{k:40s} fetch={v['fetch_gb']:7.2f} GB write={v['write_gb']:7.2f} GB total={v['total_gb']:7.2f} GB")
