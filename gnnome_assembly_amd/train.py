@@ -10,7 +10,11 @@ Differences from the reference, all deliberate:
   * under torch.distributed (one process per GPU) the W graphs of a step contribute the MEAN of
     their gradients through one RCCL all-reduce (dp.FlatGradients); single-process runs reproduce the
     reference's one-step-per-graph sequence;
-  * wandb, METIS mini-batching and the data pipeline are out of scope.
+  * the ClusterGCN mini-batch branch (train.py:282-343,428-486; batch_size_* > 1) runs on this
+    package's own partitioner (cluster.py: METIS is part of DGL and not available), otherwise with
+    the reference's loop: a fresh partition per graph and epoch with a random number of clusters in
+    [num_parts-100, num_parts+100), shuffled batches of clusters, one Adam step per batch;
+  * wandb and the data pipeline are out of scope.
 `calculate_metrics` keeps the reference's naming, in which "precision" and "recall" are swapped
 (utils.py:227-234)."""
 from __future__ import annotations
@@ -24,7 +28,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from . import dp, models
+from . import cluster, dp, models
 
 __all__ = ["get_hyperparameters", "GraphSample", "tfpn_counts", "calculate_metrics", "train", "save_checkpoint"]
 
@@ -35,6 +39,8 @@ def get_hyperparameters() -> Dict:
         "seed": 0, "lr": 1e-3, "num_epochs": 100, "dim_latent": 256, "node_features": 1, "edge_features": 2,
         "hidden_edge_features": 16, "hidden_edge_scores": 64, "num_gnn_layers": 16, "nb_pos_enc": 16,
         "batch_size_train": 1, "batch_size_eval": 1, "patience": 2, "decay": 0.95, "batch_norm": True,
+        # only read when batch_size_* > 1 (hyperparameters.py:15-18 has 500 / 500 / 50 / 50)
+        "num_parts_metis_train": 500, "num_parts_metis_eval": 500, "partition_method": "rcm",
     }
 
 
@@ -77,6 +83,16 @@ def pos_to_neg_ratio(samples: Sequence[GraphSample]) -> float:
     """train.py:181: dataset mean of #(y==1)/#(y==0)."""
     r = [((s.y == 1).sum() / (s.y == 0).sum()) for s in samples]
     return float(torch.stack(r).mean().item())
+
+
+def _cluster_batches(s: GraphSample, num_parts: int, batch_size: int, method: str):
+    """The sub-graphs of one pass over a graph in mini-batch mode; features ride on ndata / edata exactly
+    as the reference keeps them on the DGLGraph (train.py:298-307)."""
+    g = s.graph
+    g.ndata = dict(g.ndata, pe=s.pe)
+    g.edata = dict(g.edata, e=s.e, y=s.y)
+    part = cluster.partition_graph(g, num_parts, method)
+    return cluster.ClusterBatchLoader(g, part, batch_size, shuffle=True)
 
 
 @dataclass
@@ -127,14 +143,31 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
         counts = torch.zeros(4, device=dev, dtype=torch.int64)
         for gi in order:
             s = train_samples[gi]
-            flat.zero_()
-            pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)                                   # train.py:252-253
-            loss = criterion(pred, s.y)
-            loss.backward()
-            flat.all_reduce_mean()
-            optimizer.step()                                                                    # train.py:256-258
-            loss_sum += loss.detach().double()
-            counts += tfpn_counts(pred.detach(), s.y)
+            if hp["batch_size_train"] <= 1:                                                     # full graph
+                flat.zero_()
+                pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)                               # train.py:252-253
+                loss = criterion(pred, s.y)
+                loss.backward()
+                flat.all_reduce_mean()
+                optimizer.step()                                                                # train.py:256-258
+                loss_sum += loss.detach().double()
+                counts += tfpn_counts(pred.detach(), s.y)
+            else:                                                                               # train.py:282-343
+                lo = max(1, hp["num_parts_metis_train"] - 100)
+                nparts = int(torch.randint(lo, hp["num_parts_metis_train"] + 100, (1,)).item())  # train.py:291
+                gl = torch.zeros((), device=dev, dtype=torch.float64)
+                nb = 0
+                for sub in _cluster_batches(s, nparts, hp["batch_size_train"], hp["partition_method"]):
+                    flat.zero_()
+                    pred = model(sub, None, sub.edata["e"], sub.ndata["pe"]).squeeze(-1)        # train.py:306
+                    loss = criterion(pred, sub.edata["y"])
+                    loss.backward()
+                    flat.all_reduce_mean()
+                    optimizer.step()
+                    gl += loss.detach().double()
+                    nb += 1
+                    counts += tfpn_counts(pred.detach(), sub.edata["y"])
+                loss_sum += gl / max(nb, 1)                                                     # train.py:330
         n_train = torch.tensor(float(len(order)), device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(loss_sum); dist.all_reduce(n_train); dist.all_reduce(counts)        # noqa: E702
@@ -147,9 +180,20 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
         vcounts = torch.zeros(4, device=dev, dtype=torch.int64)
         with torch.no_grad():
             for s in valid_samples:
-                pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)
-                vloss += criterion(pred, s.y).double()
-                vcounts += tfpn_counts(pred, s.y)
+                if hp["batch_size_eval"] <= 1:
+                    pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)
+                    vloss += criterion(pred, s.y).double()
+                    vcounts += tfpn_counts(pred, s.y)
+                else:                                                                           # train.py:428-486
+                    gl = torch.zeros((), device=dev, dtype=torch.float64)
+                    nb = 0
+                    for sub in _cluster_batches(s, hp["num_parts_metis_eval"], hp["batch_size_eval"],
+                                                hp["partition_method"]):
+                        pred = model(sub, None, sub.edata["e"], sub.ndata["pe"]).squeeze(-1)
+                        gl += criterion(pred, sub.edata["y"]).double()
+                        nb += 1
+                        vcounts += tfpn_counts(pred, sub.edata["y"])
+                    vloss += gl / max(nb, 1)
         n_val = torch.tensor(float(len(valid_samples)), device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(vloss); dist.all_reduce(n_val); dist.all_reduce(vcounts)            # noqa: E702

@@ -499,6 +499,46 @@ def test_training_harness_counterpart(tmp_path):
     assert 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0
 
 
+def test_minibatch_mode_counterpart(tmp_path):
+    """ClusterGCN branch (train.py:282-343,428-486): a mini-batch is an induced sub-graph that goes through
+    the same model; its logits equal the oracle's on that sub-graph, and the loop trains."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import cluster, synth, train as T
+    from oracle import gatedgcn_oracle as orc
+    dev = _dev()
+    samples = []
+    for seed in range(2):
+        src, dst, n = synth.make_graph(3000, seed, permute_edge_ids=True)
+        inp = synth.make_inputs(src, dst, n, seed)
+        g = G.AssemblyGraph(src, dst, n).to(dev)
+        samples.append(T.GraphSample(g, torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(inp["pe"]).to(dev),
+                                     torch.from_numpy(inp["y"]).to(dev)))
+    # (i) one mini-batch against the oracle
+    s = samples[0]
+    loader = T._cluster_batches(s, 40, 7, "rcm")
+    sub = next(iter(loader))
+    assert 0 < sub.num_edges() < s.graph.num_edges() and sub.num_nodes() < s.graph.num_nodes()
+    H, L = 128, 2
+    sd = synth.synth_state_dict(H, L, 3)
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.to(dev)
+    with torch.no_grad():
+        got = model(sub, None, sub.edata["e"], sub.ndata["pe"])
+    ssrc, sdst = sub.edges()
+    with torch.no_grad():
+        want = orc.model_forward(sd_to_torch(sd, torch.float64), ssrc.cpu().long(), sdst.cpu().long(), sub.num_nodes(),
+                                 sub.edata["e"].cpu().double(), sub.ndata["pe"].cpu().double(), True)
+    assert_parity(got.cpu().numpy(), want.numpy(), "mini-batch logits vs oracle on the induced sub-graph")
+    # (ii) the loop
+    hp = dict(num_epochs=3, dim_latent=32, num_gnn_layers=2, lr=1e-2, batch_size_train=4, batch_size_eval=6,
+              num_parts_metis_train=112, num_parts_metis_eval=20)
+    model, best, hist = T.train(samples[:1], samples[1:], out="mb", hyperparameters=hp, workdir=str(tmp_path), verbose=False)
+    assert len(hist.loss_train) == 3 and all(np.isfinite(hist.loss_train)) and all(np.isfinite(hist.loss_valid))
+    assert hist.loss_train[-1] < hist.loss_train[0]
+    assert (tmp_path / "checkpoints" / "mb.pt").exists()
+
+
 @pytest.mark.parametrize("H,L,bn", [(256, 2, True), (64, 3, False), (128, 2, False), (32, 1, True), (128, 3, True)])
 def test_other_widths_and_norms_vs_oracle(H, L, bn):
     """Widths / depths / norm modes without a golden fixture: the HIP path (generic GEMM + row kernels
