@@ -65,6 +65,8 @@ SIGNATURES = {
     "gnm_predictor_fused_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_tn128_workspace_bytes": (_sz, []),
     "gnm_tn128": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_decode_build_adjacency": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p]),
+    "gnm_decode_iteration": (_i64, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _i64, _p]),
     "gnm_reduce_partials": (_i32, [_p, _i32, _i32, _i32, _p, _p]),
     "gnm_seg_sum_rows": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "gnm_pagerank_pe_workspace_bytes": (_sz, [_i64]),

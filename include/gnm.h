@@ -55,6 +55,28 @@ int gnm_graph_build_index(const int32_t* src, const int32_t* dst, int64_t N, int
                           int32_t* perm, int32_t* isrc, int32_t* idst, int32_t* in_ptr,
                           int32_t* out_ptr, int32_t* out_pos, int32_t* out_dst);
 
+/* ---- greedy decode (HOST pointers, sequential CPU work; inference.py:31-77,182-253) ----------
+ * build_adjacency: successors / predecessors of every node in edge-id order, as the reference's
+ *   succ / pred dicts (graph_parser.py:13-73); *_eid[p] = edges[(node, nbr)] of its edges dict, i.e. the
+ *   LAST edge id of a duplicated (src, dst) pair.  ptr arrays hold N+1, nbr / eid arrays E entries.
+ * decode_iteration: one pass of get_contigs' loop body for `nb` sampled start edges
+ *   (start_src[i] -> start_dst[i]): greedy forward walk from the head, backward walk from the tail
+ *   (forced single-neighbour moves, otherwise the best-scored neighbour that is neither in visited[]
+ *   nor consumed by this walk; a node consumes its reverse complement node ^ 1), the walk with the
+ *   greatest reconstructed length (sum of prefix_length over its edges + read_length of its last node)
+ *   wins.  Returns its node count, the nodes in walk_out, the length in *best_length_out; when the count is
+ *   >= len_threshold, visited[] (N bytes, in/out) absorbs the walk, the complements and the jumped-over
+ *   nodes.  < 0: error (-3: a cycle of forced moves, on which the reference does not terminate).     */
+int gnm_decode_build_adjacency(const int32_t* src, const int32_t* dst, int64_t N, int64_t E,
+                               int32_t* succ_ptr, int32_t* succ_nbr, int32_t* succ_eid,
+                               int32_t* pred_ptr, int32_t* pred_nbr, int32_t* pred_eid);
+int64_t gnm_decode_iteration(int64_t N, const float* scores, const int64_t* prefix_length,
+                             const int64_t* read_length, const int32_t* succ_ptr, const int32_t* succ_nbr,
+                             const int32_t* succ_eid, const int32_t* pred_ptr, const int32_t* pred_nbr,
+                             const int32_t* pred_eid, uint8_t* visited, int nb, const int32_t* start_src,
+                             const int32_t* start_dst, int len_threshold, int32_t* walk_out,
+                             int64_t walk_cap, int64_t* best_length_out);
+
 /* ---- dense (fp32 MFMA v_mfma_f32_32x32x2_f32): nn.Linear call sites
  *      gated_gcn_full.py:107-113, full_graph.py:23-26, score_predictor.py:15-17 and their
  *      autograd duals.  TN mode reduces over K with split-K partials in the workspace. */

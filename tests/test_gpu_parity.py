@@ -499,6 +499,32 @@ def test_training_harness_counterpart(tmp_path):
     assert 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0
 
 
+def test_inference_and_decode_counterpart():
+    """inference.py:444-490: no_grad logits by edge id -> greedy decode; the walks equal the oracle's on the
+    same logits and seed (the decode consumes scores BY EDGE ID, so this also checks the output order)."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import decode, synth
+    from oracle import decode_oracle as dorc
+    dev = _dev()
+    src, dst, n = synth.make_graph(1500, 5, permute_edge_ids=True)
+    inp = synth.make_inputs(src, dst, n, 5)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    model = G.GraphGatedGCNModel(1, 2, 128, 16, 2, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(128, 2, 5).items()})
+    model.to(dev)
+    rng = np.random.default_rng(5)
+    pl, rl = rng.integers(500, 12000, src.size), rng.integers(8000, 25000, n)
+    torch.manual_seed(7)
+    scores, walks = decode.infer_contigs(model, g, torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(inp["pe"]).to(dev),
+                                         pl, rl, nb_paths=10, len_threshold=10)
+    assert scores.shape == (src.size,) and len(walks) > 0
+    torch.manual_seed(7)
+    want = dorc.get_contigs(src, dst, n, scores.cpu().numpy(), pl, rl, nb_paths=10, len_threshold=10)
+    assert walks == want
+    for w in walks:                        # every step of a walk is an edge of the graph
+        assert all((a, b) in set(zip(src.tolist(), dst.tolist())) for a, b in zip(w[:2], w[1:3]))
+
+
 def test_minibatch_mode_counterpart(tmp_path):
     """ClusterGCN branch (train.py:282-343,428-486): a mini-batch is an induced sub-graph that goes through
     the same model; its logits equal the oracle's on that sub-graph, and the loop trains."""
