@@ -656,6 +656,154 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
   }
 }
 
+// fp32 variant with 32-row tiles: 236 VGPRs and 37 KB of LDS, so TWO workgroups share a CU and one's
+// gt prologue / epilogue runs under the other's MFMAs (the 64-row kernel above holds 416 registers
+// and leaves the matrix pipe idle during those phases: 68 % busy).
+constexpr int FTR2 = 32;
+
+__global__ __launch_bounds__(kBlock, 2) void edge_bwd_fused32_k(
+    int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
+    const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
+    const void* __restrict__ Wp, float* __restrict__ slab, double* __restrict__ partials, int64_t tiles_per_block) {
+  __shared__ float gs[FTR2 * FP];      // gt tile, later the transposed output image
+  __shared__ float es[FTR2 * FP];      // e_in tile
+  __shared__ float cs[7 * FH];         // mu, rstd, scale, shift, m1, m2, c = gamma*rstd
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (E + FTR2 - 1) / FTR2;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, E / FTR2);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Elast = E - 1;
+  for (int c = tid; c < FH; c += kBlock) {
+    cs[c] = stat[c];
+    cs[FH + c] = stat[FH + c];
+    cs[2 * FH + c] = stat[2 * FH + c];
+    cs[3 * FH + c] = stat[3 * FH + c];
+    cs[4 * FH + c] = bstat[c];
+    cs[5 * FH + c] = bstat[FH + c];
+    cs[6 * FH + c] = gamma[c] * stat[FH + c];
+  }
+  MmF32::Frag wf;
+  MmF32::load_w(wf, Wp, wave, lane);
+  floatx16 tn[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
+  double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;
+  __syncthreads();
+
+  float4 pg[4], pt[4], pe_[4];
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile * FTR2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t o = clampi(r0 + lrow + 8 * it, Elast) * FH + lc4;
+      pg[it] = ld4(ge + o);
+      pt[it] = ld4(t + o);
+      pe_[it] = ld4(e_in + o);
+    }
+  };
+  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * FTR2;
+    float4 gk[4];
+    {
+      const float4 mu = ld4(cs + lc4), rs = ld4(cs + FH + lc4), sc = ld4(cs + 2 * FH + lc4),
+                   sh = ld4(cs + 3 * FH + lc4), m1 = ld4(cs + 4 * FH + lc4), m2 = ld4(cs + 5 * FH + lc4),
+                   cc = ld4(cs + 6 * FH + lc4);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = lrow + 8 * it;
+        const bool ok = FULL || (r0 + row < E);
+        gk[it] = pg[it];
+        const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
+        float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
+        float4 ev = pe_[it];
+        if (!ok) { gt = f4(0.f); ev = f4(0.f); }
+        cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
+        st4(gs + row * FP + lc4, gt);
+        st4(es + row * FP + lc4, ev);
+      }
+    }
+    __syncthreads();
+    prefetch(tile + 1 < tb1 ? tile + 1 : tile);
+    // ---- acc = gt W3 (32 rows x this wave's 32 columns) ----
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    {
+      const float* p0 = gs + li * FP + 4 * lg;
+      float4 a0 = ld4(p0);
+#pragma unroll
+      for (int q = 0; q < FKQ; ++q) {
+        float4 n0 = a0;
+        if (q + 1 < FKQ) n0 = ld4(p0 + 8 * (q + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(acc, a0, wf.w[q]);
+        a0 = n0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- gW3[n][c] += sum_rows gt[row][n] e_in[row][c] over the tile's 32 rows ----
+    {
+      const float* ga = gs + 4 * lg * FP + li;
+      const float* eb = es + 4 * lg * FP + li;
+#pragma unroll
+      for (int q = 0; q < FTR2 / 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (8 * q + r) * FP;
+          const float a0 = ga[o + (2 * wn) * 32], a1 = ga[o + (2 * wn + 1) * 32];
+          const float b0 = eb[o + (2 * wc) * 32], b1 = eb[o + (2 * wc + 1) * 32];
+          tn[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, tn[0][0], 0, 0, 0);
+          tn[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, tn[0][1], 0, 0, 0);
+          tn[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, tn[1][0], 0, 0, 0);
+          tn[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, tn[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();   // gt / e_in images are dead: reuse gs as the transposed output image
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gs[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t grow = r0 + row;
+      if (FULL || grow < E) st4(ge_out + grow * FH + lc4, ld4(gs + row * FP + lc4) + gk[it]);
+    }
+    __syncthreads();
+  };
+  if (tb0 < tb1) prefetch(tb0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) st4(slab + (size_t)chunk * FH * FH + (lrow + 8 * it) * FH + lc4, f4(0.f));   // see edge_bwd_fused_k
+  for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
+  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
+
+  tn_store_slab<MmF32>(slab + (size_t)chunk * FH * FH, tn, wn, wc, li, lg);
+  double* red = reinterpret_cast<double*>(gs);     // 8 row-slots x 128 doubles = 8 KB
+  red[lrow * FH + lc4 + 0] = cg0;
+  red[lrow * FH + lc4 + 1] = cg1;
+  red[lrow * FH + lc4 + 2] = cg2;
+  red[lrow * FH + lc4 + 3] = cg3;
+  __syncthreads();
+  if (tid < FH) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_ += red[k * FH + tid];
+    partials[(size_t)chunk * FH + tid] = s_;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // node-level backward of the 5-way projection (autograd of gated_gcn_full.py:107-112):
 //   rowtile_nn_acc_k   gh_in = gh_out + gP W5            (K = 5*128, accumulated over 5 groups)
@@ -988,14 +1136,22 @@ template <class MM>
 static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in,
                                const float* stat_e, const float* bstat_e, const float* gamma_e, const float* W3,
                                float* gW3, float* gb3, double* partials, void* ws, void* stream) {
-  const int64_t ntiles = cdiv_(E, FTR);
-  const int grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k<MM>>());
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
   launch_pack<MM>(W3, FH, FH / 32, 1, ws, st);
   GNM_LAUNCH_CHECK("pack_w (NN)");
-  hipLaunchKernelGGL(edge_bwd_fused_k<MM>, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
-                     gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
+  int grid;
+  if constexpr (MM::kSplit) {
+    const int64_t ntiles = cdiv_(E, FTR);
+    grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k<MM>>());
+    hipLaunchKernelGGL(edge_bwd_fused_k<MM>, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
+                       gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
+  } else {
+    const int64_t ntiles = cdiv_(E, FTR2);
+    grid = persistent_grid(ntiles, 8, occ_blocks<edge_bwd_fused32_k>());
+    hipLaunchKernelGGL(edge_bwd_fused32_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
+                       gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
+  }
   GNM_LAUNCH_CHECK("edge_bwd_fused");
   hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
   GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
