@@ -665,3 +665,52 @@ def test_gradients_exact_for_the_branch_taken(case):
     _report(rows, f"branch_{case}.txt")
     bad = [r for r in rows if r[1] > 5e-5 and r[2] > max(GRAD_ABS_FLOOR, 1e-6 * gmax)]
     assert not bad, bad
+
+
+def test_full_size_forward_is_edge_id_order_equivariant():
+    """BASELINE config 2 size (E ~ 7.5 M): relabelling the edges permutes the logits and nothing else, up
+    to fp32 round-off (edges of one destination keep their caller order inside the internal layout, so
+    the order of a node's segmented sums follows the labels), and a repeated run is bit-identical."""
+    import gnnome_assembly_amd as G
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(750000, 128, 8, 0, dev)
+    e = torch.from_numpy(inp["e"]).to(dev)
+    pe = torch.from_numpy(inp["pe"]).to(dev)
+    with torch.no_grad():
+        s0 = model(G.AssemblyGraph(src, dst, n).to(dev), None, e, pe)
+        perm = torch.randperm(src.size, generator=torch.Generator().manual_seed(1))
+        pn = perm.numpy()
+        s1 = model(G.AssemblyGraph(src[pn], dst[pn], n).to(dev), None, e[perm.to(dev)], pe)
+        s2 = model(G.AssemblyGraph(src, dst, n).to(dev), None, e, pe)
+    assert bool(torch.isfinite(s0).all()) and torch.equal(s2, s0)
+    want = s0[perm.to(dev)]
+    r = float((s1 - want).double().norm() / want.double().norm())
+    print(f"full-size permutation equivariance: rel_l2 {r:.2e}, max abs {float((s1 - want).abs().max()):.2e}")
+    assert r <= 2e-5 and float((s1 - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline and cpu_baseline objects."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--reads", "30000", "--steps", "2", "--warmup", "1",
+                          "--cpu-reads", "2000"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["unit"] == "edges/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and "workload" in r["config"]
+    assert abs(r["value"] - r["config"]["edges"] / (r["ms_per_step"] / 1e3)) <= 1e-6 * r["value"]
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s" and cb["sample"]
+    assert r["alt_matmul"]["matmul"] == "bf16x3" and r["alt_matmul"]["value"] > 0
