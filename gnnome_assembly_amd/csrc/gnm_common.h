@@ -38,7 +38,10 @@ int reduce_partials_strided(const double* partials, int nblk, int row_stride, in
 
 // Grid for the persistent row/segment kernels: a multiple of 8 (one slice per XCD),
 // at most kMaxPartialBlocks, at least enough to give every block `min_items` items.
+int occupancy_cap();   // 0 = none; see gnm_set_occupancy_cap
 inline int persistent_grid(int64_t items, int64_t min_items_per_block, int blocks_per_cu) {
+  const int cap_ = occupancy_cap();
+  if (cap_ > 0 && blocks_per_cu > cap_) blocks_per_cu = cap_;
   int64_t want = (items + min_items_per_block - 1) / min_items_per_block;
   int64_t cap = (int64_t)num_cus() * blocks_per_cu;
   if (cap > kMaxPartialBlocks) cap = kMaxPartialBlocks;

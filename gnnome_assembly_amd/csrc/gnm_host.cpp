@@ -34,8 +34,16 @@ int num_cus() {
   return cus;
 }
 
+static int g_occ_cap = 0;
+int occupancy_cap() { return g_occ_cap; }
+
 }  // namespace gnm
 
+extern "C" int gnm_set_occupancy_cap(int blocks_per_cu) {
+  GNM_CHECK_ARG(blocks_per_cu >= 0 && blocks_per_cu <= 8, "set_occupancy_cap: %d outside [0, 8]", blocks_per_cu);
+  gnm::g_occ_cap = blocks_per_cu;
+  return 0;
+}
 extern "C" int gnm_abi_version(void) { return GNM_ABI_VERSION; }
 extern "C" const char* gnm_last_error(void) { return gnm::g_err; }
 extern "C" int gnm_num_cus(void) { return gnm::num_cus(); }

@@ -11,6 +11,7 @@ back to the caller's edge-id order.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -96,14 +97,30 @@ class _Scratch:
         return self._ws
 
 
-_scratch: Dict[torch.device, _Scratch] = {}
+_scratch: Dict[tuple, _Scratch] = {}
 
 
-def scratch(device) -> _Scratch:
+def scratch(device, key: str = "main") -> _Scratch:
     device = torch.device(device)
-    if device not in _scratch:
-        _scratch[device] = _Scratch(device)
-    return _scratch[device]
+    if (device, key) not in _scratch:
+        _scratch[(device, key)] = _Scratch(device)
+    return _scratch[(device, key)]
+
+
+# Two-stream backward (CORUN, opt-in: GNM_CORUN=1): the MFMA-bound fused edge backward runs on a side
+# stream, capped at one workgroup per CU, while the HBM-bound by-source pass runs beside it on the main
+# stream.  Measured: the pair takes 7.3 ms together instead of 4.9 + 3.2 ms (both slow down: the
+# by-source kernel is latency-bound at the 2 workgroups per CU that still fit), i.e. -0.6 ms per layer
+# (2 %) for one more [E,H] buffer -- inside the box-to-box spread, so it is not the default.
+CORUN = os.environ.get("GNM_CORUN", "0") == "1"
+_side_streams: Dict[torch.device, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device):
+    device = torch.device(device)
+    if device not in _side_streams:
+        _side_streams[device] = torch.cuda.Stream(device=device)
+    return _side_streams[device]
 
 
 # ---------------------------------------------------------------------------------------
@@ -304,13 +321,33 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
               _ptr(sc.partials), C.byref(nblk), st)
         bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
+        corun = CORUN and H == 128 and FUSED and _prof is None
+        if corun:
+            # fused edge backward (MFMA-bound) on the side stream, one workgroup per CU, writing a fresh ge ...
+            main, side = torch.cuda.current_stream(), _side_stream(dev)
+            sc2 = scratch(dev, "side")
+            g["b3"] = torch.empty(H, **f32)
+            ge_new = torch.empty_like(ge)
+            need = lib.gnm_edge_bwd_fused_workspace_bytes()
+            ws2 = sc2.ws(need)
+            side.wait_stream(main)
+            lib.gnm_set_occupancy_cap(1)
+            _lib.check(lib.gnm_edge_bwd_fused(E, H, _ptr(ge), _ptr(ge_new), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e),
+                                              _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]),
+                                              _ptr(sc2.partials), _ptr(ws2), need, C.c_void_p(side.cuda_stream)),
+                       "gnm_edge_bwd_fused")
+            lib.gnm_set_occupancy_cap(2)       # ... while the by-source pass (HBM-bound) shares the CUs
         # by-source pass: gA2h, gB1h, gB2h
         _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
               _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), st)
         del Ud, Td, Q
+        if corun:
+            lib.gnm_set_occupancy_cap(0)
+            main.wait_stream(side)
+            ge = ge_new
         # gt, B_3 gradients, ge_in = ge_tot + gt W3
-        if H == 128 and FUSED:
+        elif H == 128 and FUSED:
             g["b3"] = torch.empty(H, **f32)
             need = lib.gnm_edge_bwd_fused_workspace_bytes()
             ws = sc.ws(need)

@@ -44,6 +44,10 @@ const char* gnm_last_error(void);
 int gnm_num_cus(void);
 /* upper bound on the number of per-block partial rows any kernel writes (see *_partials) */
 int gnm_max_partial_blocks(void);
+/* Cap on the workgroups per CU the persistent kernels size their grids for (0 = none, the default:
+ * one full resident wave of workgroups).  A host that runs two kernels on two streams at once sets
+ * it around each launch so that both fit on every CU (process-wide, not thread-safe).          */
+int gnm_set_occupancy_cap(int blocks_per_cu);
 
 /* ---- graph index (HOST pointers; replaces DGL's lazy CSR/CSC build + dgl.reverse,
  *      layers/gated_gcn_full.py:115, graph_parser.py:297 edge-id order) -------------------

@@ -714,3 +714,31 @@ def test_bench_line_contract(tmp_path):
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s" and cb["sample"]
     assert r["alt_matmul"]["matmul"] == "bf16x3" and r["alt_matmul"]["value"] > 0
+
+
+def test_two_stream_backward_option_changes_nothing_but_rounding():
+    """engine.CORUN (GNM_CORUN=1): fused edge backward on a side stream beside the by-source pass.  Same
+    kernels, only the number of per-workgroup gW3 slabs differs -> gradients equal to fp32 round-off."""
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+
+    def run():
+        model, src, dst, n, inp = _model_and_inputs(20000, 128, 3, 2, dev)
+        import gnnome_assembly_amd as G
+        g = G.AssemblyGraph(src, dst, n).to(dev)
+        crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+        s = model(g, None, torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(inp["pe"]).to(dev))
+        crit(s.squeeze(-1), torch.from_numpy(inp["y"]).to(dev)).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
+    base = run()
+    engine.CORUN = True
+    try:
+        co = run()
+        co2 = run()
+    finally:
+        engine.CORUN = False
+    for k in base:
+        assert torch.equal(co[k], co2[k]), k                                   # still deterministic
+        d = float((co[k] - base[k]).abs().max())
+        assert d <= 1e-5 * float(base[k].abs().max()) + 1e-9, (k, d)

@@ -43,11 +43,24 @@ def main():
         ge = ge0.clone()
         engine.layer_backward(idx, n, E, H, prm, s, gh, ge)
     ops = engine.profile_ops(False)
+    # wall time of the same layer without per-op events (the two-stream mode only runs un-profiled)
+    import time
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(a.iters):
+            h1, e1, s = engine.layer_forward(idx, n, E, H, prm, h, e, True)
+            ge = ge0.clone()
+            engine.layer_backward(idx, n, E, H, prm, s, gh, ge)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / a.iters * 1e3
+    wall_msg = f"layer fwd+bwd wall {wall:.2f} ms (incl. one [E,H] clone, CORUN={engine.CORUN})"
     tot = 0.0
     for k, (c, t) in sorted(ops.items(), key=lambda kv: -kv[1][1]):
         print(f"{k:34s} calls={c:3d} avg_ms={t / c:8.3f}")
         tot += t / a.iters
     print(f"layer fwd+bwd total {tot:.2f} ms  (E={E}, N={n}, H={H})")
+    print(wall_msg)
 
 
 if __name__ == "__main__":
