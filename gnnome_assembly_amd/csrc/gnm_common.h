@@ -78,6 +78,19 @@ __device__ __forceinline__ int xcd_chunk(int b, int nb) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// Streaming ("read or written once by this launch") rows: non-temporal hint, so that the [E,H]
+// streams do not push the gathered node rows -- which ARE re-used, by the ~5 edges of a node -- out of
+// the 4 MB per-XCD L2.
+typedef float floatx4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  const floatx4_ v = __builtin_nontemporal_load(reinterpret_cast<const floatx4_*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  const floatx4_ w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<floatx4_*>(p));
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }

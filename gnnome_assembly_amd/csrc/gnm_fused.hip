@@ -427,7 +427,10 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = tile * FTR;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) pre[it] = ld4(X + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+    for (int it = 0; it < 8; ++it) {
+      const float* px = X + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4;
+      pre[it] = EDGE ? ld4_nt(px) : ld4(px);      // edge rows stream through once; keep L2 for the gathered node rows
+    }
     if (EDGE) {
       const int64_t r = clampi(r0 + (tid & (FTR - 1)), Mlast);
       pre_idx = (tid & FTR) ? idst[r] : isrc[r];     // threads 0-63: src, 64-127: dst (128-255 unused)
@@ -488,7 +491,8 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
         float4 v = ld4(os + row * FP + lc4) + b4;
         if (EDGE) v = v + g1[it] + g2[it];
         if (FULL || grow < M) {
-          st4(Y + grow * ldy + (cgb + cg) * FH + lc4, v);
+          if (EDGE) st4_nt(Y + grow * ldy + (cgb + cg) * FH + lc4, v);
+          else st4(Y + grow * ldy + (cgb + cg) * FH + lc4, v);
           if (EDGE) st.add_prod(v, v);
         }
       }

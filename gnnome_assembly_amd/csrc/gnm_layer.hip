@@ -75,11 +75,11 @@ __global__ __launch_bounds__(kBlock) void edge_gate_fwd_k(int64_t N, const float
     float4 num = f4(0.f), den = f4(0.f);
     for (int64_t j = a + sub; j < b; j += RPW) {
       const int64_t s = isrc[j];
-      const float4 tt = ld4(t + j * H + c4);
-      const float4 ee = ld4(e_in + j * H + c4);
+      const float4 tt = ld4_nt(t + j * H + c4);
+      const float4 ee = ld4_nt(e_in + j * H + c4);
       const float4 a2 = ld4(P + s * (5 * H) + H + c4);
       const float4 eo = relu4(fma4(tt, sc, sh)) + ee;
-      st4(e_out + j * H + c4, eo);
+      st4_nt(e_out + j * H + c4, eo);
       const float4 sg = sigmoid4(eo);
       num = fma4(sg, a2, num);
       den += sg;
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(kBlock) void edge_gate_fwd_k(int64_t N, const float
     if (sub == 0) {
       const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen),
                                      1.f / (den.z + kEpsDen), 1.f / (den.w + kEpsDen));
-      st4(hf + v * H + c4, num * inv);
-      st4(inv_f + v * H + c4, inv);
+      st4_nt(hf + v * H + c4, num * inv);
+      st4_nt(inv_f + v * H + c4, inv);
     }
   }
 }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void node_agg_src_fwd_k(
     float4 num = f4(0.f), den = f4(0.f);
     for (int64_t m = a + sub; m < b; m += RPW) {
       const int64_t j = out_pos[m], d = out_dst[m];
-      const float4 sg = sigmoid4(ld4(e_out + j * H + c4));
+      const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
       const float4 a3 = ld4(P + d * (5 * H) + 2 * H + c4);
       num = fma4(sg, a3, num);
       den += sg;
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(kBlock) void node_agg_src_fwd_k(
       const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen),
                                      1.f / (den.z + kEpsDen), 1.f / (den.w + kEpsDen));
       const float4 b_ = num * inv;
-      const float4 zz = ld4(P + v * (5 * H) + c4) + ld4(hf + v * H + c4) + b_;
-      st4(hb + v * H + c4, b_);
-      st4(inv_b + v * H + c4, inv);
-      st4(z + v * H + c4, zz);
+      const float4 zz = ld4_nt(P + v * (5 * H) + c4) + ld4_nt(hf + v * H + c4) + b_;
+      st4_nt(hb + v * H + c4, b_);
+      st4_nt(inv_b + v * H + c4, inv);
+      st4_nt(z + v * H + c4, zz);
       st.add_prod(zz, zz);
     }
   }
@@ -248,20 +248,20 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_dst_k(
     const int a = in_ptr[v], b = in_ptr[v + 1];
     float4 a3acc = f4(0.f), ud = f4(0.f), td = f4(0.f);
     if (a < b) {
-      const float4 qf_d = ld4(Q + v * (4 * H) + c4);
-      const float4 rf_d = ld4(Q + v * (4 * H) + H + c4);
-      const float4 a3_d = ld4(P + v * (5 * H) + 2 * H + c4);
+      const float4 qf_d = ld4_nt(Q + v * (4 * H) + c4);       // this node's own segments: read once here
+      const float4 rf_d = ld4_nt(Q + v * (4 * H) + H + c4);
+      const float4 a3_d = ld4_nt(P + v * (5 * H) + 2 * H + c4);
       for (int64_t j = a + sub; j < b; j += RPW) {
         const int64_t s = isrc[j];
         float4 sg, dsg;
-        sigmoid_grad4(ld4(e_out + j * H + c4), sg, dsg);
+        sigmoid_grad4(ld4_nt(e_out + j * H + c4), sg, dsg);
         const float4 a2_s = ld4(P + s * (5 * H) + H + c4);
         const float4 qb_s = ld4(Q + s * (4 * H) + 2 * H + c4);
         const float4 rb_s = ld4(Q + s * (4 * H) + 3 * H + c4);
         const float4 gsig = fma4(qf_d, a2_s, fma4(qb_s, a3_d, f4(0.f) - rf_d - rb_s));
-        const float4 g = fma4(gsig, dsg, ld4(ge + j * H + c4));
-        st4(ge + j * H + c4, g);
-        const float4 tt = ld4(t + j * H + c4);
+        const float4 g = fma4(gsig, dsg, ld4_nt(ge + j * H + c4));
+        st4_nt(ge + j * H + c4, g);
+        const float4 tt = ld4_nt(t + j * H + c4);
         const float4 gu = gate4(fma4(tt, sc, sh), g);
         const float4 th = (tt - mu) * rs;
         st.add_prod(gu, th);
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_dst_k(
       td += shfl_xor4(td, off);
     }
     if (sub == 0) {
-      st4(gP + v * (5 * H) + 2 * H + c4, a3acc);
-      st4(Ud + v * H + c4, ud);
-      st4(Td + v * H + c4, td);
+      st4_nt(gP + v * (5 * H) + 2 * H + c4, a3acc);
+      st4_nt(Ud + v * H + c4, ud);
+      st4_nt(Td + v * H + c4, td);
     }
   }
   block_stat_store<H>(st, lds, partials, chunk);
@@ -311,10 +311,10 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_src_k(
     float4 a2acc = f4(0.f), us = f4(0.f), ts = f4(0.f);
     for (int64_t m = a + sub; m < b; m += RPW) {
       const int64_t j = out_pos[m], d = out_dst[m];
-      const float4 sg = sigmoid4(ld4(e_out + j * H + c4));
+      const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
       const float4 qf_d = ld4(Q + d * (4 * H) + c4);
-      const float4 tt = ld4(t + j * H + c4);
-      const float4 gu = gate4(fma4(tt, sc, sh), ld4(ge + j * H + c4));
+      const float4 tt = ld4_nt(t + j * H + c4);
+      const float4 gu = gate4(fma4(tt, sc, sh), ld4_nt(ge + j * H + c4));
       a2acc = fma4(sg, qf_d, a2acc);
       us += gu;
       ts += (tt - mu) * rs;
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_src_k(
       const float outdeg = (float)(b - a);
       const float indeg = (float)(in_ptr[v + 1] - in_ptr[v]);
       float* g = gP + v * (5 * H) + c4;
-      st4(g + H, a2acc);
-      st4(g + 3 * H, c * (us - m1 * outdeg - m2 * ts));
-      st4(g + 4 * H, c * (ld4(Ud + v * H + c4) - m1 * indeg - m2 * ld4(Td + v * H + c4)));
+      st4_nt(g + H, a2acc);
+      st4_nt(g + 3 * H, c * (us - m1 * outdeg - m2 * ts));
+      st4_nt(g + 4 * H, c * (ld4_nt(Ud + v * H + c4) - m1 * indeg - m2 * ld4_nt(Td + v * H + c4)));
     }
   }
 }

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlock, 2) void pred_fwd_k(
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = tile * PT;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) pre[it] = ld4(e + clampr(r0 + lrow + 8 * it, Elast) * PH + lc4);
+    for (int it = 0; it < 8; ++it) pre[it] = ld4_nt(e + clampr(r0 + lrow + 8 * it, Elast) * PH + lc4);
     pre_idx = ibase[clampr(r0 + lane, Elast)];
   };
   auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock, 2) void pred_fwd_k(
       const int row = p * 16 + er;
       const int64_t grow = r0 + row;
       float4 v = ld4(os + row * PGP + ec4) + b1v + gsv[p] + gdv[p];
-      if (SAVE && (FULL || grow < E)) st4(hid + grow * PS + ec4, v);
+      if (SAVE && (FULL || grow < E)) st4_nt(hid + grow * PS + ec4, v);
       const float4 r = relu4(v);
       float dot = r.x * w2v.x + r.y * w2v.y + r.z * w2v.z + r.w * w2v.w;
 #pragma unroll
