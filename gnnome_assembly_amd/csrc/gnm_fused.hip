@@ -346,6 +346,24 @@ __device__ __forceinline__ void tn_store_slab(float* __restrict__ sl, const floa
       }
 }
 
+// rows 0-31 of a split row image x this wave's 32 weight columns (32-row tiles of the two-workgroup kernels)
+__device__ __forceinline__ void mma32_b3(const void* img, int row0, const MmB3::Frag& f, floatx16& acc, int li, int lg) {
+  const __bf16* p0 = reinterpret_cast<const __bf16*>(img) + (row0 + li) * BP + 8 * lg;
+#pragma unroll
+  for (int c = 0; c < BKC; ++c) {
+    bf16x8 a0[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a0[s] = *reinterpret_cast<const bf16x8*>(p0 + s * BIMG + 16 * c);
+    mfb(acc, a0[2], f.w[c][0]);
+    mfb(acc, a0[0], f.w[c][2]);
+    mfb(acc, a0[1], f.w[c][1]);
+    mfb(acc, a0[1], f.w[c][0]);
+    mfb(acc, a0[0], f.w[c][1]);
+    mfb(acc, a0[0], f.w[c][0]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Split-bf16 fragment pack: Wp3[cb][c][s][lane] (bf16x8), s = hi/mid/lo;
 //   NT: element j of lane (i,g) = W[(cb*32 + i) * ld + 16c + 8g + j];  NN: W[(16c + 8g + j) * ld + cb*32 + i]
 __global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int nn, bf16x8* __restrict__ Wp) {
@@ -946,6 +964,80 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nn_group_k(
   }
 }
 
+// The same with 32-row tiles: 26 KB of LDS and <= 256 VGPRs -> two workgroups per CU, so that the split
+// staging of one overlaps the MFMAs of the other.
+constexpr int NR3 = 32;
+template <int T>
+__global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const void* __restrict__ Wp,
+    const float* __restrict__ R, float* __restrict__ Y, int64_t groups_per_block) {
+  // the three bf16 images keep the 64-row layout of MmB3::stage; rows 0-31 / 32-63 are two tile buffers,
+  // so a step needs ONE barrier (the next step stages into the half the slower waves are not reading)
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);                    // later: 32 x 132 fp32 output image
+  static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ngroups = (M + NR3 * T - 1) / (NR3 * T);
+  const int64_t g0 = (int64_t)chunk * groups_per_block;
+  const int64_t g1 = min(ngroups, g0 + groups_per_block);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  // T steps (one whole column group of the row group) of rows in flight: a 32-row step of cheap MFMAs is
+  // far shorter than the HBM latency.  pre[tl] always holds tile tl of the NEXT column group.
+  float4 pre[T][4];
+  auto prefetch = [&](float4 (&buf)[4], int64_t g, int cg, int tl) __attribute__((always_inline)) {
+    if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
+    const int64_t r0 = (g * T + tl) * NR3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  if (g0 < g1) {
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) prefetch(pre[tl], g0, 0, tl);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t t0 = g * T;
+    floatx16 acc[T];
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
+    for (int cg = 0; cg < ncg; ++cg) {
+      MmB3::Frag wf;
+      MmB3::load_w(wf, Wp, cg * 4 + wave, lane);
+#pragma unroll
+      for (int tl = 0; tl < T; ++tl) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        __syncthreads();
+        prefetch(pre[tl], g, cg + 1, tl);
+        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) {
+      const int64_t r0 = (t0 + tl) * NR3;
+      float4 rr[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) rr[it] = ld4(R + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+      __syncthreads();   // MFMAs (first pass) / the previous tile's row reads are done with the image memory
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xs[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[tl][e];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        if (grow < M) st4(Y + grow * FH + lc4, ld4(xs + row * FP + lc4) + rr[it]);
+      }
+    }
+    __syncthreads();   // the output image overlays both tile buffers: done before the next group stages
+  }
+}
+
 // slab[(cg*nslot + slot)][n][c] = sum over the slot's rows of A[row][cg*128+n] * B[row][c];
 // partials[(cg*nslot + slot)][128] = column sums of A[:, cg*128 ..]
 template <class MM>
@@ -1043,6 +1135,130 @@ __global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void tn_colgroup_k(
     for (int k = 0; k < 8; ++k) s_ += red[k * FH + tid];
     partials[(size_t)(cg * nslot + slot) * FH + tid] = s_;
   }
+}
+
+// Split-mode TN with 32-row tiles: 61 KB of LDS and < 256 VGPRs, so two workgroups share a CU and one's
+// split / transposition VALU work runs under the other's MFMAs (with 64-row tiles and one workgroup per
+// CU the matrix pipe was 26 % busy).  A thread owns rows 8*wave .. +7 x columns 2*lane, 2*lane+1 of both
+// operands (float2 loads, 512 B per row and wave); column c = 2*cp + j is kept in slot 64*j + cp, so the
+// two ds_write_b128 per operand and image go to 64 consecutive slots and a fragment read of slots
+// 32*blk .. +31 is conflict-free at pitch 40 (5 sixteen-byte units).  MFMA block blk, index i therefore
+// stands for column 64*(blk & 1) + 2*i + (blk >> 1).
+constexpr int TR3 = 32;                 // rows per tile
+constexpr int TP3 = TR3 + 8;            // bf16 pitch of a slot
+constexpr int TIMG3 = FH * TP3;         // elements per transposed image
+
+__device__ __forceinline__ int colmap32(int blk, int i) { return 64 * (blk & 1) + 2 * i + (blk >> 1); }
+
+__global__ __launch_bounds__(kBlock, 2) void tn_colgroup32_b3_k(
+    int64_t M, const float* __restrict__ A, int64_t lda, int ncg, const float* __restrict__ B,
+    float* __restrict__ slab, double* __restrict__ partials, int nslot, int64_t tiles_per_slot) {
+  __shared__ __attribute__((aligned(16))) __bf16 ta[3 * TIMG3];
+  __shared__ __attribute__((aligned(16))) __bf16 tb[3 * TIMG3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;      // see tn_colgroup_k
+  const int cg = jj % ncg, slot = xcd * (nslot / kXcds) + jj / ncg;
+  const int64_t ntiles = (M + TR3 - 1) / TR3;
+  const int64_t tb0 = (int64_t)slot * tiles_per_slot;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_slot);
+  const int64_t Mlast = M - 1;
+  floatx16 tn[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
+  double c0 = 0.0, c1 = 0.0;            // column sums of A for columns 2*lane, 2*lane + 1
+  float2 pa[8], pb[8];
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * TR3 + 8 * wave;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t r = clampi(r0 + it, Mlast);
+      pa[it] = *reinterpret_cast<const float2*>(A + r * lda + cg * FH + 2 * lane);
+      pb[it] = *reinterpret_cast<const float2*>(B + r * FH + 2 * lane);
+    }
+  };
+  // 8 rows x 2 columns of one operand -> its three transposed images
+  auto stage = [&](__bf16* img, const float2 (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 h, m, l;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const float x = j ? v[it].y : v[it].x;
+        const __bf16 hh = (__bf16)x;
+        const float r1 = x - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[it] = hh;
+        m[it] = mm;
+        l[it] = (__bf16)(r1 - (float)mm);
+      }
+      __bf16* o = img + (64 * j + lane) * TP3 + 8 * wave;
+      *reinterpret_cast<bf16x8*>(o) = h;
+      *reinterpret_cast<bf16x8*>(o + TIMG3) = m;
+      *reinterpret_cast<bf16x8*>(o + 2 * TIMG3) = l;
+    }
+  };
+  if (tb0 < tb1) prefetch(tb0);
+  for (int64_t tile = tb0; tile < tb1; ++tile) {
+    const int64_t r0 = tile * TR3 + 8 * wave;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      if (r0 + it >= M) pa[it] = make_float2(0.f, 0.f);
+      c0 += (double)pa[it].x;
+      c1 += (double)pa[it].y;
+    }
+    stage(ta, pa);
+    stage(tb, pb);
+    __syncthreads();
+    prefetch(tile + 1);
+    const __bf16* qa = ta + ((2 * wn) * 32 + li) * TP3 + 8 * lg;
+    const __bf16* qb = tb + ((2 * wc) * 32 + li) * TP3 + 8 * lg;
+#pragma unroll
+    for (int kc = 0; kc < TR3 / 16; ++kc) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+          a[x][s_] = *reinterpret_cast<const bf16x8*>(qa + s_ * TIMG3 + x * 32 * TP3 + 16 * kc);
+          b[x][s_] = *reinterpret_cast<const bf16x8*>(qb + s_ * TIMG3 + x * 32 * TP3 + 16 * kc);
+        }
+#pragma unroll
+      for (int t_ = 0; t_ < 6; ++t_) {
+        const int sa = t_ == 0 ? 2 : (t_ == 2 || t_ == 3) ? 1 : 0;
+        const int sb = t_ == 1 ? 2 : (t_ == 2 || t_ == 4) ? 1 : 0;
+        mfb(tn[0][0], a[0][sa], b[0][sb]);
+        mfb(tn[0][1], a[0][sa], b[1][sb]);
+        mfb(tn[1][0], a[1][sa], b[0][sb]);
+        mfb(tn[1][1], a[1][sa], b[1][sb]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* sl = slab + (size_t)(cg * nslot + slot) * FH * FH;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = colmap32(2 * wn + a, (e & 3) + 8 * (e >> 2) + 4 * lg);
+        const int c = colmap32(2 * wc + b, li);
+        sl[n * FH + c] = tn[a][b][e];
+      }
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(ta);          // [4 waves][128] doubles
+  red[wave * FH + 2 * lane] = c0;
+  red[wave * FH + 2 * lane + 1] = c1;
+  __syncthreads();
+  if (tid < FH) partials[(size_t)(cg * nslot + slot) * FH + tid] = red[tid] + red[FH + tid] + red[2 * FH + tid] + red[3 * FH + tid];
 }
 
 // out[i] = sum_b slab[b][i], fixed order -> deterministic
@@ -1178,15 +1394,15 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
 static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,
                         double* partials, float* slab, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const int64_t ntiles = cdiv_(N, FTR);
-  const int occ = g_matmul_mode ? occ_blocks<tn_colgroup_k<MmB3>>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  const int64_t ntiles = cdiv_(N, g_matmul_mode ? TR3 : FTR);
+  const int occ = g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
   int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
   nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
   if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
   if (g_matmul_mode)
-    hipLaunchKernelGGL(tn_colgroup_k<MmB3>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
+    hipLaunchKernelGGL(tn_colgroup32_b3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
                        nslot, cdiv_(ntiles, nslot));
   else
     hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
@@ -1216,9 +1432,9 @@ static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* 
   GNM_LAUNCH_CHECK("pack_w (NN, node)");
   if constexpr (MM::kSplit) {
     constexpr int T = 4;
-    const int64_t ngroups = cdiv_(N, FTR * T);
-    const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn_group_k<MM, T>>());
-    hipLaunchKernelGGL((rowtile_nn_group_k<MM, T>), dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
+    const int64_t ngroups = cdiv_(N, NR3 * T);
+    const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn_group32_b3_k<T>>());
+    hipLaunchKernelGGL((rowtile_nn_group32_b3_k<T>), dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
                        (const void*)ws, gh_out, gh_in, cdiv_(ngroups, grid));
   } else {
     const int64_t ntiles = cdiv_(N, FTR);
