@@ -533,6 +533,98 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
 }
 
 // ------------------------------------------------------------------------------------------
+// Split-mode edge t kernel with 32-row tiles: t = e W3^T + b3 + B1h[src] + B2h[dst] + BatchNorm sums.
+// 69 KB of LDS and <= 256 VGPRs -> two workgroups per CU (the 64-row version needs 330 registers, and
+// with one wave per SIMD its split staging and epilogue leave the matrix pipe 32 % busy).  The two
+// 32-row halves of the three bf16 images are two tile buffers, the fp32 output image is separate.
+// ------------------------------------------------------------------------------------------
+constexpr int ER3 = 32;
+__global__ __launch_bounds__(kBlock, 2) void edge_t32_b3_k(
+    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
+    const int32_t* __restrict__ idst, double* __restrict__ partials, int64_t tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ float os[ER3 * FP];
+  __shared__ int sd[2][2 * ER3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (M + ER3 - 1) / ER3;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, M / ER3);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  const int32_t* const ibase = (lane & 32) ? idst : isrc;     // lanes 0-31: src of row lane, 32-63: dst of row lane-32
+
+  MmB3::Frag wf;
+  MmB3::load_w(wf, Wp, wave, lane);
+  const float4 b4 = ld4(bias + lc4);
+  float4 pre[2][4];
+  int pidx[2] = {0, 0};
+  auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+    idx = ibase[clampi(r0 + (lane & 31), Mlast)];
+  };
+  Stat4 st;
+  st.zero();
+  auto body = [&](auto tag, float4 (&buf)[4], int& idx, int64_t tile, int hb) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * hb + lrow + 8 * it, lc4, buf[it]);
+    sd[hb][lane] = idx;
+    __syncthreads();
+    float4 g1[4], g2[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t s_ = sd[hb][row], d_ = sd[hb][ER3 + row];
+      g1[it] = ld4(P + s_ * (5 * FH) + 3 * FH + lc4);
+      g2[it] = ld4(P + d_ * (5 * FH) + 4 * FH + lc4);
+    }
+    prefetch(buf, idx, tile + 2);
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    mma32_b3(xraw, 32 * hb, wf, acc, li, lg);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) os[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t grow = r0 + row;
+      const float4 v = ld4(os + row * FP + lc4) + b4 + g1[it] + g2[it];
+      if (FULL || grow < M) {
+        st4_nt(Y + grow * FH + lc4, v);
+        st.add_prod(v, v);
+      }
+    }
+  };
+  if (tb0 < tb1) {
+    prefetch(pre[0], pidx[0], tb0);
+    prefetch(pre[1], pidx[1], tb0 + 1);
+  }
+  int64_t tile = tb0;
+  for (; tile + 2 <= nfull; tile += 2) {
+    body(full_t{}, pre[0], pidx[0], tile, 0);
+    body(full_t{}, pre[1], pidx[1], tile + 1, 1);
+  }
+  // at most one more full tile and one ragged tile
+  int hb = 0;
+  for (; tile < tb1; ++tile, hb ^= 1) {
+    if (hb == 0) body(ragged_t{}, pre[0], pidx[0], tile, 0);
+    else body(ragged_t{}, pre[1], pidx[1], tile, 1);
+  }
+  __syncthreads();
+  block_stat_store<FH>(st, reinterpret_cast<double*>(xraw), partials, chunk);
+}
+
+// ------------------------------------------------------------------------------------------
 // fused edge backward: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
 // ------------------------------------------------------------------------------------------
 template <class MM>
@@ -1293,6 +1385,15 @@ static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, cons
   hipStream_t st = (hipStream_t)stream;
   launch_pack<MM>(W3, FH, FH / 32, 0, ws, st);
   GNM_LAUNCH_CHECK("pack_w (NT)");
+  if constexpr (MM::kSplit) {
+    const int64_t ntiles = cdiv_(E, ER3);
+    const int grid = persistent_grid(ntiles, 8, occ_blocks<edge_t32_b3_k>());
+    hipLaunchKernelGGL(edge_t32_b3_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                       partials, cdiv_(ntiles, grid));
+    GNM_LAUNCH_CHECK("edge_t_fused_fwd");
+    *nblk_out = grid;
+    return 0;
+  }
   const int64_t ntiles = cdiv_(E, FTR);
   const int grid = persistent_grid(ntiles, 4, occ_blocks<rowtile_nt_k<MM, true, 1>>());
   hipLaunchKernelGGL((rowtile_nt_k<MM, true, 1>), dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t,
