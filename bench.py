@@ -91,7 +91,7 @@ def op_model(op: str, N: int, E: int, H: int):
 
 # C-ABI op -> HIP kernel whose PMC traffic (profiles/r01_b_traffic.json) belongs to it
 OP_KERNEL = {
-    "gnm_edge_bwd_fused": "edge_bwd_fused_k<MmF32>", "gnm_edge_bwd_dst": "edge_bwd_dst_k<128>",
+    "gnm_edge_bwd_fused": "edge_bwd_fused32_k", "gnm_edge_bwd_dst": "edge_bwd_dst_k<128>",
     "gnm_edge_bwd_src": "edge_bwd_src_k<128>", "gnm_edge_gate_fwd": "edge_gate_fwd_k<128>",
     "gnm_node_agg_src_fwd": "node_agg_src_fwd_k<128>", "gnm_edge_t_fused_fwd": "rowtile_nt_k<MmF32, true, 1>",
     "gnm_node_proj_fwd": "rowtile_nt_k<MmF32, false, 5>", "gnm_node_bwd_apply": "node_bwd_apply_k<128>",
@@ -101,7 +101,7 @@ OP_KERNEL = {
 def measured_traffic(op, N, E, H):
     """Per-launch HBM bytes of `op` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), if they were taken on this workload."""
-    path = os.path.join(REPO, "profiles", "r01_d_traffic.json")
+    path = os.path.join(REPO, "profiles", "r01_e_traffic.json")
     if os.environ.get("GNM_MATMUL", "f32") not in ("", "f32", "fp32"):
         return None                              # the counters were taken in the default matmul mode
     try:
