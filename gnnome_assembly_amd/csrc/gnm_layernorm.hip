@@ -52,9 +52,9 @@ __global__ __launch_bounds__(kBlock) void ln_edge_gate_fwd_k(
     for (int64_t j = a + sub; j < b; j += RPW) {
       const int64_t s = isrc[j];
       float rstd;
-      const float4 th = row_normalize<H>(ld4(t + j * H + c4), rstd);
-      const float4 eo = relu4(fma4(th, ga, be)) + ld4(e_in + j * H + c4);
-      st4(e_out + j * H + c4, eo);
+      const float4 th = row_normalize<H>(ld4_nt(t + j * H + c4), rstd);
+      const float4 eo = relu4(fma4(th, ga, be)) + ld4_nt(e_in + j * H + c4);
+      st4_nt(e_out + j * H + c4, eo);
       const float4 sg = sigmoid4(eo);
       num = fma4(sg, ld4(P + s * (5 * H) + H + c4), num);
       den += sg;
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(kBlock) void ln_edge_gate_fwd_k(
     if (sub == 0) {
       const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen),
                                      1.f / (den.z + kEpsDen), 1.f / (den.w + kEpsDen));
-      st4(hf + v * H + c4, num * inv);
-      st4(inv_f + v * H + c4, inv);
+      st4_nt(hf + v * H + c4, num * inv);
+      st4_nt(inv_f + v * H + c4, inv);
     }
   }
 }
@@ -154,28 +154,28 @@ __global__ __launch_bounds__(kBlock) void ln_edge_bwd_dst_k(
     const int a = in_ptr[v], b = in_ptr[v + 1];
     float4 a3acc = f4(0.f), gtsum = f4(0.f);
     if (a < b) {
-      const float4 qf_d = ld4(Q + v * (4 * H) + c4);
-      const float4 rf_d = ld4(Q + v * (4 * H) + H + c4);
-      const float4 a3_d = ld4(P + v * (5 * H) + 2 * H + c4);
+      const float4 qf_d = ld4_nt(Q + v * (4 * H) + c4);
+      const float4 rf_d = ld4_nt(Q + v * (4 * H) + H + c4);
+      const float4 a3_d = ld4_nt(P + v * (5 * H) + 2 * H + c4);
       for (int64_t j = a + sub; j < b; j += RPW) {
         const int64_t s = isrc[j];
         float4 sg, dsg;
-        sigmoid_grad4(ld4(e_out + j * H + c4), sg, dsg);
+        sigmoid_grad4(ld4_nt(e_out + j * H + c4), sg, dsg);
         const float4 a2_s = ld4(P + s * (5 * H) + H + c4);
         const float4 qb_s = ld4(Q + s * (4 * H) + 2 * H + c4);
         const float4 rb_s = ld4(Q + s * (4 * H) + 3 * H + c4);
         const float4 gsig = fma4(qf_d, a2_s, fma4(qb_s, a3_d, f4(0.f) - rf_d - rb_s));
-        const float4 g = fma4(gsig, dsg, ld4(ge + j * H + c4));
-        st4(ge + j * H + c4, g);
+        const float4 g = fma4(gsig, dsg, ld4_nt(ge + j * H + c4));
+        st4_nt(ge + j * H + c4, g);
         float rstd;
-        const float4 th = row_normalize<H>(ld4(t + j * H + c4), rstd);
+        const float4 th = row_normalize<H>(ld4_nt(t + j * H + c4), rstd);
         const float4 gu = gate4(fma4(th, ga, be), g);
         st.add_prod(gu, th);
         const float4 ag = ga * gu;
         const float m1 = row_sum<G>(hsum4(ag)) * (1.0f / H);
         const float m2 = row_sum<G>(hsum4(ag * th)) * (1.0f / H);
         const float4 gtv = (ag - f4(m1) - th * m2) * rstd;
-        st4(gt + j * H + c4, gtv);
+        st4_nt(gt + j * H + c4, gtv);
         a3acc = fma4(sg, qb_s, a3acc);
         gtsum += gtv;
       }
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(kBlock) void ln_edge_bwd_dst_k(
       gtsum += shfl_xor4(gtsum, off);
     }
     if (sub == 0) {
-      st4(gP + v * (5 * H) + 2 * H + c4, a3acc);
-      st4(gP + v * (5 * H) + 4 * H + c4, gtsum);
+      st4_nt(gP + v * (5 * H) + 2 * H + c4, a3acc);
+      st4_nt(gP + v * (5 * H) + 4 * H + c4, gtsum);
     }
   }
   block_stat_store<H>(st, lds, partials, chunk);
@@ -211,9 +211,9 @@ __global__ __launch_bounds__(kBlock) void ln_edge_bwd_src_k(
     float4 a2acc = f4(0.f), gts = f4(0.f);
     for (int64_t m = a + sub; m < b; m += RPW) {
       const int64_t j = out_pos[m], d = out_dst[m];
-      const float4 sg = sigmoid4(ld4(e_out + j * H + c4));
+      const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
       a2acc = fma4(sg, ld4(Q + d * (4 * H) + c4), a2acc);
-      gts += ld4(gt + j * H + c4);
+      gts += ld4_nt(gt + j * H + c4);
     }
 #pragma unroll
     for (int off = G; off < 64; off <<= 1) {
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(kBlock) void ln_edge_bwd_src_k(
       gts += shfl_xor4(gts, off);
     }
     if (sub == 0) {
-      st4(gP + v * (5 * H) + H + c4, a2acc);
-      st4(gP + v * (5 * H) + 3 * H + c4, gts);
+      st4_nt(gP + v * (5 * H) + H + c4, a2acc);
+      st4_nt(gP + v * (5 * H) + 3 * H + c4, gts);
     }
   }
 }
