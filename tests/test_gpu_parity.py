@@ -742,3 +742,25 @@ def test_two_stream_backward_option_changes_nothing_but_rounding():
         assert torch.equal(co[k], co2[k]), k                                   # still deterministic
         d = float((co[k] - base[k]).abs().max())
         assert d <= 1e-5 * float(base[k].abs().max()) + 1e-9, (k, d)
+
+
+def test_cxx_host_through_the_c_abi(tmp_path):
+    """tests/cabi/host_layer.cpp: a C++ program with no Python and no torch runs one layer forward on
+    hipMalloc'd buffers through include/gnm.h + libgnm.so and checks it against its own fp64 loops."""
+    import shutil
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = shutil.which("hipcc")
+    assert hipcc, "hipcc not found"
+    exe = str(tmp_path / "host_layer")
+    libdir = os.path.join(repo, "gnnome_assembly_amd")
+    cc = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(repo, "include"),
+                         os.path.join(repo, "tests", "cabi", "host_layer.cpp"), "-L", libdir, "-lgnm", "-o", exe],
+                        capture_output=True, text=True, timeout=600)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", "")))
+    print(run.stdout)
+    assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
