@@ -1356,9 +1356,19 @@ __global__ __launch_bounds__(kBlock, 2) void tn_colgroup32_b3_k(
 // out[i] = sum_b slab[b][i], fixed order -> deterministic
 __global__ void slab_reduce_k(const float* __restrict__ slab, int nslab, int total, float* __restrict__ out) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    for (int b = 0; b < nslab; ++b) acc += slab[(size_t)b * total + i];
-    out[i] = acc;
+    // four independent chains (fixed order -> still deterministic): one chain of nslab dependent loads was
+    // the fixed cost that showed on small graphs
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* p = slab + i;
+    int b = 0;
+    for (; b + 3 < nslab; b += 4) {
+      a0 += p[(size_t)b * total];
+      a1 += p[(size_t)(b + 1) * total];
+      a2 += p[(size_t)(b + 2) * total];
+      a3 += p[(size_t)(b + 3) * total];
+    }
+    for (; b < nslab; ++b) a0 += p[(size_t)b * total];
+    out[i] = (a0 + a1) + (a2 + a3);
   }
 }
 
