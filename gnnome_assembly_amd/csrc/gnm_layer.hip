@@ -210,17 +210,17 @@ __global__ __launch_bounds__(kBlock) void node_bwd_apply_k(
     const float4 sc = ld4(stat + 2 * H + c4), sh = ld4(stat + 3 * H + c4);
     const float4 m1 = ld4(bstat + c4), m2 = ld4(bstat + H + c4);
     const float4 c = ld4(gamma + c4) * rs;
-    const float4 zz = ld4(z + o);
-    const float4 gw = gate4(fma4(zz, sc, sh), ld4(gh_out + o));
+    const float4 zz = ld4_nt(z + o);
+    const float4 gw = gate4(fma4(zz, sc, sh), ld4_nt(gh_out + o));
     const float4 gz = c * (gw - m1 - ((zz - mu) * rs) * m2);
-    st4(gP + v * (5 * H) + c4, gz);
-    const float4 qf = gz * ld4(inv_f + o);
-    const float4 qb = gz * ld4(inv_b + o);
+    st4_nt(gP + v * (5 * H) + c4, gz);
+    const float4 qf = gz * ld4_nt(inv_f + o);
+    const float4 qb = gz * ld4_nt(inv_b + o);
     float* q = Q + v * (4 * H) + c4;
-    st4(q, qf);
-    st4(q + H, qf * ld4(hf + o));
-    st4(q + 2 * H, qb);
-    st4(q + 3 * H, qb * ld4(hb + o));
+    st4_nt(q, qf);
+    st4_nt(q + H, qf * ld4_nt(hf + o));
+    st4_nt(q + 2 * H, qb);
+    st4_nt(q + 3 * H, qb * ld4_nt(hb + o));
   }
 }
 
