@@ -98,7 +98,7 @@ def induced_subgraph(graph: AssemblyGraph, node_mask: torch.Tensor) -> AssemblyG
     eid = torch.nonzero(keep, as_tuple=False).squeeze(1)
     s_sub = new_id[src[eid].long()]
     d_sub = new_id[dst[eid].long()]
-    sub = AssemblyGraph(s_sub, d_sub, int(nid.numel())).to(dev)
+    sub = AssemblyGraph.from_tensors(s_sub, d_sub, int(nid.numel()))        # edges and index stay on the device
     sub.ndata = {k: v[nid] for k, v in graph.ndata.items()}
     sub.edata = {k: v[eid] for k, v in graph.edata.items()}
     sub.ndata[NID] = nid

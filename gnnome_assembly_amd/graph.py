@@ -23,7 +23,54 @@ __all__ = ["AssemblyGraph", "from_dgl"]
 _INDEX_KEYS = ("perm", "isrc", "idst", "in_ptr", "out_ptr", "out_pos", "out_dst")
 
 
+def tensor_index(src: torch.Tensor, dst: torch.Tensor, n: int):
+    """The same seven index arrays as gnm_graph_build_index, built with tensor ops on the device the edge
+    list lives on (two stable sorts, two bincounts): for graphs that are born on the GPU, e.g. the induced
+    sub-graphs of the mini-batch mode, so that no edge list crosses PCIe.  Bit-identical to the host
+    builder (tests/test_host_cpu.py::test_tensor_index_equals_host_index)."""
+    s64, d64 = src.long(), dst.long()
+    perm = torch.sort(d64, stable=True).indices                       # stable by destination
+    isrc, idst = s64[perm], d64[perm]
+    zero = torch.zeros(1, dtype=torch.int64, device=src.device)
+    in_ptr = torch.cat((zero, torch.cumsum(torch.bincount(d64, minlength=n), 0)))
+    out_pos = torch.sort(isrc, stable=True).indices                   # by source, ascending internal position
+    out_ptr = torch.cat((zero, torch.cumsum(torch.bincount(s64, minlength=n), 0)))
+    i32 = lambda t: t.to(torch.int32).contiguous()  # noqa: E731
+    return {"perm": i32(perm), "isrc": i32(isrc), "idst": i32(idst), "in_ptr": i32(in_ptr), "out_ptr": i32(out_ptr),
+            "out_pos": i32(out_pos), "out_dst": i32(idst[out_pos])}
+
+
 class AssemblyGraph:
+    @classmethod
+    def from_tensors(cls, src: torch.Tensor, dst: torch.Tensor, num_nodes: int) -> "AssemblyGraph":
+        """A graph whose edge list already lives on a device: edges and index stay there (tensor_index);
+        the host copy is only made if something asks for it."""
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src and dst must be 1-D tensors of equal length")
+        g = cls.__new__(cls)
+        g._n = int(num_nodes)
+        g._src_t, g._dst_t = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
+        g._src_np = g._dst_np = None
+        g._host_index = None
+        g._dev_index = {}
+        g._dev_edges = {src.device: (g._src_t, g._dst_t)}
+        g.device = src.device
+        g.ndata = {}
+        g.edata = {}
+        return g
+
+    @property
+    def _src(self):
+        if self._src_np is None:
+            self._src_np = np.ascontiguousarray(self._src_t.cpu().numpy(), dtype=np.int32)
+        return self._src_np
+
+    @property
+    def _dst(self):
+        if self._dst_np is None:
+            self._dst_np = np.ascontiguousarray(self._dst_t.cpu().numpy(), dtype=np.int32)
+        return self._dst_np
+
     def __init__(self, src, dst, num_nodes=None):
         src = np.ascontiguousarray(_to_numpy(src), dtype=np.int32)
         dst = np.ascontiguousarray(_to_numpy(dst), dtype=np.int32)
@@ -32,8 +79,9 @@ class AssemblyGraph:
         if num_nodes is None:
             num_nodes = int(max(src.max(initial=-1), dst.max(initial=-1)) + 1)
         self._n = int(num_nodes)
-        self._src = src
-        self._dst = dst
+        self._src_np = src
+        self._dst_np = dst
+        self._src_t = self._dst_t = None
         self._host_index = None
         self._dev_index = {}      # device -> dict of int32 tensors
         self._dev_edges = {}      # device -> (src, dst) tensors
@@ -46,7 +94,7 @@ class AssemblyGraph:
         return self._n
 
     def num_edges(self):
-        return int(self._src.size)
+        return int(self._src_np.size if self._src_np is not None else self._src_t.numel())
 
     number_of_nodes = num_nodes
     number_of_edges = num_edges
@@ -108,8 +156,14 @@ class AssemblyGraph:
         """The index as int32 tensors on `device` (default: the graph's device)."""
         device = torch.device(device) if device is not None else self.device
         if device not in self._dev_index:
-            h = self.host_index()
-            self._dev_index[device] = {k: torch.from_numpy(v).to(device) for k, v in h.items()}
+            if self._src_t is not None and self._host_index is None:       # born on a device: build it there
+                idx = tensor_index(self._src_t, self._dst_t, self._n)
+                self._dev_index[self._src_t.device] = idx
+                if device != self._src_t.device:
+                    self._dev_index[device] = {k: v.to(device) for k, v in idx.items()}
+            else:
+                h = self.host_index()
+                self._dev_index[device] = {k: torch.from_numpy(v).to(device) for k, v in h.items()}
         return self._dev_index[device]
 
 

@@ -130,3 +130,23 @@ def test_harness_metrics_match_reference_definitions():
     assert np.allclose(T.calculate_metrics(TP, TN, FP, FN), z["metrics"])
     assert T.calculate_metrics(0, 5, 0, 0) == (1.0, 0, 0, 0)
     assert abs(T.get_hyperparameters()["decay"] - 0.95) < 1e-12
+
+
+def test_tensor_index_equals_host_index():
+    """graph.tensor_index (tensor ops, used for graphs born on a device) == gnm_graph_build_index (host)."""
+    import numpy as np
+    import torch
+    from gnnome_assembly_amd import AssemblyGraph, synth
+    from gnnome_assembly_amd.graph import tensor_index
+    cases = [synth.make_graph(300, 1, permute_edge_ids=True), synth.tiny_edge_case_graph()]
+    cases.append((np.array([2, 2, 0], np.int32), np.array([2, 0, 1], np.int32), 5))     # isolated nodes, self loop
+    for src, dst, n in cases:
+        want = AssemblyGraph(src, dst, n).host_index()
+        got = tensor_index(torch.from_numpy(np.asarray(src, np.int32)), torch.from_numpy(np.asarray(dst, np.int32)), int(n))
+        for k, v in want.items():
+            assert np.array_equal(got[k].numpy(), v), k
+        g = AssemblyGraph.from_tensors(torch.from_numpy(np.asarray(src, np.int32)), torch.from_numpy(np.asarray(dst, np.int32)), int(n))
+        assert g.num_edges() == len(src) and g.num_nodes() == n
+        for k, v in want.items():
+            assert np.array_equal(g.index()[k].numpy(), v), k
+        assert np.array_equal(g._src, np.asarray(src, np.int32))        # lazy host copy
