@@ -41,9 +41,9 @@ __global__ __launch_bounds__(kBlock) void edge_t_stats_fwd_k(int64_t E, float* _
   st.zero();
   for (int64_t j = r0 + wave * RPW + sub; j < r1; j += kWavesPerBlock * RPW) {
     const int64_t s = isrc[j], d = idst[j];
-    float4 v = ld4(t + j * H + c4);
+    float4 v = ld4_nt(t + j * H + c4);
     v = v + ld4(P + s * (5 * H) + 3 * H + c4) + ld4(P + d * (5 * H) + 4 * H + c4);
-    st4(t + j * H + c4, v);
+    st4_nt(t + j * H + c4, v);
     st.add_prod(v, v);
   }
   block_stat_store<H>(st, lds, partials, chunk);
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_gt_k(int64_t E, const float* 
     const float4 sc = ld4(stat + 2 * H + c4), sh = ld4(stat + 3 * H + c4);
     const float4 m1 = ld4(bstat + c4), m2 = ld4(bstat + H + c4);
     const float4 c = ld4(gamma + c4) * rs;
-    const float4 tt = ld4(t + o);
-    const float4 gu = gate4(fma4(tt, sc, sh), ld4(ge + o));
-    st4(gt + o, c * (gu - m1 - ((tt - mu) * rs) * m2));
+    const float4 tt = ld4_nt(t + o);
+    const float4 gu = gate4(fma4(tt, sc, sh), ld4_nt(ge + o));
+    st4_nt(gt + o, c * (gu - m1 - ((tt - mu) * rs) * m2));
   }
 }
 
