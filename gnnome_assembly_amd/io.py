@@ -1,0 +1,55 @@
+"""On-disk graph format (the reference stores `.dgl` files written by
+dgl.save_graphs, graph_dataset.py:129, a private DGL binary format, plus pickled succ / pred / edges
+dicts, :130-134).  Here a graph is ONE documented `.npz`:
+
+    src[E] int32, dst[E] int32, num_nodes,  ndata/<key>[N,...],  edata/<key>[E,...]
+
+in the caller's edge-id order (so `edata['score']`, labels `y`, `prefix_length` ... keep their meaning,
+inference.py:454, graph_parser.py:55-73,309).  The adjacency dicts need no file: decode.DecodeGraph
+rebuilds them from src / dst in edge-id order.  `convert_dgl` turns a reference `.dgl` file into this
+format wherever DGL is installed (it is not in this image)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .graph import AssemblyGraph
+
+__all__ = ["save_graph", "load_graph", "convert_dgl"]
+
+
+def save_graph(path: str, graph: AssemblyGraph) -> None:
+    arrays = {"src": graph._src, "dst": graph._dst, "num_nodes": np.int64(graph.num_nodes())}
+    for k, v in graph.ndata.items():
+        arrays["ndata/" + k] = v.detach().cpu().numpy()
+    for k, v in graph.edata.items():
+        arrays["edata/" + k] = v.detach().cpu().numpy()
+    np.savez_compressed(path, **arrays)
+
+
+def load_graph(path: str, device="cpu") -> AssemblyGraph:
+    with np.load(path) as z:
+        g = AssemblyGraph(z["src"], z["dst"], int(z["num_nodes"]))
+        n, e = g.num_nodes(), g.num_edges()
+        for k in z.files:
+            if k.startswith("ndata/"):
+                a = torch.from_numpy(z[k])
+                if a.shape[0] != n:
+                    raise ValueError(f"{k}: {a.shape[0]} rows for {n} nodes")
+                g.ndata[k[6:]] = a
+            elif k.startswith("edata/"):
+                a = torch.from_numpy(z[k])
+                if a.shape[0] != e:
+                    raise ValueError(f"{k}: {a.shape[0]} rows for {e} edges")
+                g.edata[k[6:]] = a
+    return g.to(device) if torch.device(device).type != "cpu" else g
+
+
+def convert_dgl(dgl_path: str, out_path: str, index: int = 0) -> None:
+    """`.dgl` (dgl.load_graphs) -> `.npz`; needs DGL, which this image does not have."""
+    try:
+        import dgl
+    except ImportError as e:       # pragma: no cover
+        raise RuntimeError("convert_dgl needs DGL; run it where the reference's environment is installed") from e
+    from .graph import from_dgl
+    save_graph(out_path, from_dgl(dgl.load_graphs(dgl_path)[0][index]))

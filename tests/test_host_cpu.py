@@ -150,3 +150,29 @@ def test_tensor_index_equals_host_index():
         for k, v in want.items():
             assert np.array_equal(g.index()[k].numpy(), v), k
         assert np.array_equal(g._src, np.asarray(src, np.int32))        # lazy host copy
+
+
+def test_graph_file_round_trip(tmp_path):
+    import numpy as np
+    import torch
+    from gnnome_assembly_amd import AssemblyGraph, io, synth
+    src, dst, n = synth.make_graph(200, 2, permute_edge_ids=True)
+    g = AssemblyGraph(src, dst, n)
+    rng = np.random.default_rng(0)
+    g.ndata["read_length"] = torch.from_numpy(rng.integers(1, 9, n))
+    g.ndata["pe"] = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32))
+    g.edata["score"] = torch.from_numpy(rng.standard_normal(src.size).astype(np.float32))
+    path = str(tmp_path / "g.npz")
+    io.save_graph(path, g)
+    h = io.load_graph(path)
+    assert h.num_nodes() == n and np.array_equal(h._src, src) and np.array_equal(h._dst, dst)
+    assert set(h.ndata) == {"read_length", "pe"} and set(h.edata) == {"score"}
+    for k in g.ndata:
+        assert torch.equal(h.ndata[k], g.ndata[k])
+    assert torch.equal(h.edata["score"], g.edata["score"])
+    bad = dict(np.load(path))
+    bad["edata/score"] = bad["edata/score"][:-1]
+    np.savez(str(tmp_path / "bad.npz"), **bad)
+    import pytest
+    with pytest.raises(ValueError):
+        io.load_graph(str(tmp_path / "bad.npz"))
