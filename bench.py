@@ -21,6 +21,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
 from __future__ import annotations
 
 import argparse
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL, before the HIP runtime starts
 import json
 import os
 import sys

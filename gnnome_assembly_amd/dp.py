@@ -26,6 +26,7 @@ def init_process_group(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if backend == "nccl" and "GNM_BENCH_DEVICE" not in os.environ:
