@@ -21,12 +21,12 @@ Rank 0 prints ONE JSON line.  Extra objects:
 from __future__ import annotations
 
 import argparse
-import os as _os
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL, before the HIP runtime starts
 import json
 import os
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must be set before the HIP runtime starts
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
