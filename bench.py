@@ -13,10 +13,15 @@ HBM before the timed region.  Weak scaling: every rank owns one graph (seed = ra
 sum of edges over ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant HIP kernel: algorithmic bytes per launch / its average launch time
-                (HIP events on the launch stream, measured here) vs the 8 TB/s HBM peak
+  roofline      SURVEY.md section 8(d): the STEP against the HBM roofline -- achieved = algorithmic bytes
+                (32*H*L per edge) / measured step time, peak 8 TB/s, frac = achieved / peak.  Inside it:
+                `kernels` (every C-ABI op >= 2 % of the step: launches, average launch time from HIP events on
+                the launch stream, its own algorithmic GB/s and TFLOP/s against the HBM / matrix-core peaks,
+                PMC traffic where a committed rocprofv3 pass has it), `dominant_kernel` (the slowest of them),
+                `traffic` = PMC HBM bytes of one step's layer kernels and `traffic_source` = where they
+                were measured (the counters cannot be read from inside this process)
   cpu_baseline  the CPU oracle (torch restatement of the reference path; "port") timed on this
-                box's host cores on a bounded 1/10-size sample of the same workload
+                box's host cores on a bounded, smaller sample of the same workload (ratio stated in `sample`)
 """
 from __future__ import annotations
 
@@ -52,20 +57,20 @@ def parse():
     ap.add_argument("--inference", action="store_true", help="forward only under no_grad (config 5)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3"],
-                    help="fused-kernel matmul mode (default: GNM_MATMUL or f32); see include/gnm.h")
-    ap.add_argument("--no-alt-matmul", action="store_true", help="skip the extra bf16x3-mode measurement")
+                    help="fused-kernel matmul mode (default: GNM_MATMUL or the library default bf16x3); see include/gnm.h")
+    ap.add_argument("--no-alt-matmul", action="store_true", help="skip the extra measurement in the other matmul mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores)")
     return ap.parse_args()
 
 
 def op_model(op: str, N: int, E: int, H: int):
-    """(algorithmic HBM bytes, MFMA flops) of ONE launch of `op` (fp32).  Bytes = the [E,H] / [N,H]
+    """(algorithmic HBM bytes, matrix flops) of ONE launch of `op` (fp32).  Bytes = the [E,H] / [N,H]
     streams it must read or write once, assuming perfect reuse of gathered node rows (DESIGN.md
     section 3).  (None, None) for ops not modelled."""
     eh, nh = 4.0 * E * H, 4.0 * N * H
     table = {
         "gnm_edge_t_stats_fwd": (2 * eh + 2 * nh, 0.0),       # t in/out, B1h/B2h rows
-        "gnm_edge_gate_fwd": (3 * eh + 3 * nh, 0.0),          # t, e_in in; e_out out; A2h in; hf, inv_f out
+        "gnm_edge_gate_fwd": (3 * eh + 4 * nh, 0.0),          # t, e_in in; e_out out; A2h in; hf, inv_f, Td out
         "gnm_node_agg_src_fwd": (1 * eh + 6 * nh, 0.0),       # e_out in; A1h, A3h, hf in; hb, inv_b, z out
         "gnm_edge_bwd_dst": (4 * eh + 9 * nh, 0.0),           # e_out, t, ge in; ge out; Q(4) A2h A3h in; gA3h Ud Td out
         "gnm_edge_bwd_src": (3 * eh + 6 * nh, 0.0),           # e_out, t, ge in; Qf Ud Td in; gA2h gB1h gB2h out
@@ -73,11 +78,15 @@ def op_model(op: str, N: int, E: int, H: int):
         "gnm_edge_t_fused_fwd": (2 * eh + 2 * nh, 2.0 * E * H * H),        # e_in in, t out, B1h/B2h rows
         "gnm_edge_bwd_fused": (4 * eh, 4.0 * E * H * H),                   # ge in/out, t, e_in; NN + TN
         "gnm_node_proj_fwd": (6 * nh, 2.0 * N * H * 5 * H),                # h in, P out
-        "gnm_node_proj_bwd": (8 * nh, 4.0 * N * H * 5 * H),                # gP, h_in, gh_out in; gh_in out; NN + TN
+        "gnm_node_proj_bwd_nn": (7 * nh, 2.0 * N * H * 5 * H),             # gP, gh_out in; gh_in out
+        "gnm_node_proj_bwd_tn": (6 * nh, 2.0 * N * H * 5 * H),             # gP, h_in in
         "gnm_edge_encoder_fwd": (eh, 0.0),
         "gnm_edge_encoder_bwd": (eh, 0.0),
         "gnm_node_bwd_apply": (11 * nh, 0.0),
+        "gnm_node_bwd_stats": (2 * nh, 0.0),
         "gnm_node_update_fwd": (3 * nh, 0.0),
+        "gnm_predictor_fused_fwd": (1.5 * eh + 2 * 4.0 * N * 64, 2.0 * E * H * 64),    # e in, hid out ([E,64])
+        "gnm_predictor_fused_bwd": (2 * eh + 4.0 * E * 64, 4.0 * E * H * 64),          # e in, ge out, hid in place
     }
     if op in table:
         return table[op]
@@ -91,33 +100,41 @@ def op_model(op: str, N: int, E: int, H: int):
     return None, None
 
 
-# C-ABI op -> HIP kernel whose PMC traffic (profiles/r01_b_traffic.json) belongs to it
-OP_KERNEL = {
-    "gnm_edge_bwd_fused": "edge_bwd_fused32_k", "gnm_edge_bwd_dst": "edge_bwd_dst_k<128>",
-    "gnm_edge_bwd_src": "edge_bwd_src_k<128>", "gnm_edge_gate_fwd": "edge_gate_fwd_k<128>",
-    "gnm_node_agg_src_fwd": "node_agg_src_fwd_k<128>", "gnm_edge_t_fused_fwd": "rowtile_nt_k<MmF32, true, 1>",
-    "gnm_node_proj_fwd": "rowtile_nt_k<MmF32, false, 5>", "gnm_node_bwd_apply": "node_bwd_apply_k<128>",
+# The committed PMC pass (tools/collect_traffic.sh + tools/traffic_summary.py): HBM bytes per kernel launch on
+# this workload.  PMC counters cannot be collected from inside this process, so the bench line carries the
+# number together with `traffic_source`; C-ABI op -> rocprof kernel name(s) of the op in each matmul mode.
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+OP_KERNELS = {
+    "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_fused_k<MmB3>", "edge_bwd_tr_k"]},
+    "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
+    "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
+    "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3_k"]},
+    "gnm_node_proj_fwd": {"f32": ["rowtile_nt_k<MmF32, false, 5>"], "bf16x3": ["rowtile_nt_k<MmB3, false, 1>"]},
+    "gnm_node_proj_bwd_nn": {"f32": ["rowtile_nn_acc_k<MmF32>"], "bf16x3": ["rowtile_nn_group32_b3_k<4>"]},
+    "gnm_node_proj_bwd_tn": {"f32": ["tn_colgroup_k<MmF32>"], "bf16x3": ["tn_colgroup32_b3_k", "tn_tr_k"]},
+    "gnm_node_bwd_apply": ["node_bwd_apply_k<128>"], "gnm_node_bwd_stats": ["node_bwd_stats_k<128>"],
+    "gnm_node_update_fwd": ["node_update_fwd_k<128>"],
 }
 
 
-def measured_traffic(op, N, E, H):
-    """Per-launch HBM bytes of `op` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), if they were taken on this workload."""
-    path = os.path.join(REPO, "profiles", "r01_e_traffic.json")
-    if os.environ.get("GNM_MATMUL", "f32") not in ("", "f32", "fp32"):
-        return None                              # the counters were taken in the default matmul mode
+def load_traffic(N, E, H, mode):
+    """({op: bytes per launch}, source string) from the committed PMC pass, if it was taken on this workload
+    in this matmul mode; ({}, None) otherwise."""
+    path = os.path.join(REPO, TRAFFIC_FILE)
     try:
         d = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return {}, None
     w = d.get("workload", {})
-    if (w.get("edges"), w.get("nodes"), w.get("hidden")) != (E, N, H):
-        return None
-    if op == "gnm_node_proj_bwd":       # two kernels behind one entry point
-        ks = [d["per_launch"].get("rowtile_nn_acc_k<MmF32>"), d["per_launch"].get("tn_colgroup_k<MmF32>")]
-        return sum(k["total_gb"] for k in ks) * 1e9 if all(ks) else None
-    k = d["per_launch"].get(OP_KERNEL.get(op, ""))
-    return k["total_gb"] * 1e9 if k else None
+    if (w.get("edges"), w.get("nodes"), w.get("hidden")) != (E, N, H) or w.get("matmul", "f32") != mode:
+        return {}, None
+    out = {}
+    for op, ks in OP_KERNELS.items():
+        ks = ks[mode] if isinstance(ks, dict) else ks
+        hit = [d["per_launch"][k]["total_gb"] * 1e9 for k in ks if k in d["per_launch"]]
+        if hit:
+            out[op] = hit[0]
+    return out, f"{TRAFFIC_FILE} @ {d.get('commit', 'unknown commit')} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
 
 
 def usable_cores():
@@ -134,7 +151,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(reads, H, L, budget_s=25.0, threads=0):
+def cpu_baseline(reads, H, L, budget_s=25.0, threads=0, full_reads=750_000):
     """fwd+bwd edges/s of the CPU oracle on this host (all cores torch gives us), on a bounded
     sample: the graph is shrunk until one step fits the time budget (edges/s is size-normalised)."""
     from gnnome_assembly_amd import synth
@@ -178,8 +195,10 @@ def cpu_baseline(reads, H, L, budget_s=25.0, threads=0):
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": E / med, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"R={r} (N={n}, E={E}) H={H} L={L} fwd+bwd, torch-CPU oracle fp32, "
-                      f"median of {len(times)} steps after warm-up ({med:.2f} s/step)"}
+            "sample": f"R={r} (N={n}, E={E}) = 1/{full_reads / r:.0f} of the GPU workload's R={full_reads} (edges/s is "
+                      f"size-normalised; the small graph is cache-friendlier, which favours the CPU; SURVEY 8(d) asked "
+                      f"for 1/10 and 3 steps, the time budget of the default run allows this), H={H} L={L} fwd+bwd, "
+                      f"torch-CPU oracle fp32, median of {len(times)} steps after warm-up ({med:.2f} s/step)"}
 
 
 def cpu_baseline_subprocess(args, timeout_s=120):
@@ -187,7 +206,8 @@ def cpu_baseline_subprocess(args, timeout_s=120):
     come out within minutes whatever the host does."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-reads", str(args.cpu_reads),
-           "--hidden", str(args.hidden), "--layers", str(args.layers), "--cpu-threads", str(args.cpu_threads)]
+           "--hidden", str(args.hidden), "--layers", str(args.layers), "--cpu-threads", str(args.cpu_threads),
+           "--reads", str(args.reads)]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in reversed(out.stdout.strip().splitlines()):
@@ -208,7 +228,8 @@ def dbg(msg):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.cpu_reads, args.hidden, args.layers, threads=args.cpu_threads)), flush=True)
+        print(json.dumps(cpu_baseline(args.cpu_reads, args.hidden, args.layers, threads=args.cpu_threads,
+                                      full_reads=args.reads)), flush=True)
         return
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -298,66 +319,69 @@ def main():
     step()
     ops = engine.profile_ops(False) if rank == 0 else None
     dbg("profile step done")
-    # the opt-in split-precision matmul mode (include/gnm.h), measured the same way right after the
+    # the other matmul mode of the fused kernels (include/gnm.h), measured the same way right after the
     # default run; reported beside `value`, never as `value`
     alt = None
-    if args.matmul is None and G._lib.get_matmul_mode() == "f32" and H == 128 and not args.no_alt_matmul:
-        G._lib.set_matmul_mode("bf16x3")
+    mode = G._lib.get_matmul_mode()
+    if args.matmul is None and H == 128 and not args.no_alt_matmul and not args.inference:
+        other = "f32" if mode == "bf16x3" else "bf16x3"
+        G._lib.set_matmul_mode(other)
         step()
         adt, aedges = timed_run(args.steps)
-        G._lib.set_matmul_mode("f32")
-        alt = {"matmul": "bf16x3", "ms_per_step": adt / args.steps * 1e3, "value": aedges * args.steps / adt,
-               "unit": "edges/s", "note": "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, "
-                                          "fp32 accumulate; same parity bars (tests/test_gpu_bf16x3.py)"}
+        G._lib.set_matmul_mode(mode)
+        alt = {"matmul": other, "ms_per_step": adt / args.steps * 1e3, "value": aedges * args.steps / adt,
+               "unit": "edges/s",
+               "note": "f32: every contraction on v_mfma_f32_32x32x2_f32 (fp32 operands); bf16x3: fp32 operands split "
+                       "exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate.  Both modes pass the "
+                       "whole of tests/test_gpu_parity.py"}
         dbg("alt matmul run done")
     res = None
     if rank == 0:
         tot = sum(t for _, t in ops.values())
         ranked = sorted(ops.items(), key=lambda kv: -kv[1][1])
-        # the dominant KERNEL: entry points that launch two big kernels (node_proj_bwd = NN + TN) are not one
-        # rocprof row, so the roofline object is taken for the slowest single-kernel entry point
-        dom, (dc, dt_ms) = next((kv for kv in ranked if kv[0] not in ("gnm_node_proj_bwd",)), ranked[0])
-        ab, fl = op_model(dom, n, E, H)
-        avg_s = dt_ms / dc / 1e3
-        t_hbm = (ab or 0.0) / HBM_PEAK            # time the launch would take at the HBM roofline
-        mm_peak = BF16_MFMA_PEAK / 6 if G._lib.get_matmul_mode() == "bf16x3" else F32_MFMA_PEAK
-        t_mfma = (fl or 0.0) / mm_peak            # ... at the matrix-core roofline of the matmul mode
-        if t_mfma > t_hbm:
-            roof = {"kernel": dom, "bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": mm_peak / 1e12,
-                    "unit": "TFLOP/s", "frac": t_mfma / avg_s, "traffic": None}
-        else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": (ab or 0.0) / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": t_hbm / avg_s, "traffic": None}
-        roof["traffic"] = measured_traffic(dom, n, E, H)
-        roof.update({"launches_per_step": dc, "avg_launch_ms": avg_s * 1e3,
-                     "algorithmic_gb_per_launch": (ab or 0.0) / 1e9, "hbm_frac": t_hbm / avg_s,
-                     "mfma_frac": t_mfma / avg_s})
-        # the dominant HBM-bound (gather / scatter / normalise) kernel, for the north_star's evidence
+        mm_peak = BF16_MFMA_PEAK / 6 if mode == "bf16x3" else F32_MFMA_PEAK   # fp32-equivalent FLOP/s of the mode
+        traffic, traffic_src = load_traffic(n, E, H, mode)
+        kernels = []
         for k, (c, tms) in ranked:
-            kb, kf = op_model(k, n, E, H)
-            if kb and not kf:
-                roof["top_hbm_kernel"] = {"kernel": k, "achieved_gbps": kb / (tms / c / 1e3) / 1e9,
-                                          "frac": kb / (tms / c / 1e3) / HBM_PEAK, "avg_launch_ms": tms / c,
-                                          "algorithmic_gb_per_launch": kb / 1e9,
-                                          "traffic": measured_traffic(k, n, E, H)}
-                break
-        per_edge = (12 if args.inference else 32) * H * L
-        step_frac = per_edge * total_edges / world / (ms / 1e3) / HBM_PEAK
+            if tms < 0.02 * tot:
+                continue
+            ab, fl = op_model(k, n, E, H)
+            avg_s = tms / c / 1e3
+            row = {"op": k, "launches_per_step": c, "avg_launch_ms": round(avg_s * 1e3, 4), "share_of_step": round(tms / tot, 4)}
+            if ab:
+                row["hbm"] = {"algorithmic_gb": round(ab / 1e9, 3), "achieved_gbps": round(ab / avg_s / 1e9, 1),
+                              "frac": round(ab / avg_s / HBM_PEAK, 4)}
+            if fl:
+                row["mfma"] = {"tflop": round(fl / 1e12, 4), "achieved_tflops": round(fl / avg_s / 1e12, 1),
+                               "peak_tflops": round(mm_peak / 1e12, 1), "frac": round(fl / avg_s / mm_peak, 4)}
+            if ab is not None:
+                row["bound"] = "mfma" if (fl or 0.0) / mm_peak > ab / HBM_PEAK else "hbm"
+            if k in traffic:
+                row["traffic_gb"] = round(traffic[k] / 1e9, 3)
+            kernels.append(row)
+        per_edge = (12 if args.inference else 32) * H * L          # algorithmic B / edge / step
+        alg_bytes = per_edge * total_edges / world                  # per GPU and step
+        achieved = alg_bytes / (ms / 1e3)
+        # PMC traffic of one step's modelled kernels (launches x bytes per launch), where the pass has them
+        step_traffic = sum(traffic[k] * c for k, (c, _) in ops.items() if k in traffic) if traffic else None
+        roof = {"scope": "whole training step on one GPU (SURVEY.md 8d)" if not args.inference else "whole forward pass",
+                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "algorithmic_bytes_per_edge_step": per_edge,
+                "traffic": step_traffic, "traffic_source": traffic_src,
+                "kernels": kernels, "dominant_kernel": kernels[0] if kernels else None}
         res = {
             "metric": "GatedGCN edges/sec fwd+bwd, chr19 assembly graph" if not args.inference
                       else "GatedGCN edges/sec fwd only (inference)",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (bf16x3 split products, f32 accumulate)" if mode == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"synthetic chr19-scale assembly graph per GPU: R={R} reads, N={n} nodes, "
                                    f"E={E} edges, hidden={H}, layers={L}, BCE fwd+bwd + Adam"
                                    + (", RCCL grad all-reduce" if world > 1 else ""),
-                       "reads": R, "nodes": n, "edges": E, "hidden": H, "layers": L,
-                       "parallelism": f"dp{world}", "edge_layers_per_s": value * L,
-                       "matmul": G._lib.get_matmul_mode()},
+                       "reads": R, "nodes": n, "edges": E, "edges_total": int(total_edges), "hidden": H, "layers": L,
+                       "parallelism": f"dp{world}", "edge_layers_per_s": value * L, "matmul": mode,
+                       "activations": engine.ACTIVATIONS if hasattr(engine, "ACTIVATIONS") else "saved"},
             "roofline": roof,
-            "step_hbm_roofline_frac": step_frac,
-            "algorithmic_bytes_per_edge_step": per_edge,
             "op_ms": {k: round(v[1], 3) for k, v in ranked},
             "op_total_ms": round(tot, 3),
             "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

@@ -54,6 +54,8 @@ SIGNATURES = {
     "gnm_node_proj_fwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_workspace_bytes": (_sz, [_i32]),
     "gnm_node_proj_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_node_proj_bwd_nn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_node_proj_bwd_tn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_bwd_fused_workspace_bytes": (_sz, []),
     "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_encoder_fwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -103,7 +105,7 @@ def load():
         raise GnmError(f"libgnm.so ABI version {v}, expected 1")
     _lib = lib
     mode = os.environ.get("GNM_MATMUL", "").strip().lower()
-    if mode:                                     # opt-in split-precision matmul (see gnm.h)
+    if mode:                                     # matmul mode of the fused kernels (gnm.h); library default: bf16x3
         if mode not in MATMUL_MODES:
             raise GnmError(f"GNM_MATMUL={mode!r}: expected one of {sorted(MATMUL_MODES)}")
         check(lib.gnm_set_matmul_mode(MATMUL_MODES[mode]), "gnm_set_matmul_mode")
@@ -114,7 +116,7 @@ MATMUL_MODES = {"f32": 0, "fp32": 0, "bf16x3": 1}
 
 
 def set_matmul_mode(mode: str) -> None:
-    """'f32' (default: fp32 MFMA) or 'bf16x3' (exact 3-way bf16 split, six bf16 MFMAs per product)."""
+    """'bf16x3' (default: exact 3-way bf16 split, six bf16 MFMAs per product, fp32 accumulate) or 'f32' (fp32 MFMA)."""
     if mode not in MATMUL_MODES:
         raise GnmError(f"matmul mode {mode!r}: expected one of {sorted(MATMUL_MODES)}")
     check(load().gnm_set_matmul_mode(MATMUL_MODES[mode]), "gnm_set_matmul_mode")

@@ -131,13 +131,13 @@ __device__ __forceinline__ int64_t clampi(int64_t r, int64_t hi) { return r < hi
 // ------------------------------------------------------------------------------------------
 // Matmul policies of the row-tile kernels (how a 64 x 128 fp32 tile meets a 128 x 32 weight block)
 //
-//   MmF32   v_mfma_f32_32x32x2_f32 on the fp32 tile image (the default).
+//   MmF32   v_mfma_f32_32x32x2_f32 on the fp32 tile image (gnm_set_matmul_mode(0)).
 //   MmB3    fp32 x fp32 as SIX bf16 MFMAs (v_mfma_f32_32x32x16_bf16, 8x the fp32 rate):
 //           x = x1 + x2 + x3 exactly, with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
 //           (3 x 8 significand bits = fp32's 24), every product x_i * w_j is exact in the fp32
 //           accumulator, and the three products below 2^-24 |x w| (x2 w3, x3 w2, x3 w3) are
 //           dropped -- the same order as ONE fp32 rounding of the product.  Accumulation stays
-//           fp32.  Opt-in (gnm_set_matmul_mode(1)); inf inputs give NaN (inf - inf in the split).
+//           fp32.  The default (gnm_set_matmul_mode(0) selects MmF32); inf inputs give NaN (inf - inf in the split).
 // A policy stages tile rows into its LDS image(s), keeps this wave's weight block as fragments in
 // VGPRs, and accumulates rows 0-31 / 32-63 of the tile into acc0 / acc1.
 // ------------------------------------------------------------------------------------------
@@ -390,7 +390,7 @@ __global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int 
   }
 }
 
-static int g_matmul_mode = 0;   // 0: exact fp32 MFMA, 1: bf16x3 split
+static int g_matmul_mode = 1;   // 0: fp32 MFMA, 1: bf16x3 split (default since round 2: same parity bars, 2.7x the matrix rate)
 constexpr size_t kPackBytesPerBlk = MmB3::kPackBytes;   // workspace sizing: the larger of the two
 
 template <class MM>
@@ -1557,20 +1557,33 @@ static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* 
   return 0;
 }
 
+// The two halves of gnm_node_proj_bwd as separate entry points (same workspace layout), so that a caller can
+// time / schedule the NN and the TN kernel on their own.
+extern "C" int gnm_node_proj_bwd_nn(int64_t N, int H, int ncols, const float* gP, const float* W, const float* gh_out,
+                                    float* gh_in, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "node_proj_bwd_nn: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && W && gh_out && gh_in, "node_proj_bwd_nn: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_bwd_nn: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  return (g_matmul_mode ? node_proj_bwd_nn<MmB3>(N, ncols, gP, W, gh_out, gh_in, ws, st)
+                        : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st)) ? -2 : 0;
+}
+
+extern "C" int gnm_node_proj_bwd_tn(int64_t N, int H, int ncols, const float* gP, const float* h_in, float* gW, float* gb,
+                                    double* partials, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "node_proj_bwd_tn: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && h_in && gW && gb && partials, "node_proj_bwd_tn: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_node_proj_bwd_workspace_bytes(ncols), "node_proj_bwd_tn: workspace too small");
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(ncols));
+  return tn_colgroups(N, gP, ncols, ncols / FH, h_in, gW, gb, partials, slab, stream);
+}
+
 extern "C" int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
                                  const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,
                                  void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(H == FH, "node_proj_bwd: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && h_in && W && gh_out && gh_in && gW && gb && partials,
-                "node_proj_bwd: bad argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_node_proj_bwd_workspace_bytes(ncols), "node_proj_bwd: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  const int ncg = ncols / FH;
-  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(ncols));
-  if (g_matmul_mode ? node_proj_bwd_nn<MmB3>(N, ncols, gP, W, gh_out, gh_in, ws, st)
-                    : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st))
-    return -2;
-  return tn_colgroups(N, gP, ncols, ncg, h_in, gW, gb, partials, slab, stream);
+  const int rc = gnm_node_proj_bwd_nn(N, H, ncols, gP, W, gh_out, gh_in, ws, ws_bytes, stream);
+  return rc ? rc : gnm_node_proj_bwd_tn(N, H, ncols, gP, h_in, gW, gb, partials, ws, ws_bytes, stream);
 }
 
 // out[cg*128 + n][c] = sum_rows A[row][cg*128 + n] * B[row][c];  colsum[cg*128 + n] = sum_rows A[row][cg*128 + n]

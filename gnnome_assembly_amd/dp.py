@@ -14,7 +14,7 @@ from typing import Iterable
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_process_group", "FlatGradients", "shard_graphs"]
+__all__ = ["init_process_group", "FlatGradients", "shard_graphs", "steps_per_epoch"]
 
 
 def init_process_group(backend: str | None = None):
@@ -37,13 +37,18 @@ def init_process_group(backend: str | None = None):
 
 class FlatGradients:
     """Makes every parameter's .grad a view into ONE contiguous fp32 buffer, so that the
-    gradient exchange is a single all-reduce and zeroing is a single memset."""
+    gradient exchange is a single all-reduce and zeroing is a single memset.
+
+    `flat` carries one extra trailing element: the number of graphs this rank contributed to the step
+    (1, or 0 for a padding step of a rank whose shard is shorter).  It rides in the same collective, and the
+    summed gradient is divided by the summed count -- the mean over the graphs that actually took part."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.grads = self.flat[:n]                # the gradient proper (what an optimizer sees through p.grad)
         o = 0
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
@@ -57,16 +62,28 @@ class FlatGradients:
                 raise RuntimeError("FlatGradients: a parameter's .grad was re-allocated; use "
                                    "optimizer.zero_grad(set_to_none=False) or FlatGradients.zero_()")
 
-    def all_reduce_mean(self, async_op: bool = False):
-        """Average the gradient over all ranks (one collective on the current stream)."""
+    def all_reduce_mean(self, contributed: bool = True):
+        """Average the gradient over the ranks that contributed a graph to this step: ONE all-reduce (sum) of
+        the flat buffer on the current stream, then a device-side division by the summed count (no host
+        sync).  Every rank must call it the same number of times; a rank without a graph for this step
+        calls zero_() and all_reduce_mean(contributed=False)."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return None
-        w = dist.get_world_size()
-        if dist.get_backend() == "nccl":
-            return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, async_op=async_op)
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)
-        self.flat.div_(w)
-        return work
+        self.flat[-1] = 1.0 if contributed else 0.0
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.grads.div_(self.flat[-1])
+        return None
+
+
+def steps_per_epoch(local_steps: int, device=None) -> int:
+    """The number of optimizer steps EVERY rank takes in an epoch: the maximum of the ranks' local counts
+    (shard_graphs gives uneven shards whenever num_graphs % world != 0); shorter ranks pad with
+    zero-contribution steps so that the collectives stay matched."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(local_steps)
+    t = torch.tensor([int(local_steps)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 def shard_graphs(num_graphs: int, rank: int, world: int, sizes=None):

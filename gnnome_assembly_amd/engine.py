@@ -11,6 +11,7 @@ back to the caller's edge-id order.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -28,6 +29,26 @@ LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device_of(pick):
+    """Run the wrapped entry point with the HIP device of `pick(*args)` current.  HIP launches go to the CURRENT
+    device and _stream() is the current device's stream; the reference's own pattern is model.to('cuda:3') with
+    no set_device (hyperparameters.py:25), so without this the kernels would be queued on device 0 with
+    device-3 pointers."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*a, **k):
+            t = pick(*a, **k)
+            dev = t.device if torch.is_tensor(t) else torch.device(t)
+            if dev.type != "cuda":
+                raise _lib.GnmError("gnnome_assembly_amd: tensors must be on a HIP device (no CPU fallback)")
+            if dev.index is None or dev.index == torch.cuda.current_device():
+                return fn(*a, **k)
+            with torch.cuda.device(dev):
+                return fn(*a, **k)
+        return wrapper
+    return deco
 
 
 # Optional per-op timing (bench.py / profiling only): when `_prof` is a list every C-ABI call is
@@ -127,6 +148,7 @@ def _side_stream(device):
 # thin wrappers
 # ---------------------------------------------------------------------------------------
 
+@on_device_of(lambda mode, A, *a, **k: A)
 def gemm(mode: int, A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, bias=None, resid=None, relu=False):
     """C = op(A) op(B) (+bias +resid, relu).  A, B, C, resid are 2-D views with unit inner
     stride; shapes follow include/gnm.h (NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N])."""
@@ -156,6 +178,7 @@ def gemm(mode: int, A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, bias=Non
     return C_
 
 
+@on_device_of(lambda X, *a, **k: X)
 def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     _chk_dev(X)
@@ -219,6 +242,7 @@ class LayerSaved:
     stat_h: torch.Tensor = None
 
 
+@on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
 def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True):
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
     Returns (h_out, e_out, LayerSaved or None)."""
@@ -277,6 +301,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     return h_out, e_out, saved
 
 
+@on_device_of(lambda idx, N, E, H, prm, s, gh_out, *a, **k: gh_out)
 def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True):
     """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
     and is OVERWRITTEN with d loss / d e_in.  Returns (gh_in, ge, grads dict)."""
@@ -368,8 +393,9 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         g["b5"] = torch.empty(5 * H, **f32)
         need = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
         ws = sc.ws(need)
-        _call("gnm_node_proj_bwd", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(prm.W5), _ptr(gh_out), _ptr(gh_in),
-              _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc.partials), _ptr(ws), need, st)
+        _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh_out), _ptr(gh_in), _ptr(ws), need, st)
+        _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
+              _ptr(sc.partials), _ptr(ws), need, st)
     else:
         gemm(TN, gP, s.h_in, g["W5"])
         g["b5"] = colsum(gP)
@@ -389,6 +415,7 @@ class PredSaved:
     W1sd: torch.Tensor = None
 
 
+@on_device_of(lambda idx, N, E, H, W1, b1, W2, b2, x, *a, **k: x)
 def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     """scores (caller edge-id order, [E,1]) from internal-order x [N,H], e [E,H]."""
     lib = _lib.load()
@@ -417,6 +444,7 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     return scores, saved
 
 
+@on_device_of(lambda idx, N, E, H, W1, W2, s, gscores: gscores)
 def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores):
     """Returns (gx [N,H], ge [E,H] fresh buffer, grads dict W1,b1,W2,b2)."""
     lib = _lib.load()
@@ -503,6 +531,7 @@ def layer_params(P: Dict[str, torch.Tensor], i: int) -> LayerParams:
         gamma_h=P[p + "bn_h.weight"], beta_h=P[p + "bn_h.bias"])
 
 
+@on_device_of(lambda graph, e_raw, pe, *a, **k: pe)
 def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int, save: bool, batch_norm: bool = True):
     """GraphGatedGCNModel.forward.  e_raw [E,edge_features] in edge-id order, pe [N,nb_pos_enc+2].
     Returns (scores [E,1] in edge-id order, ModelSaved or None)."""
@@ -544,6 +573,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     return scores, ms
 
 
+@on_device_of(lambda graph, P, num_layers, ms, gscores, *a, **k: gscores)
 def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores, batch_norm: bool = True):
     """Gradients of every parameter (keys = state_dict keys) from d loss / d scores."""
     dev = ms.pe.device
@@ -594,6 +624,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     return G
 
 
+@on_device_of(lambda scores, *a, **k: scores)
 def bce_with_logits(scores, y, pos_weight: float):
     """(loss [1], dloss/dscores [E,1]) -- train.py:210-211,253-255, fused in one pass."""
     lib = _lib.load()

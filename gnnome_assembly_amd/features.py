@@ -8,11 +8,12 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import _call, _ptr, _stream, scratch
+from .engine import _call, _ptr, _stream, on_device_of, scratch
 
 __all__ = ["positional_encoding", "edge_features", "prepare_graph"]
 
 
+@on_device_of(lambda graph, *a, **k: graph.device)
 def positional_encoding(graph, pe_dim: int = 16, alpha: float = 0.95) -> torch.Tensor:
     """[N, 2+pe_dim] fp32 = in_deg | out_deg | k-step PageRank (the `pe` argument of the model)."""
     lib = _lib.load()
@@ -29,6 +30,7 @@ def positional_encoding(graph, pe_dim: int = 16, alpha: float = 0.95) -> torch.T
     return pe
 
 
+@on_device_of(lambda overlap_length, overlap_similarity: overlap_similarity)
 def edge_features(overlap_length: torch.Tensor, overlap_similarity: torch.Tensor) -> torch.Tensor:
     """[E,2] fp32 z-scored edge features in the caller's edge-id order (the `e` argument)."""
     dev = overlap_similarity.device

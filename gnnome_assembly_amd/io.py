@@ -18,18 +18,35 @@ from .graph import AssemblyGraph
 __all__ = ["save_graph", "load_graph", "convert_dgl"]
 
 
+def _npz_path(path: str) -> str:
+    """np.savez appends '.npz' to a path that lacks it; do the same on both sides so that
+    save_graph(p) / load_graph(p) always name the same file."""
+    path = str(path)
+    return path if path.endswith(".npz") else path + ".npz"
+
+
 def save_graph(path: str, graph: AssemblyGraph) -> None:
     arrays = {"src": graph._src, "dst": graph._dst, "num_nodes": np.int64(graph.num_nodes())}
     for k, v in graph.ndata.items():
         arrays["ndata/" + k] = v.detach().cpu().numpy()
     for k, v in graph.edata.items():
         arrays["edata/" + k] = v.detach().cpu().numpy()
-    np.savez_compressed(path, **arrays)
+    np.savez_compressed(_npz_path(path), **arrays)
 
 
 def load_graph(path: str, device="cpu") -> AssemblyGraph:
-    with np.load(path) as z:
-        g = AssemblyGraph(z["src"], z["dst"], int(z["num_nodes"]))
+    with np.load(_npz_path(path)) as z:
+        src, dst, num_nodes = z["src"], z["dst"], int(z["num_nodes"])
+        for name, a in (("src", src), ("dst", dst)):
+            if a.ndim != 1 or not np.issubdtype(a.dtype, np.integer):
+                raise ValueError(f"{name}: expected a 1-D integer array, got {a.dtype} {a.shape}")
+            if a.size and (int(a.min()) < 0 or int(a.max()) >= num_nodes):
+                raise ValueError(f"{name}: node id outside [0, {num_nodes})")
+        if src.shape != dst.shape:
+            raise ValueError(f"src has {src.size} entries, dst {dst.size}")
+        if num_nodes > np.iinfo(np.int32).max or src.size > np.iinfo(np.int32).max:
+            raise ValueError("graph too large for the int32 index of the HIP path")
+        g = AssemblyGraph(src, dst, num_nodes)
         n, e = g.num_nodes(), g.num_edges()
         for k in z.files:
             if k.startswith("ndata/"):

@@ -36,6 +36,8 @@ class _LayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh_out, ge_out):
+        if ctx.saved is None:
+            raise RuntimeError("GatedGCN_1d: backward called twice (retain_graph is not supported) or forward ran without grad")
         N, E, H = ctx.dims
         idx = ctx.graph.index(gh_out.device)
         perm = idx["perm"].long()
@@ -79,6 +81,10 @@ class GatedGCN_1d(nn.Module):
             raise NotImplementedError("GatedGCN_1d: in_channels != out_channels is outside the hot path")
         if dropout != 0:
             raise NotImplementedError("dropout != 0 is never used by the reference (processor.py:12)")
+        if not residual:
+            # the kernels always add h_in / e_in (gated_gcn_full.py:149-152 with residual=True, the only
+            # value the model passes, processor.py:11-12): refuse rather than return a silently different result
+            raise NotImplementedError("GatedGCN_1d: residual=False is outside the hot path")
         self.dropout = dropout
         self.batch_norm = batch_norm
         self.residual = residual
@@ -124,6 +130,8 @@ class _PredFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gscores):
+        if ctx.saved is None:      # the saved pre-activation is overwritten in place by its gradient
+            raise RuntimeError("ScorePredictor: backward called twice (retain_graph is not supported) or forward ran without grad")
         N, E, H = ctx.dims
         idx = ctx.graph.index(gscores.device)
         perm = idx["perm"].long()

@@ -51,6 +51,11 @@ class GraphGatedGCNModel(nn.Module):
     def forward(self, graph, x, e, pe):
         names, flat = zip(*self.named_parameters())
         need = torch.is_grad_enabled() and any(p.requires_grad for p in flat)
+        if torch.is_grad_enabled() and (e.requires_grad or pe.requires_grad):
+            # the reference never differentiates its inputs (train.py:245-258); the whole-model backward
+            # stops at the encoders, so refuse instead of returning a silent None for these gradients
+            raise NotImplementedError("GraphGatedGCNModel: gradients w.r.t. the inputs e / pe are not computed; "
+                                      "detach them (the stand-alone layers do return input gradients)")
         return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, self.batch_norm, *flat)
 
 

@@ -102,6 +102,12 @@ class History:
     lr: List[float] = field(default_factory=list)
     metrics_train: List[tuple] = field(default_factory=list)
     metrics_valid: List[tuple] = field(default_factory=list)
+    step_losses: List[float] = field(default_factory=list)      # every optimizer step's loss, in order (this rank's)
+    step_graph: List[int] = field(default_factory=list)         # ... and the index of the graph it was taken on
+    tfpn_train: List[tuple] = field(default_factory=list)       # per epoch: (TP, TN, FP, FN) summed over the graphs
+    tfpn_valid: List[tuple] = field(default_factory=list)
+    best_epoch: int = -1
+    final_lr: float = 0.0
 
 
 def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSample], out: str = "model",
@@ -141,39 +147,57 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
         model.train()
         loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
         counts = torch.zeros(4, device=dev, dtype=torch.int64)
-        for gi in order:
-            s = train_samples[gi]
+        ep_losses = []                       # device scalars; read back once per epoch
+        # every rank takes the same number of optimizer steps: shards may be uneven (dp.shard_graphs), the
+        # shorter ranks pad with zero-contribution steps so that the gradient collectives stay matched
+        nsteps = dp.steps_per_epoch(len(order), dev)
+        for it in range(nsteps):
+            s = train_samples[order[it]] if it < len(order) else None
             if hp["batch_size_train"] <= 1:                                                     # full graph
                 flat.zero_()
-                pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)                               # train.py:252-253
-                loss = criterion(pred, s.y)
-                loss.backward()
-                flat.all_reduce_mean()
+                if s is not None:
+                    pred = model(s.graph, s.x, s.e, s.pe).squeeze(-1)                           # train.py:252-253
+                    loss = criterion(pred, s.y)
+                    loss.backward()
+                flat.all_reduce_mean(contributed=s is not None)
                 optimizer.step()                                                                # train.py:256-258
-                loss_sum += loss.detach().double()
-                counts += tfpn_counts(pred.detach(), s.y)
+                if s is not None:
+                    loss_sum += loss.detach().double()
+                    ep_losses.append(loss.detach())
+                    hist.step_graph.append(order[it])
+                    counts += tfpn_counts(pred.detach(), s.y)
             else:                                                                               # train.py:282-343
                 lo = max(1, hp["num_parts_metis_train"] - 100)
                 nparts = int(torch.randint(lo, hp["num_parts_metis_train"] + 100, (1,)).item())  # train.py:291
                 gl = torch.zeros((), device=dev, dtype=torch.float64)
                 nb = 0
-                for sub in _cluster_batches(s, nparts, hp["batch_size_train"], hp["partition_method"]):
+                loader = _cluster_batches(s, nparts, hp["batch_size_train"], hp["partition_method"]) if s is not None else []
+                nbatches = dp.steps_per_epoch(len(loader), dev)          # the ranks' cluster counts differ
+                batches = iter(loader)
+                for _ in range(nbatches):
+                    sub = next(batches, None)
                     flat.zero_()
-                    pred = model(sub, None, sub.edata["e"], sub.ndata["pe"]).squeeze(-1)        # train.py:306
-                    loss = criterion(pred, sub.edata["y"])
-                    loss.backward()
-                    flat.all_reduce_mean()
+                    if sub is not None:
+                        pred = model(sub, None, sub.edata["e"], sub.ndata["pe"]).squeeze(-1)    # train.py:306
+                        loss = criterion(pred, sub.edata["y"])
+                        loss.backward()
+                    flat.all_reduce_mean(contributed=sub is not None)
                     optimizer.step()
-                    gl += loss.detach().double()
-                    nb += 1
-                    counts += tfpn_counts(pred.detach(), sub.edata["y"])
-                loss_sum += gl / max(nb, 1)                                                     # train.py:330
+                    if sub is not None:
+                        gl += loss.detach().double()
+                        nb += 1
+                        counts += tfpn_counts(pred.detach(), sub.edata["y"])
+                if s is not None:
+                    loss_sum += gl / max(nb, 1)                                                 # train.py:330
         n_train = torch.tensor(float(len(order)), device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(loss_sum); dist.all_reduce(n_train); dist.all_reduce(counts)        # noqa: E702
         train_loss = float(loss_sum / n_train)
         hist.loss_train.append(train_loss)
-        hist.metrics_train.append(calculate_metrics(*[int(c) for c in counts.tolist()]))
+        if ep_losses:
+            hist.step_losses += torch.stack(ep_losses).double().cpu().tolist()
+        hist.tfpn_train.append(tuple(int(c) for c in counts.tolist()))
+        hist.metrics_train.append(calculate_metrics(*hist.tfpn_train[-1]))
         # ---- validation (train.py:385-511): eval mode, no_grad, no activations kept ----
         model.eval()
         vloss = torch.zeros((), device=dev, dtype=torch.float64)
@@ -199,16 +223,19 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
             dist.all_reduce(vloss); dist.all_reduce(n_val); dist.all_reduce(vcounts)            # noqa: E702
         val_loss = float(vloss / n_val.clamp(min=1))
         hist.loss_valid.append(val_loss)
-        hist.metrics_valid.append(calculate_metrics(*[int(c) for c in vcounts.tolist()]) if int(vcounts.sum()) else None)
+        hist.tfpn_valid.append(tuple(int(c) for c in vcounts.tolist()))
+        hist.metrics_valid.append(calculate_metrics(*hist.tfpn_valid[-1]) if int(vcounts.sum()) else None)
         hist.lr.append(optimizer.param_groups[0]["lr"])
         if len(hist.loss_valid) > 1 and hist.loss_valid[-1] < min(hist.loss_valid[:-1]):        # train.py:525-527
             best_state = copy.deepcopy(model.state_dict())
+            hist.best_epoch = epoch
             if rank == 0:
                 os.makedirs(os.path.dirname(model_path), exist_ok=True)
                 torch.save(best_state, model_path)
         if rank == 0:
             save_checkpoint(epoch, model, optimizer, train_loss, val_loss, out, os.path.join(workdir, "checkpoints"))
         scheduler.step(val_loss)                                                                # train.py:529
+        hist.final_lr = optimizer.param_groups[0]["lr"]
         if verbose and rank == 0:
             print(f"epoch {epoch}: train loss {train_loss:.4f}  valid loss {val_loss:.4f}  lr {hist.lr[-1]:.2e}")
     return model, best_state, hist

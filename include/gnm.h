@@ -207,7 +207,7 @@ int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const f
  * ws: gnm_rowtile_workspace_bytes(ncols) / gnm_node_proj_bwd_workspace_bytes(ncols) /
  *     gnm_edge_bwd_fused_workspace_bytes().  partials: the BatchNorm partials buffer.      */
 size_t gnm_rowtile_workspace_bytes(int ncols);
-/* How the fused kernels multiply a fp32 tile by a fp32 weight block (process-wide, default 0):
+/* How the fused kernels multiply a fp32 tile by a fp32 weight block (process-wide, default 1):
  *   0  v_mfma_f32_32x32x2_f32 -- fp32 operands on the matrix cores;
  *   1  "bf16x3": each fp32 operand is split EXACTLY into three bf16 terms (3 x 8 = 24 significand
  *      bits) and the product is formed from six v_mfma_f32_32x32x16_bf16 (all partial products
@@ -224,6 +224,12 @@ size_t gnm_node_proj_bwd_workspace_bytes(int ncols);
 int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
                       const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,
                       void* ws, size_t ws_bytes, void* stream);
+/* the two kernels behind gnm_node_proj_bwd on their own (same ws layout and size): gh_in = gh_out + gP W, and
+ * gW = gP^T h_in, gb = sum gP                                                  autograd of :107-112 */
+int gnm_node_proj_bwd_nn(int64_t N, int H, int ncols, const float* gP, const float* W, const float* gh_out,
+                         float* gh_in, void* ws, size_t ws_bytes, void* stream);
+int gnm_node_proj_bwd_tn(int64_t N, int H, int ncols, const float* gP, const float* h_in, float* gW, float* gb,
+                         double* partials, void* ws, size_t ws_bytes, void* stream);
 size_t gnm_edge_bwd_fused_workspace_bytes(void);
 int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const float* t, const float* e_in,
                        const float* stat_e, const float* bstat_e, const float* gamma_e,

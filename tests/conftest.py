@@ -12,6 +12,8 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "default_mode_only: large GPU test that runs under the default matmul mode only")
+    config.addinivalue_line("markers", "mode_independent: GPU test that never reaches a fused (matmul-mode dependent) kernel")
 
 
 def golden_files(pattern=""):

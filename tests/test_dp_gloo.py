@@ -44,14 +44,14 @@ def _worker(rank, world, port, out_dir):
     model = G.GraphGatedGCNModel(1, 2, 32, 16, 2, 64, True, 16)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     flat = dp.FlatGradients(model.parameters())
-    assert flat.flat.numel() == sum(p.numel() for p in model.parameters())
+    assert flat.grads.numel() == sum(p.numel() for p in model.parameters()) == flat.flat.numel() - 1
     flat.zero_()
     for k, p in model.named_parameters():
         assert p.grad.data_ptr() >= flat.flat.data_ptr()        # a view of the flat buffer
         p.grad += grads[k]                                       # what autograd's accumulation does
     flat.all_reduce_mean()
     torch.optim.Adam(model.parameters(), lr=1e-3).step()
-    np.save(os.path.join(out_dir, f"flat{rank}.npy"), flat.flat.numpy())
+    np.save(os.path.join(out_dir, f"flat{rank}.npy"), flat.grads.numpy())
     np.save(os.path.join(out_dir, f"w{rank}.npy"), torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -80,3 +80,34 @@ def test_shard_graphs():
         s = sorted(sizes[sh[step]] for sh in shards)
         assert s[-1] - s[0] <= 4
     assert dp.shard_graphs(5, 1, 2) == [1, 3]
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from gnnome_assembly_amd import dp
+    dp.init_process_group("gloo")
+    mine = dp.shard_graphs(3, rank, world)             # rank 0: graphs [0, 2], rank 1: graph [1]
+    w = torch.nn.Parameter(torch.zeros(4))
+    flat = dp.FlatGradients([w])
+    nsteps = dp.steps_per_epoch(len(mine))
+    seen = []
+    for it in range(nsteps):                            # the loop shape of train.train
+        flat.zero_()
+        if it < len(mine):
+            w.grad += float(mine[it] + 1)               # "gradient" of graph g = g + 1
+        flat.all_reduce_mean(contributed=it < len(mine))
+        seen.append(w.grad.clone().numpy())
+    np.save(os.path.join(out_dir, f"uneven{rank}.npy"), np.stack(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_do_not_hang_and_average_over_contributors(tmp_path):
+    """3 graphs on 2 ranks (the rank with the shorter shard used to leave the loop early and meet the
+    others in the wrong collective).  Every rank takes max-over-ranks steps; a padding step contributes
+    nothing and is not counted in the mean."""
+    world = 2
+    mp.spawn(_uneven_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "uneven0.npy"), np.load(tmp_path / "uneven1.npy")
+    assert a.shape == (2, 4) and np.array_equal(a, b)
+    assert np.allclose(a[0], (1 + 2) / 2) and np.allclose(a[1], 3.0)     # step 1: graphs 0 and 1; step 2: graph 2 alone

@@ -1,8 +1,10 @@
-"""The opt-in "bf16x3" matmul mode of the fused kernels (include/gnm.h: gnm_set_matmul_mode(1)): every
-fp32 operand is split exactly into three bf16 terms and each product is formed from six bf16 MFMAs
-with fp32 accumulation.  The claim to verify is that this is an fp32-class matmul: the SAME parity
-bars as the default mode must hold (logits vs the reference's fp64 run, per-kernel outputs vs the
-fp64 oracle, gradients exact for the branch taken, chr19-scale directional derivative)."""
+"""The "bf16x3" matmul mode of the fused kernels (include/gnm.h: gnm_set_matmul_mode(1), the library
+default): every fp32 operand is split exactly into three bf16 terms and each product is formed from six
+bf16 MFMAs with fp32 accumulation.  The claim to verify is that this is an fp32-class matmul.  The whole
+of tests/test_gpu_parity.py runs under both modes (its autouse `matmul_mode` fixture); this file holds
+the mode-vs-mode comparisons: per-kernel error against fp64 next to the fp32-MFMA mode's, logits no
+further from the reference's fp64 run than 3x the reference's own fp32 run, and a 40-step training
+trajectory that follows the fp32-MFMA mode's."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +21,7 @@ def bf16x3_mode():
     _lib.set_matmul_mode("bf16x3")
     assert _lib.get_matmul_mode() == "bf16x3"
     yield
-    _lib.set_matmul_mode("f32")
+    _lib.set_matmul_mode("bf16x3")      # the library default
 
 
 def test_mode_switch_is_validated():
@@ -68,15 +70,10 @@ def test_fused_kernels_match_fp64_like_the_fp32_mode(M):
         assert rb <= 2e-6 and rb <= 2 * rf + 2e-7, (name, rb, rf)
 
 
-@pytest.mark.parametrize("fname", ["small_h128l8_s1.npz"])
-def test_layer_kernels_vs_oracle(fname):
-    base.test_layer_kernels_vs_oracle(fname)
-
-
 @pytest.mark.parametrize("fname", ["tiny_h128l8_s0.npz", "small_h128l8_s0.npz", "small_h128l8_s1.npz"])
 def test_logits_and_loss_match_golden(fname):
-    """Same bar as test_gpu_parity.test_model_matches_golden; the plain gradient comparison there is
-    limited by relu-branch flips of either side, so gradients are checked branch-exactly below."""
+    """Logits and loss bar of test_gpu_parity.test_model_matches_golden, plus: no further from the reference's
+    fp64 run than 3x the reference's own fp32 run is."""
     dev = base._dev()
     z, sd, H, L, bn = load_case(fname)
     model, graph, x, e, pe, y, crit = base._run_model(z, sd, H, L, dev)
@@ -91,19 +88,6 @@ def test_logits_and_loss_match_golden(fname):
     assert abs(loss.item() - float(z["loss64"])) <= 1e-5 * max(1.0, abs(float(z["loss64"])))
     for k, prm in model.named_parameters():
         assert bool(torch.isfinite(prm.grad).all()), k
-
-
-@pytest.mark.parametrize("case", ["small_h128l8_s0.npz", "small_h128l8_s1.npz", "synth_h128l3"])
-def test_gradients_exact_for_the_branch_taken(case):
-    base.test_gradients_exact_for_the_branch_taken(case)
-
-
-def test_three_adam_steps_match_reference():
-    base.test_three_adam_steps_match_reference("small_h128l8_s0.npz")
-
-
-def test_chr19_scale_step_is_finite_and_self_consistent():
-    base.test_chr19_scale_step_is_finite_and_self_consistent()
 
 
 def test_training_trajectory_matches_the_fp32_mode():

@@ -1,0 +1,123 @@
+"""The data-parallel path with the HIP kernels under N > 1 (the reference's per-graph
+step is train.py:238-258, it has no DP of its own): two processes, each running the real model on its own
+graph, exchange ONE flat gradient.  A 1-GPU box has one device, so both ranks share it and the collective goes
+through gloo (GNM_BENCH_DEVICE=0, GNM_BENCH_BACKEND=gloo); with one device per rank the same code uses RCCL.
+
+DP parity contract: exchanged gradient == mean of the two single-rank HIP gradients == mean of the two
+single-graph oracle gradients; replicas bit-equal after the Adam step."""
+import json
+import os
+import signal
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_group(cmds, envs, timeout):
+    """Start the ranks in their own process groups; on timeout kill exactly those groups."""
+    procs = [subprocess.Popen(c, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+             for c, e in zip(cmds, envs)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            outs.append(o)
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        raise AssertionError(f"data-parallel ranks did not finish within {timeout} s:\n" + "\n".join(outs))
+    return procs, outs
+
+
+def _log(name, text):
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", name), "w") as f:
+        f.write(text)
+
+
+def test_two_ranks_hip_gradients_average_and_replicas_stay_equal(tmp_path):
+    world, H, L, R = 2, 128, 3, 1500
+    port = _free_port()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+                GNM_BENCH_DEVICE="0", GNM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), str(tmp_path), str(H), str(L), str(R)]
+    procs, outs = _run_group([cmd] * world, [dict(base, RANK=str(r), LOCAL_RANK=str(r)) for r in range(world)], 300)
+    _log("dp2_hip_ranks.log", "\n".join(outs))
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    # (1) one collective, same result everywhere, replicas bit-equal after Adam
+    assert np.array_equal(z[0]["reduced"], z[1]["reduced"]) and np.array_equal(z[0]["w"], z[1]["w"])
+    # (2) == mean of the two single-rank HIP gradients (gloo: fp32 sum, then /W)
+    mean_hip = (z[0]["own"] + z[1]["own"]) / np.float32(world)
+    assert np.array_equal(z[0]["reduced"], mean_hip.astype(np.float32))
+    # (3) == mean of the two single-graph ORACLE gradients (fp64), per parameter tensor, at the gradient bars of
+    #     test_gpu_parity (rel-L2 2e-4, or within 3x the fp32 oracle's own distance: relu-kink noise)
+    from gnnome_assembly_amd import synth
+    from oracle import gatedgcn_oracle as orc
+    sd = synth.synth_state_dict(H, L, seed=0)
+    pw = float(z[0]["pos_weight"])
+
+    def oracle(dtype):
+        tot = None
+        for r in range(world):
+            src, dst, n = synth.make_graph(R, seed=r, permute_edge_ids=True)
+            inp = synth.make_inputs(src, dst, n, seed=r)
+            p = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in sd.items()}
+            s = orc.model_forward(p, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(inp["e"]).to(dtype),
+                                  torch.from_numpy(inp["pe"]).to(dtype))
+            orc.bce_loss(s, torch.from_numpy(inp["y"]).to(dtype), pw).backward()
+            g = {k: v.grad.double().numpy() / world for k, v in p.items()}
+            tot = g if tot is None else {k: tot[k] + g[k] for k in g}
+        return tot
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    o, bad = 0, []
+    gmax = max(float(np.linalg.norm(v)) for v in g64.values())
+    for k in [str(s) for s in z[0]["order"]]:
+        want = g64[k].reshape(-1)
+        got = z[0]["reduced"][o:o + want.size].astype(np.float64)
+        o += want.size
+        r, r32, mx = rel_l2(got, want), rel_l2(g32[k].reshape(-1), want), float(np.abs(got - want).max())
+        if not (r <= 2e-4 or r <= 3.0 * r32 + 1e-6 or mx <= max(2e-7, 1e-6 * gmax)):
+            bad.append((k, r, r32, mx))
+    assert o == z[0]["reduced"].size and not bad, bad
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one JSON line from rank 0),
+    with both ranks on the one device of this box and gloo instead of RCCL."""
+    port = _free_port()
+    env = dict(os.environ, GNM_BENCH_DEVICE="0", GNM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--reads", "30000", "--no-cpu-baseline"]
+    procs, outs = _run_group([cmd], [env], 600)
+    _log("dp2_bench.log", outs[0])
+    assert procs[0].returncode == 0, outs[0][-4000:]
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, outs[0][-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak" and r["value"] > 0
+    assert r["steps"] == 2 and r["warmup"] == 1
+    # whole-job aggregate: the edges of BOTH ranks per max-over-ranks step time
+    assert abs(r["value"] - r["config"]["edges_total"] / (r["ms_per_step"] / 1e3)) <= 1e-6 * r["value"]

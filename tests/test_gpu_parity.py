@@ -17,6 +17,20 @@ from helpers import load_case, sd_to_torch, rel_l2, assert_parity, RTOL, ATOL
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+def matmul_mode(request):
+    """Every test of this file runs under BOTH matmul modes of the fused kernels (include/gnm.h):
+    "bf16x3" -- the library default, the mode bench.py's `value` is measured in -- and the fp32-MFMA
+    mode.  Tests that never reach a fused kernel are marked `mode_independent` and run once."""
+    from gnnome_assembly_amd import _lib
+    if request.param == "f32" and (request.node.get_closest_marker("mode_independent")
+                                   or request.node.get_closest_marker("default_mode_only")):
+        pytest.skip("runs once (does not depend on the matmul mode, or too large to run twice)")
+    _lib.set_matmul_mode(request.param)
+    yield request.param
+    _lib.set_matmul_mode("bf16x3")
+
 GRAD_L2 = 2e-4          # norm-relative bar for one parameter-gradient tensor (fp32 vs fp64 oracle)
 GRAD_ABS_FLOOR = 2e-7   # gradients that are analytically zero (biases in front of a BatchNorm)
 # Gradients that pass through BatchNorm_e backward (B_1/B_2/B_3, bn_e) are differences of
@@ -66,6 +80,7 @@ def _cmp(name, got, want, rows):
 # library / GEMM
 # -----------------------------------------------------------------------------------------
 
+@pytest.mark.mode_independent
 def test_library_loaded_and_device():
     from gnnome_assembly_amd import _lib
     lib = _lib.load()
@@ -74,6 +89,7 @@ def test_library_loaded_and_device():
     print("CUs:", lib.gnm_num_cus(), torch.cuda.get_device_name(0))
 
 
+@pytest.mark.mode_independent
 @pytest.mark.parametrize("mode,M,N,K", [
     (0, 256, 128, 128), (0, 1000, 640, 128), (0, 777, 64, 128), (0, 300, 128, 18), (0, 513, 16, 2),
     (1, 256, 128, 128), (1, 1000, 128, 640), (1, 333, 16, 128), (1, 500, 128, 64),
@@ -233,6 +249,14 @@ def test_model_matches_golden(fname):
         if not _grad_ok(rows[-1][1], r32, rows[-1][2], max(GRAD_ABS_FLOOR, 1e-6 * gmax)):
             bad.append(rows[-1] + (r32,))
     _report(rows, f"model_{fname}.txt")
+    if bad and bn:
+        # A tensor outside the plain bars is accepted ONLY if the whole deviation is a relu decision that fell
+        # the other way in fp32 (every fp32 evaluation, the reference's own included, flips some): against
+        # the fp64 backward evaluated on the branches the device took it must agree to fp32 round-off.
+        brows, bgmax = _branch_exact_rows(z["src"], z["dst"], int(z["n"]), z["e_raw"], z["pe"], z["y"],
+                                          float(z["pos_weight"]), sd, L, dev)
+        exact = {r[0]: r for r in brows}
+        bad = [b for b in bad if exact[b[0]][1] > BRANCH_L2 and exact[b[0]][2] > max(GRAD_ABS_FLOOR, 1e-6 * bgmax)]
     assert not bad, f"gradient mismatches (name, rel_l2, max_abs, ref_norm, reference-fp32 rel_l2): {bad}"
     # eval mode == train mode (BatchNorm has no running stats: gated_gcn_full.py:55-56)
     model.eval()
@@ -268,6 +292,7 @@ def test_three_adam_steps_match_reference(fname):
     assert sum(abs(a - int(b)) for a, b in zip(tfpn, z["tfpn"])) <= 2, (tfpn, list(z["tfpn"]))
 
 
+@pytest.mark.mode_independent
 def test_fused_bce_matches_torch():
     import gnnome_assembly_amd as G
     dev = _dev()
@@ -452,6 +477,7 @@ def test_no_grad_forward_keeps_no_activations():
     assert peak_inf < 8 * eh and peak_train > 2 * peak_inf
 
 
+@pytest.mark.mode_independent
 def test_feature_preparation_matches_reference(golden_dir):
     """utils.add_positional_encoding output of the reference (golden pe_pagerank.npz) and
     utils.preprocess_graph's z-score, computed on the GPU from the graph index."""
@@ -592,8 +618,6 @@ def test_other_widths_and_norms_vs_oracle(H, L, bn):
     l64.backward()
     assert_parity(s.detach().cpu().numpy(), s64.detach().numpy(), f"H={H} L={L} bn={bn} logits")
     assert abs(loss.item() - l64.item()) < 1e-5
-    if bn:
-        return      # BatchNorm gradients: test_gradients_exact_for_the_branch_taken (kink-free comparison)
     g32 = _oracle_grads(z, sd, torch.float32, bn)
     bad = []
     for k, prm in model.named_parameters():
@@ -601,6 +625,10 @@ def test_other_widths_and_norms_vs_oracle(H, L, bn):
         r, r32 = rel_l2(got, want), rel_l2(g32[k], want)
         if not _grad_ok(r, r32, float(np.abs(got - want).max()), GRAD_ABS_FLOOR):
             bad.append((k, r, r32))
+    if bad and bn:      # BatchNorm: only relu-kink flips may explain a miss (see test_model_matches_golden)
+        brows, bgmax = _branch_exact_rows(src, dst, n, inp["e"], inp["pe"], inp["y"], float(inp["pos_weight"]), sd, L, dev)
+        exact = {r[0]: r for r in brows}
+        bad = [b for b in bad if exact[b[0]][1] > BRANCH_L2 and exact[b[0]][2] > max(GRAD_ABS_FLOOR, 1e-6 * bgmax)]
     assert not bad, bad
 
 
@@ -625,26 +653,11 @@ def _device_masks(ms, sd, e_raw_np, perm):
     return {"u": u, "w": w, "hid": hid, "a1": a1}
 
 
-@pytest.mark.parametrize("case", ["small_h128l8_s0.npz", "small_h128l8_s1.npz", "small_h64l1_s1.npz", "tiny_h64l1_s0.npz",
-                                  "synth_h256l2", "synth_h64l4", "synth_h128l3", "synth_h32l1"])
-def test_gradients_exact_for_the_branch_taken(case):
-    """Gradient parity without the relu-kink ambiguity: the fp64 oracle backward is evaluated on the
-    SAME relu branches the device took (see _device_masks); every parameter gradient must then agree to
-    fp32 round-off (rel-L2 <= 5e-5), including the B_1/B_2/B_3 tensors whose plain comparison is limited
-    by single-element branch flips of either side."""
-    from gnnome_assembly_amd import AssemblyGraph, engine, synth
+def _branch_exact_rows(src, dst, n, e_raw, pe, y, pw, sd, L, dev):
+    """rows (name, rel_l2, max_abs, ref_norm) of the HIP gradients against the fp64 oracle backward evaluated
+    on the SAME relu branches the device took, and the largest reference gradient norm."""
+    from gnnome_assembly_amd import AssemblyGraph, engine
     from oracle import gatedgcn_oracle as orc
-    dev = _dev()
-    if case.startswith("synth"):
-        H, L = {"synth_h256l2": (256, 2), "synth_h64l4": (64, 4), "synth_h128l3": (128, 3), "synth_h32l1": (32, 1)}[case]
-        src, dst, n = synth.make_graph(700, seed=H + L, permute_edge_ids=True)
-        inp = synth.make_inputs(src, dst, n, seed=H)
-        sd = synth.synth_state_dict(H, L, seed=L)
-        e_raw, pe, y, pw = inp["e"], inp["pe"], inp["y"], float(inp["pos_weight"])
-    else:
-        z, sd, H, L, bn = load_case(case)
-        src, dst, n = z["src"], z["dst"], int(z["n"])
-        e_raw, pe, y, pw = z["e_raw"], z["pe"], z["y"], float(z["pos_weight"])
     g = AssemblyGraph(src, dst, n).to(dev)
     perm = g.index()["perm"].long().cpu()
     P = {k: v.to(dev) for k, v in sd_to_torch(sd).items()}
@@ -662,8 +675,34 @@ def test_gradients_exact_for_the_branch_taken(case):
     gmax = max(float(v.norm()) for v in g64.values())
     for k in g64:
         _cmp(k, Gd[k], g64[k], rows)
+    return rows, gmax
+
+
+BRANCH_L2 = 5e-5
+
+
+@pytest.mark.parametrize("case", ["small_h128l8_s0.npz", "small_h128l8_s1.npz", "small_h64l1_s1.npz", "tiny_h64l1_s0.npz",
+                                  "synth_h256l2", "synth_h64l4", "synth_h128l3", "synth_h32l1"])
+def test_gradients_exact_for_the_branch_taken(case):
+    """Gradient parity without the relu-kink ambiguity: the fp64 oracle backward is evaluated on the
+    SAME relu branches the device took (see _device_masks); every parameter gradient must then agree to
+    fp32 round-off (rel-L2 <= 5e-5), including the B_1/B_2/B_3 tensors whose plain comparison is limited
+    by single-element branch flips of either side."""
+    from gnnome_assembly_amd import synth
+    dev = _dev()
+    if case.startswith("synth"):
+        H, L = {"synth_h256l2": (256, 2), "synth_h64l4": (64, 4), "synth_h128l3": (128, 3), "synth_h32l1": (32, 1)}[case]
+        src, dst, n = synth.make_graph(700, seed=H + L, permute_edge_ids=True)
+        inp = synth.make_inputs(src, dst, n, seed=H)
+        sd = synth.synth_state_dict(H, L, seed=L)
+        e_raw, pe, y, pw = inp["e"], inp["pe"], inp["y"], float(inp["pos_weight"])
+    else:
+        z, sd, H, L, bn = load_case(case)
+        src, dst, n = z["src"], z["dst"], int(z["n"])
+        e_raw, pe, y, pw = z["e_raw"], z["pe"], z["y"], float(z["pos_weight"])
+    rows, gmax = _branch_exact_rows(src, dst, n, e_raw, pe, y, pw, sd, L, dev)
     _report(rows, f"branch_{case}.txt")
-    bad = [r for r in rows if r[1] > 5e-5 and r[2] > max(GRAD_ABS_FLOOR, 1e-6 * gmax)]
+    bad = [r for r in rows if r[1] > BRANCH_L2 and r[2] > max(GRAD_ABS_FLOOR, 1e-6 * gmax)]
     assert not bad, bad
 
 
@@ -689,6 +728,110 @@ def test_full_size_forward_is_edge_id_order_equivariant():
     assert r <= 2e-5 and float((s1 - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
 
 
+@pytest.mark.mode_independent
+def test_train_loop_matches_the_reference_loop(tmp_path, golden_dir):
+    """gnnome_assembly_amd.train.train (the build's own LOOP, not a hand-rolled one) against the reference's
+    full-graph training loop run on the reference's own model (tests/golden/make_golden_train.py: train.py:181,
+    195-212,237-258,346-353,385-411,525-529): same seeded initial weights, same shuffled graph order, the per-step
+    loss sequence, the per-epoch train / validation losses, TP/TN/FP/FN totals, the ReduceLROnPlateau LR
+    sequence (it halves twice in this run) and the best epoch."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth, train as T
+    dev = _dev()
+    z = np.load(os.path.join(golden_dir, "train_loop_h128l2.npz"))
+    hp = {str(k): float(v) for k, v in zip(z["hp_keys"], z["hp_vals"])}
+    for k in ("seed", "num_epochs", "dim_latent", "node_features", "edge_features", "hidden_edge_features", "hidden_edge_scores",
+              "num_gnn_layers", "nb_pos_enc", "batch_size_train", "batch_size_eval", "patience"):
+        hp[k] = int(hp[k])
+    hp["batch_norm"] = bool(hp["batch_norm"])
+
+    def sample(spec):
+        reads, seed, permute = (int(v) for v in spec)
+        src, dst, n = synth.make_graph(reads, seed, permute_edge_ids=bool(permute))
+        inp = synth.make_inputs(src, dst, n, seed)
+        g = G.AssemblyGraph(src, dst, n).to(dev)
+        return T.GraphSample(g, torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(inp["pe"]).to(dev),
+                             torch.from_numpy(inp["y"]).to(dev))
+    train = [sample(z[f"train{i}"]) for i in range(2)]
+    valid = [sample(z["valid0"])]
+    # the seeded initialisation of the build's model class == the reference class's (same creation order)
+    torch.manual_seed(hp["seed"])
+    m0 = G.GraphGatedGCNModel(hp["node_features"], hp["edge_features"], hp["dim_latent"], hp["hidden_edge_features"],
+                              hp["num_gnn_layers"], hp["hidden_edge_scores"], hp["batch_norm"], hp["nb_pos_enc"])
+    for k, v in m0.state_dict().items():
+        assert np.array_equal(v.numpy().reshape(-1)[::13], z["init/" + k]), f"seeded init differs: {k}"
+    model, best, hist = T.train(train, valid, out="pin", hyperparameters=hp, workdir=str(tmp_path), verbose=False)
+    assert abs(T.pos_to_neg_ratio(train) - float(z["ratio64"])) < 1e-6                      # train.py:181
+    assert hist.step_graph == z["step_graph64"].tolist()                                    # random.shuffle order
+    got, w64, w32 = np.array(hist.step_losses), z["step_losses64"], z["step_losses32"]
+    noise = np.abs(w32 - w64) / w64                  # how far the reference's own fp32 run drifts from its fp64 run
+    rel = np.abs(got - w64) / w64
+    print("per-step loss rel. error vs reference fp64:", np.array2string(rel, precision=2),
+          "reference fp32:", np.array2string(noise, precision=2))
+    assert np.all(rel <= np.maximum(1e-4, 5 * noise)), (got, w64)
+    for name, g_, ref in (("train", hist.loss_train, z["loss_train64"]), ("valid", hist.loss_valid, z["loss_valid64"])):
+        assert np.allclose(g_, ref, rtol=1e-4, atol=0), (name, g_, ref)
+    assert hist.lr == z["lr64"].tolist() and hist.final_lr == float(z["final_lr64"])       # ReduceLROnPlateau
+    assert hist.best_epoch == int(z["best_epoch64"])
+    # TP/TN/FP/FN: predictions within round-off of 0.5 may fall either way (the reference's fp32 and fp64 runs
+    # differ by a few edges themselves); allow that band, exact where the two reference runs agree
+    for name, g_, r64, r32 in (("train", hist.tfpn_train, z["tfpn_train64"], z["tfpn_train32"]),
+                               ("valid", hist.tfpn_valid, z["tfpn_valid64"], z["tfpn_valid32"])):
+        g_ = np.array(g_)
+        assert g_.shape == r64.shape and np.array_equal(g_.sum(1), r64.sum(1))
+        assert np.all(np.abs(g_ - r64) <= 3 * np.abs(r32 - r64) + 2), (name, g_.tolist(), r64.tolist())
+    for k, v in model.state_dict().items():         # final weights after 8 Adam steps, strided sample, vs fp64
+        want = z["final/" + k]
+        got_w = v.detach().cpu().double().numpy().reshape(-1)[::13]
+        assert np.allclose(got_w, want, rtol=2e-3, atol=2e-4), (k, float(np.abs(got_w - want).max()))
+
+
+@pytest.mark.default_mode_only
+def test_chr1_scale_inference_at_size():
+    """BASELINE config 5 at its size (chr1 = 4.03 x chr19 -> R=3 M reads, N=6 M nodes, E~30 M edges,
+    H=128, L=8), forward only under no_grad as inference.py:444-454 calls the model.  E*H = 3.9 G elements
+    exceeds 2^31, so this is the case that guards every row-offset computation in the kernels.  Checks:
+    finite; a repeated run is bit-identical; peak memory stays below 8 [E,H] units (nothing is kept for a
+    backward); relabelling the edges (reversed edge-id order) permutes the logits and nothing else."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import features, synth
+    dev = _dev()
+    R, H, L = 3_000_000, 128, 8
+    src, dst, n = synth.make_graph(R, seed=5)
+    E = int(src.size)
+    assert E * H > 2 ** 31
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(H, L, 0).items()})
+    model.to(dev).eval()
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    pe = features.positional_encoding(g)                       # degrees + PageRank PE on the device (utils.py:97-138)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    e = torch.randn(E, 2, device=dev, generator=gen)
+    g.index()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        s0 = model(g, None, e, pe)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        s1 = model(g, None, e, pe)
+    unit = 4.0 * E * H
+    print(f"chr1-scale inference: N={n} E={E} peak {peak / 2**30:.1f} GiB = {peak / unit:.2f} [E,H] units")
+    assert s0.shape == (E, 1) and bool(torch.isfinite(s0).all()) and torch.equal(s0, s1)
+    assert float(s0.std()) > 1e-3                               # not a constant
+    assert peak < 8 * unit
+    del s1
+    with torch.no_grad():
+        g2 = G.AssemblyGraph(src[::-1].copy(), dst[::-1].copy(), n).to(dev)
+        s2 = model(g2, None, e.flip(0).contiguous(), pe)
+    want = s0.flip(0)
+    r = float((s2 - want).double().norm() / want.double().norm())
+    print(f"chr1-scale edge-id reversal: rel_l2 {r:.2e}, max abs {float((s2 - want).abs().max()):.2e}")
+    assert r <= 2e-5 and float((s2 - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
+
+
+@pytest.mark.mode_independent
 def test_bench_line_contract(tmp_path):
     """bench.py prints ONE JSON line with the driver's keys, the roofline and cpu_baseline objects."""
     import json
@@ -706,14 +849,27 @@ def test_bench_line_contract(tmp_path):
         assert k in r, k
     assert r["unit"] == "edges/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1
     assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
-    assert r["dtype"] == "f32" and r["data"] == "synthetic" and "workload" in r["config"]
+    assert r["dtype"] == "f32 (bf16x3 split products, f32 accumulate)" and r["config"]["matmul"] == "bf16x3"
+    assert r["data"] == "synthetic" and "workload" in r["config"]
     assert abs(r["value"] - r["config"]["edges"] / (r["ms_per_step"] / 1e3)) <= 1e-6 * r["value"]
-    rf = r["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
+    rf = r["roofline"]                 # the step against the HBM roofline, per-kernel table inside
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf and "traffic_source" in rf
+    alg = 32 * r["config"]["hidden"] * r["config"]["layers"] * r["config"]["edges"]
+    assert abs(rf["achieved"] * 1e9 - alg / (r["ms_per_step"] / 1e3)) <= 1e-6 * rf["achieved"] * 1e9
+    ks = rf["kernels"]
+    assert ks and rf["dominant_kernel"] == ks[0] and all(k["share_of_step"] >= 0.02 for k in ks)
+    ops = {k["op"] for k in ks}
+    assert "gnm_node_proj_bwd" not in ops            # its two kernels are timed on their own
+    for k in ks:
+        if "hbm" in k:
+            assert 0 < k["hbm"]["frac"] < 1.0
+        if "mfma" in k:
+            assert 0 < k["mfma"]["frac"] < 1.0
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s" and cb["sample"]
-    assert r["alt_matmul"]["matmul"] == "bf16x3" and r["alt_matmul"]["value"] > 0
+    assert r["alt_matmul"]["matmul"] == "f32" and r["alt_matmul"]["value"] > 0
+    assert "1/" in cb["sample"]                      # the sample states its ratio to the GPU workload
 
 
 def test_two_stream_backward_option_changes_nothing_but_rounding():
@@ -744,6 +900,7 @@ def test_two_stream_backward_option_changes_nothing_but_rounding():
         assert d <= 1e-5 * float(base[k].abs().max()) + 1e-9, (k, d)
 
 
+@pytest.mark.mode_independent
 def test_cxx_host_through_the_c_abi(tmp_path):
     """tests/cabi/host_layer.cpp: a C++ program with no Python and no torch runs one layer forward on
     hipMalloc'd buffers through include/gnm.h + libgnm.so and checks it against its own fp64 loops."""
