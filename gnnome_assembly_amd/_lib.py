@@ -48,6 +48,7 @@ SIGNATURES = {
     "gnm_ln_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_rowtile_workspace_bytes": (_sz, [_i32]),
     "gnm_set_occupancy_cap": (_i32, [_i32]),
+    "gnm_debug_set_variant": (_i32, [C.c_char_p, _i32]),
     "gnm_set_matmul_mode": (_i32, [_i32]),
     "gnm_get_matmul_mode": (_i32, []),
     "gnm_edge_t_fused_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),

@@ -28,6 +28,7 @@
 // the wait for the prefetched rows is vmcnt(#stores issued after them), not vmcnt(0) -- with a
 // predicated epilogue it waited for the previous tile's stores to drain on every iteration.
 // The (at most one) ragged tile of a workgroup runs through a predicated copy of the body.
+#include <string.h>
 #include <type_traits>
 
 #include "gnm_common.h"
@@ -1378,6 +1379,29 @@ using namespace gnm;
 
 static inline int64_t cdiv_(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+namespace gnm {   // gnm_tr.hip: the split-mode TN kernel on swizzled row-major images + transpose reads
+int tn_tr_rows_per_tile();
+int tn_tr_occupancy();
+void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* slab, double* partials,
+                  int nslot, int64_t tiles_per_slot, hipStream_t st);
+size_t edge_bwd_tr_pack_bytes();
+int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
+                       const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
+                       double* partials, hipStream_t st);
+}
+static int g_tn_variant = 1;     // split mode: 1 = tn_tr_k (transpose reads), 0 = tn_colgroup32_b3_k (round 1)
+static int g_eb_variant = 1;     // split mode: 1 = edge_bwd_tr_k (16-row tiles, two workgroups per CU), 0 = edge_bwd_fused_k<MmB3>
+namespace gnm {
+int eb_variant() { return g_eb_variant; }
+}
+extern "C" int gnm_debug_set_variant(const char* what, int v) {
+  if (what && !strcmp(what, "tn")) { g_tn_variant = v; return 0; }
+  if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
+  ::gnm::set_error("debug_set_variant: unknown switch");
+  return -1;
+}
+
+
 // workspace: packed weights (ncb * 16 * 64 float4)
 extern "C" size_t gnm_rowtile_workspace_bytes(int ncols) { return (size_t)(ncols / 32) * kPackBytesPerBlk; }
 
@@ -1469,9 +1493,16 @@ static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const 
                                float* gW3, float* gb3, double* partials, void* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  int grid;
+  if (MM::kSplit && g_eb_variant == 1) {
+    grid = edge_bwd_tr_launch(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, ws, slab, partials, st);
+    GNM_LAUNCH_CHECK("edge_bwd_fused (tr)");
+    hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
+    GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
+    return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
+  }
   launch_pack<MM>(W3, FH, FH / 32, 1, ws, st);
   GNM_LAUNCH_CHECK("pack_w (NN)");
-  int grid;
   if constexpr (MM::kSplit) {
     const int64_t ntiles = cdiv_(E, FTR);
     grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k<MM>>());
@@ -1505,14 +1536,17 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
 static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,
                         double* partials, float* slab, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const int64_t ntiles = cdiv_(N, g_matmul_mode ? TR3 : FTR);
-  const int occ = g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  const bool tr = g_matmul_mode && g_tn_variant == 1;
+  const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : g_matmul_mode ? TR3 : FTR);
+  const int occ = tr ? tn_tr_occupancy() : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
   int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
   nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
   if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
-  if (g_matmul_mode)
+  if (tr)
+    tn_tr_launch(N, A, lda, ncg, B, slab, partials, nslot, cdiv_(ntiles, nslot), st);
+  else if (g_matmul_mode)
     hipLaunchKernelGGL(tn_colgroup32_b3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
                        nslot, cdiv_(ntiles, nslot));
   else

@@ -213,6 +213,7 @@ size_t gnm_rowtile_workspace_bytes(int ncols);
  *      bits) and the product is formed from six v_mfma_f32_32x32x16_bf16 (all partial products
  *      above 2^-24 |x w|), accumulated in fp32 -- fp32-class accuracy at 8/6 x 2 the MFMA rate.
  * Applies to the NT / NN contractions of edge_t_fused_fwd, node_proj_fwd/bwd, edge_bwd_fused.   */
+int gnm_debug_set_variant(const char* what, int v);   /* A/B switches between kernel generations (tests, tools) */
 int gnm_set_matmul_mode(int mode);
 int gnm_get_matmul_mode(void);
 int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
