@@ -1494,7 +1494,7 @@ static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const 
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
   int grid;
-  if (MM::kSplit && g_eb_variant == 1) {
+  if (MM::kSplit && g_eb_variant >= 1) {
     grid = edge_bwd_tr_launch(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, ws, slab, partials, st);
     GNM_LAUNCH_CHECK("edge_bwd_fused (tr)");
     hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __r
 // wave's 32 columns of gt W3) by ds_read_b128 into v_mfma_f32_16x16x32_bf16, W3 stationary in 96 VGPRs.
 // 16-ROW tiles: with the weight fragments (96) and the TN accumulators (64) pinned, a 32-row tile's prefetch
 // (48 registers) no longer fits 256 registers next to the phase-0 temporaries; 16 rows need 24, and the kernel
-// runs TWO workgroups per CU (37 KB of LDS each) -- one's gt prologue / split staging / stores and HBM waits
+// runs TWO workgroups per CU (45 KB of LDS each) -- one's gt prologue / split staging / stores and HBM waits
 // under the other's MFMAs.  Round 1's split kernel kept a second, register-transposed image set (159 KB, one
 // workgroup per CU, matrix pipe 39 % busy).
 // ------------------------------------------------------------------------------------------
@@ -158,6 +158,9 @@ __global__ void pack_w3_nn16_k(const float* __restrict__ W, int64_t ld, bf16x8* 
 template <bool FULL>
 struct tile_tag { static constexpr bool full = FULL; };
 
+// VAR bit 0: residual ge rows and the fp64 column sums wait in LDS (1) or in registers (0);
+//     bit 1: the prefetch is pinned right behind the first barrier (1) or left to hipcc's scheduler (0)
+template <int VAR>
 __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
     const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
@@ -165,11 +168,14 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     float* __restrict__ slab,                        // [grid][128][128] partial gW3
     double* __restrict__ partials,                   // [grid][128]: per-workgroup column sums of gt
     int64_t tiles_per_block) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * EIMG + ER * EOP * 4 + 7 * SW * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + kBlock * 32];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in images
-  float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // gt W3 in row layout
+  float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // residual ge rows, then ge + gt W3 (row layout)
   float* cs = og + ER * EOP;                                             // mu, rstd, scale, shift, m1, m2, c = gamma*rstd
+  // this thread's four fp64 column sums of gt live in LDS, like the residual rows: the weight fragments (96
+  // registers) and the TN accumulators (64) leave no room for them beside the prefetched rows
+  double* cgs = reinterpret_cast<double*>(cs + 7 * SW) + 4 * threadIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -206,16 +212,10 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
-  double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;        // column sums of gt for columns lc4 .. lc4+3
-  // lane-constant bases of the transpose reads (gnm_tr.h): [column block][q]
-  int tra[2][2], trb[2][2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      tra[x][q] = simg_tr_base(lane, q) ^ ((2 * wn + x) << 6);
-      trb[x][q] = simg_tr_base(lane, q) ^ ((2 * wc + x) << 6);
-    }
+  constexpr bool STASH = VAR & 1, PIN = VAR & 2;
+  double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;        // column sums of gt for columns lc4 .. lc4+3 (!STASH)
+  cgs[0] = 0.0; cgs[1] = 0.0; cgs[2] = 0.0; cgs[3] = 0.0;   // ... (STASH)
+  const int trq0 = simg_tr_base(lane, 0), trq1 = simg_tr_base(lane, 1);   // transpose-read bases (gnm_tr.h)
   // NN A fragment (16x16x32): lane (i = l & 15, g = l >> 4) reads slot 4 kc + g of row i:
   //   i * SPITCH + (((kc ^ (i & 3)) << 2 | (g ^ f(i >> 2))) << 4)  =  nnb ^ (kc << 6)
   const int ni = lane & 15, ng = lane >> 4;
@@ -223,24 +223,32 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
   __syncthreads();
 
   float4 pg[2], pt[2], pe_[2];
+  // wave-uniform tile base (scalar registers) + a 32-bit lane offset: no 64-bit address registers are kept;
+  // rows past the end are clamped to the last valid row (branch-free, never stored)
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = tile * ER;
+    const int64_t left = E - r0;                                   // >= 1
+    const int last = left < ER ? (int)left - 1 : ER - 1;
+    const float* bg = ge + r0 * SW;
+    const float* bt = t + r0 * SW;
+    const float* be = e_in + r0 * SW;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      int64_t r = r0 + lrow + 8 * it;
-      r = r < Elast ? r : Elast;                     // branch-free: rows past the end are clamped, never stored
-      const int64_t o = r * SW + lc4;
-      pg[it] = ld4(ge + o);
-      pt[it] = ld4(t + o);
-      pe_[it] = ld4(e_in + o);
+      const int rl = lrow + 8 * it;
+      const int o = (rl < last ? rl : last) * SW + lc4;
+      pg[it] = ld4(bg + o);
+      pt[it] = ld4(bt + o);
+      pe_[it] = ld4(be + o);
     }
   };
   auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(tag)::full;
     const int64_t r0 = tile * ER;
-    float4 gk[2];      // this tile's ge rows, kept for the residual add in the epilogue
-    // ---- phase 0: gt tile and e_in tile -> split images ----
+    // ---- phase 0: gt tile and e_in tile -> split images; residual ge rows -> og ----
+    float4 gk[2];
     {
+      double c0 = cg0, c1 = cg1, c2 = cg2, c3 = cg3;
+      if (STASH) { c0 = cgs[0]; c1 = cgs[1]; c2 = cgs[2]; c3 = cgs[3]; }
       const float4 mu = ld4(cs + lc4), rs = ld4(cs + SW + lc4), sc = ld4(cs + 2 * SW + lc4),
                    sh = ld4(cs + 3 * SW + lc4), m1 = ld4(cs + 4 * SW + lc4), m2 = ld4(cs + 5 * SW + lc4),
                    cc = ld4(cs + 6 * SW + lc4);
@@ -248,29 +256,38 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
       for (int it = 0; it < 2; ++it) {
         const int row = lrow + 8 * it;
         const bool ok = FULL || (r0 + row < E);
-        gk[it] = pg[it];
+        if (STASH) st4(og + row * EOP + lc4, pg[it]);   // this thread read exactly these og elements in the previous epilogue
+        else gk[it] = pg[it];
         const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
         float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
         float4 ev = pe_[it];
         if (!ok) { gt = f4(0.f); ev = f4(0.f); }
-        cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
+        c0 += (double)gt.x; c1 += (double)gt.y; c2 += (double)gt.z; c3 += (double)gt.w;
         simg_stage(ig, EIMG, row, lc4, gt);
         simg_stage(ie, EIMG, row, lc4, ev);
       }
+      if (STASH) { cgs[0] = c0; cgs[1] = c1; cgs[2] = c2; cgs[3] = c3; }
+      else { cg0 = c0; cg1 = c1; cg2 = c2; cg3 = c3; }
     }
-    __syncthreads();   // images ready; every wave is done reading og of the previous tile
+    __syncthreads();   // images and residual rows ready
     prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // in flight under the MFMAs, the epilogue and the partner workgroup
+    if (PIN) __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (hipcc otherwise sinks them behind the MFMAs)
     // ---- TN: gW3[n][c] += sum_rows gt[row][n] e_in[row][c], this wave's 64 x 64 block (transpose reads) ----
     {
+      // two lane-constant bases; the column-block term is a wave-uniform XOR applied at the read.  The empty asm
+      // keeps hipcc from hoisting the eight XORed addresses into registers that live across the whole loop.
+      int tr0 = trq0, tr1 = trq1;
+      asm volatile("" : "+v"(tr0), "+v"(tr1));
       bf16x8 a[2][3];
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) a[x][s_] = simg_col_frag2(ig + s_ * EIMG, tra[x][0], tra[x][1]);
+        for (int s_ = 0; s_ < 3; ++s_)
+          a[x][s_] = simg_col_frag2(ig + s_ * EIMG, tr0 ^ ((2 * wn + x) << 6), tr1 ^ ((2 * wn + x) << 6));
 #pragma unroll
       for (int sb = 0; sb < 3; ++sb) {             // B part by B part: only two B fragments live at a time
-        const bf16x8 b0 = simg_col_frag2(ie + sb * EIMG, trb[0][0], trb[0][1]);
-        const bf16x8 b1 = simg_col_frag2(ie + sb * EIMG, trb[1][0], trb[1][1]);
+        const bf16x8 b0 = simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc) << 6), tr1 ^ ((2 * wc) << 6));
+        const bf16x8 b1 = simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc + 1) << 6), tr1 ^ ((2 * wc + 1) << 6));
 #pragma unroll
         for (int sa = 0; sa < 3; ++sa) {
           if (sa + sb > 2) continue;               // the three products below 2^-24 are dropped
@@ -302,18 +319,22 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
         mfb16s(acc[nb], a[0], wf.w[nb][kc][0]);
       }
     }
-    // C / D of the 16 x 16 MFMA: column = lane & 15, row = 4 (lane >> 4) + e  ->  row image
+    // C / D of the 16 x 16 MFMA: column = lane & 15, row = 4 (lane >> 4) + e; every og element is touched by
+    // exactly one lane: ge_in = ge + gt W3 is formed in place
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) og[(4 * ng + e) * EOP + wave * 32 + nb * 16 + ni] = acc[nb][e];
+      for (int e = 0; e < 4; ++e) {
+        float* o = og + (4 * ng + e) * EOP + wave * 32 + nb * 16 + ni;
+        *o = STASH ? *o + acc[nb][e] : acc[nb][e];
+      }
     __syncthreads();   // og complete; every wave is done with the images (the next phase 0 overwrites them)
     // ---- ge_in = ge + gt W3, whole 512-byte rows, one float4 per lane ----
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int row = lrow + 8 * it;
       const int64_t grow = r0 + row;
-      if (FULL || grow < E) st4(ge_out + grow * SW + lc4, ld4(og + row * EOP + lc4) + gk[it]);
+      if (FULL || grow < E) st4(ge_out + grow * SW + lc4, STASH ? ld4(og + row * EOP + lc4) : ld4(og + row * EOP + lc4) + gk[it]);
     }
   };
 
@@ -336,20 +357,18 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
         sl[m * SW + (2 * wc + b) * 32 + li] = tn[a][b][e];
       }
   __syncthreads();
-  double* red = reinterpret_cast<double*>(lds);          // 8 row slots x 128 columns = 8 KB
-  red[lrow * SW + lc4 + 0] = cg0;
-  red[lrow * SW + lc4 + 1] = cg1;
-  red[lrow * SW + lc4 + 2] = cg2;
-  red[lrow * SW + lc4 + 3] = cg3;
+  if (!STASH) { cgs[0] = cg0; cgs[1] = cg1; cgs[2] = cg2; cgs[3] = cg3; }
   __syncthreads();
-  if (tid < SW) {
+  if (tid < SW) {       // column c is held by the threads 32 k + c/4 (k = 0..7), entry c % 4
+    const double* all = reinterpret_cast<const double*>(cs + 7 * SW);
     double s_ = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s_ += red[k * SW + tid];
+    for (int k = 0; k < 8; ++k) s_ += all[4 * (32 * k + (tid >> 2)) + (tid & 3)];
     partials[(size_t)chunk * SW + tid] = s_;
   }
 }
 
+int eb_variant();   // gnm_fused.hip
 size_t edge_bwd_tr_pack_bytes() { return (size_t)(SW / 16) * (SW / 32) * 3 * 64 * sizeof(bf16x8); }
 // returns the grid size (= number of slabs / partial rows written)
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
@@ -357,9 +376,14 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
                        double* partials, hipStream_t st) {
   hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   const int64_t ntiles = (E + ER - 1) / ER;
-  const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_bwd_tr_k>());
-  hipLaunchKernelGGL(edge_bwd_tr_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e,
-                     (const bf16x8*)wpack, slab, partials, (ntiles + grid - 1) / grid);
+  const int var = eb_variant();      // 1: LDS stash + pinned prefetch (default); 2: registers, unpinned (A/B: within 1 % of each other)
+  const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_bwd_tr_k<3>>());
+#define GNM_EB_LAUNCH(V)                                                                                               \
+  hipLaunchKernelGGL(edge_bwd_tr_k<V>, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, \
+                     (const bf16x8*)wpack, slab, partials, (ntiles + grid - 1) / grid)
+  if (var == 2) GNM_EB_LAUNCH(0);
+  else GNM_EB_LAUNCH(3);
+#undef GNM_EB_LAUNCH
   return grid;
 }
 

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_500_000)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--which", default="edge_bwd,tn")
+    ap.add_argument("--eb-variants", default="0,1,2")
     a = ap.parse_args()
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import engine, _lib
@@ -57,7 +58,8 @@ def main():
         need = lib.gnm_edge_bwd_fused_workspace_bytes()
         ws = sc.ws(need)
         out = {}
-        for v in (0, 1):
+        EV = [int(x) for x in a.eb_variants.split(",")]
+        for v in EV:
             lib.gnm_debug_set_variant(b"edge_bwd", v)
             ge_out = torch.empty_like(ge0)
             gW3, gb3 = torch.empty(H, H, device=dev), torch.empty(H, device=dev)
@@ -68,23 +70,23 @@ def main():
             run()
             torch.cuda.synchronize()
             out[v] = (ge_out.clone(), gW3.clone(), gb3.clone(), run)
-        res = {v: [] for v in (0, 1)}
+        res = {v: [] for v in EV}
         for _ in range(a.rounds):
-            for v in (0, 1):
+            for v in EV:
                 lib.gnm_debug_set_variant(b"edge_bwd", v)
                 res[v].append(timed(out[v][3], 1)[0])
         lib.gnm_debug_set_variant(b"edge_bwd", 1)
-        for v in (0, 1):
+        for v in EV:
             print(f"edge_bwd_fused variant {v}: median {np.median(res[v]):.3f} ms  min {np.min(res[v]):.3f} ms  "
                   f"({4 * E * H * 4 / np.median(res[v]) / 1e9:.2f} TB/s algorithmic)")
-        for name, i in (("ge_out", 0), ("gW3", 1), ("gb3", 2)):
-            print(f"  {name}: rel_l2(new, old) = {rel(out[1][i], out[0][i]):.3e}")
+        for v in EV[1:]:
+            print(f"  variant {v} vs {EV[0]}: " + "  ".join(f"{name} {rel(out[v][i], out[EV[0]][i]):.3e}" for name, i in (("ge_out", 0), ("gW3", 1), ("gb3", 2))))
         # fp64 check on the first 200k rows (ge_out) -- and of gW3 / gb3 over everything in fp64 chunks
         n = min(E, 200_000)
         gu = torch.where(t[:n] * stat[2] + stat[3] > 0, ge0[:n], torch.zeros_like(ge0[:n])).double()
         gt = (gamma * stat[1]).double() * (gu - bstat[0].double() - ((t[:n].double() - mean.double()) * rstd.double()) * bstat[1].double())
         want = ge0[:n].double() + gt @ W3.double()
-        for v in (0, 1):
+        for v in EV:
             print(f"  variant {v}: ge_out vs fp64 (first {n} rows) rel_l2 = {rel(out[v][0][:n], want):.3e}")
         gW = torch.zeros(H, H, dtype=torch.float64, device=dev)
         gb = torch.zeros(H, dtype=torch.float64, device=dev)
@@ -94,7 +96,7 @@ def main():
             gt = (gamma * stat[1]).double() * (gu - bstat[0].double() - ((t[sl].double() - mean.double()) * rstd.double()) * bstat[1].double())
             gW += gt.T @ e_in[sl].double()
             gb += gt.sum(0)
-        for v in (0, 1):
+        for v in EV:
             print(f"  variant {v}: gW3 vs fp64 rel_l2 = {rel(out[v][1], gW):.3e}   gb3 rel_l2 = {rel(out[v][2], gb):.3e}")
         del ge0, t, e_in, out
         torch.cuda.empty_cache()
