@@ -72,7 +72,7 @@ def op_model(op: str, N: int, E: int, H: int):
         "gnm_edge_t_stats_fwd": (2 * eh + 2 * nh, 0.0),       # t in/out, B1h/B2h rows
         "gnm_edge_gate_fwd": (3 * eh + 4 * nh, 0.0),          # t, e_in in; e_out out; A2h in; hf, inv_f, Td out
         "gnm_node_agg_src_fwd": (1 * eh + 6 * nh, 0.0),       # e_out in; A1h, A3h, hf in; hb, inv_b, z out
-        "gnm_edge_bwd_dst": (4 * eh + 9 * nh, 0.0),           # e_out, t, ge in; ge out; Q(4) A2h A3h in; gA3h Ud Td out
+        "gnm_edge_bwd_dst": (4 * eh + 9 * nh, 0.0),           # e_out, t, ge in; ge out; Qf hf A3h (own) Qb hb A2h (src) in; gA3h Ud Td out
         "gnm_edge_bwd_src": (3 * eh + 6 * nh, 0.0),           # e_out, t, ge in; Qf Ud Td in; gA2h gB1h gB2h out
         "gnm_edge_bwd_gt": (3 * eh, 0.0),                     # ge, t in; gt out
         "gnm_edge_t_fused_fwd": (2 * eh + 2 * nh, 2.0 * E * H * H),        # e_in in, t out, B1h/B2h rows
@@ -82,7 +82,7 @@ def op_model(op: str, N: int, E: int, H: int):
         "gnm_node_proj_bwd_tn": (6 * nh, 2.0 * N * H * 5 * H),             # gP, h_in in
         "gnm_edge_encoder_fwd": (eh, 0.0),
         "gnm_edge_encoder_bwd": (eh, 0.0),
-        "gnm_node_bwd_apply": (11 * nh, 0.0),
+        "gnm_node_bwd_apply": (7 * nh, 0.0),                  # z, gh_out, inv_f, inv_b in; gz, Qf, Qb out
         "gnm_node_bwd_stats": (2 * nh, 0.0),
         "gnm_node_update_fwd": (3 * nh, 0.0),
         "gnm_predictor_fused_fwd": (1.5 * eh + 2 * 4.0 * N * 64, 2.0 * E * H * 64),    # e in, hid out ([E,64])
@@ -335,6 +335,20 @@ def main():
                        "exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate.  Both modes pass the "
                        "whole of tests/test_gpu_parity.py"}
         dbg("alt matmul run done")
+    # the "lean" activation mode (engine.set_activation_mode): one step, for its time and its peak memory
+    alt_act = None
+    peak_saved = torch.cuda.max_memory_allocated()
+    if not args.inference and args.matmul is None and not args.no_alt_matmul and engine.ACTIVATIONS == "saved":
+        engine.set_activation_mode("lean")
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        step()
+        ldt, ledges = timed_run(max(2, args.steps // 2))
+        alt_act = {"activations": "lean", "ms_per_step": ldt / max(2, args.steps // 2) * 1e3,
+                   "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                   "note": "P [N,5H] and t [E,H] are rebuilt in the backward by the kernels that made them instead of being "
+                           "kept; bit-identical results (tests/test_gpu_parity.py::test_lean_activation_mode...)"}
+        engine.set_activation_mode("saved")
     res = None
     if rank == 0:
         tot = sum(t for _, t in ops.values())
@@ -380,14 +394,16 @@ def main():
                                    + (", RCCL grad all-reduce" if world > 1 else ""),
                        "reads": R, "nodes": n, "edges": E, "edges_total": int(total_edges), "hidden": H, "layers": L,
                        "parallelism": f"dp{world}", "edge_layers_per_s": value * L, "matmul": mode,
-                       "activations": engine.ACTIVATIONS if hasattr(engine, "ACTIVATIONS") else "saved"},
+                       "activations": engine.ACTIVATIONS},
             "roofline": roof,
             "op_ms": {k: round(v[1], 3) for k, v in ranked},
             "op_total_ms": round(tot, 3),
-            "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "peak_mem_gib": round(peak_saved / 2 ** 30, 1),
         }
         if alt:
             res["alt_matmul"] = alt
+        if alt_act:
+            res["alt_activations"] = alt_act
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(res), flush=True)

@@ -37,8 +37,8 @@ SIGNATURES = {
     "gnm_node_agg_src_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p]),
     "gnm_node_bwd_stats": (_i32, [_i64, _i32, _p, _p, _p, _p, _pi, _p]),
-    "gnm_node_bwd_apply": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_node_bwd_apply": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_bwd_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_ln_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

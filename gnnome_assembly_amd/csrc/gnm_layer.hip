@@ -192,13 +192,15 @@ __global__ __launch_bounds__(kBlock) void node_bwd_stats_k(int64_t N, const floa
   block_stat_store<H>(st, lds, partials, chunk);
 }
 
-// gz = gamma*rstd*(gw - m1 - zhat*m2) -> gP[:,0:H]; Q = [gz*inv_f | gz*inv_f*hf | gz*inv_b | gz*inv_b*hb]
+// gz = gamma*rstd*(gw - m1 - zhat*m2) -> gP[:,0:H]; Q[N,2H] = [qf = gz*inv_f | qb = gz*inv_b]
+// (the by-destination / by-source passes form rf = qf*hf and rb = qb*hb themselves from the saved hf / hb rows:
+//  same number of rows read there, two [N,H] writes and two [N,H] reads fewer here)
 template <int H>
 __global__ __launch_bounds__(kBlock) void node_bwd_apply_k(
     int64_t N, const float* __restrict__ z, const float* __restrict__ stat,
     const float* __restrict__ bstat, const float* __restrict__ gamma,
-    const float* __restrict__ gh_out, const float* __restrict__ hf, const float* __restrict__ inv_f,
-    const float* __restrict__ hb, const float* __restrict__ inv_b, float* __restrict__ gP,
+    const float* __restrict__ gh_out, const float* __restrict__ inv_f,
+    const float* __restrict__ inv_b, float* __restrict__ gP,
     float* __restrict__ Q) {
   constexpr int G = H / 4;
   const int64_t total = N * G;
@@ -214,13 +216,9 @@ __global__ __launch_bounds__(kBlock) void node_bwd_apply_k(
     const float4 gw = gate4(fma4(zz, sc, sh), ld4_nt(gh_out + o));
     const float4 gz = c * (gw - m1 - ((zz - mu) * rs) * m2);
     st4_nt(gP + v * (5 * H) + c4, gz);
-    const float4 qf = gz * ld4_nt(inv_f + o);
-    const float4 qb = gz * ld4_nt(inv_b + o);
-    float* q = Q + v * (4 * H) + c4;
-    st4_nt(q, qf);
-    st4_nt(q + H, qf * ld4_nt(hf + o));
-    st4_nt(q + 2 * H, qb);
-    st4_nt(q + 3 * H, qb * ld4_nt(hb + o));
+    float* q = Q + v * (2 * H) + c4;
+    st4_nt(q, gz * ld4_nt(inv_f + o));
+    st4_nt(q + H, gz * ld4_nt(inv_b + o));
   }
 }
 
@@ -229,7 +227,8 @@ template <int H>
 __global__ __launch_bounds__(kBlock) void edge_bwd_dst_k(
     int64_t N, const float* __restrict__ e_out, const float* __restrict__ t,
     const float* __restrict__ stat, float* __restrict__ ge, const float* __restrict__ P,
-    const float* __restrict__ Q, const int32_t* __restrict__ isrc,
+    const float* __restrict__ Q, const float* __restrict__ hf, const float* __restrict__ hb,
+    const int32_t* __restrict__ isrc,
     const int32_t* __restrict__ in_ptr, float* __restrict__ gP, float* __restrict__ Ud,
     float* __restrict__ Td, double* __restrict__ partials, int64_t nodes_per_block) {
   constexpr int G = H / 4, RPW = 64 / G;
@@ -248,16 +247,16 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_dst_k(
     const int a = in_ptr[v], b = in_ptr[v + 1];
     float4 a3acc = f4(0.f), ud = f4(0.f), td = f4(0.f);
     if (a < b) {
-      const float4 qf_d = ld4_nt(Q + v * (4 * H) + c4);       // this node's own segments: read once here
-      const float4 rf_d = ld4_nt(Q + v * (4 * H) + H + c4);
+      const float4 qf_d = ld4_nt(Q + v * (2 * H) + c4);       // this node's own rows: read once here
+      const float4 rf_d = qf_d * ld4_nt(hf + v * H + c4);
       const float4 a3_d = ld4_nt(P + v * (5 * H) + 2 * H + c4);
       for (int64_t j = a + sub; j < b; j += RPW) {
         const int64_t s = isrc[j];
         float4 sg, dsg;
         sigmoid_grad4(ld4_nt(e_out + j * H + c4), sg, dsg);
         const float4 a2_s = ld4(P + s * (5 * H) + H + c4);
-        const float4 qb_s = ld4(Q + s * (4 * H) + 2 * H + c4);
-        const float4 rb_s = ld4(Q + s * (4 * H) + 3 * H + c4);
+        const float4 qb_s = ld4(Q + s * (2 * H) + H + c4);
+        const float4 rb_s = qb_s * ld4(hb + s * H + c4);
         const float4 gsig = fma4(qf_d, a2_s, fma4(qb_s, a3_d, f4(0.f) - rf_d - rb_s));
         const float4 g = fma4(gsig, dsg, ld4_nt(ge + j * H + c4));
         st4_nt(ge + j * H + c4, g);
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_src_k(
     for (int64_t m = a + sub; m < b; m += RPW) {
       const int64_t j = out_pos[m], d = out_dst[m];
       const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
-      const float4 qf_d = ld4(Q + d * (4 * H) + c4);
+      const float4 qf_d = ld4(Q + d * (2 * H) + c4);
       const float4 tt = ld4_nt(t + j * H + c4);
       const float4 gu = gate4(fma4(tt, sc, sh), ld4_nt(ge + j * H + c4));
       a2acc = fma4(sg, qf_d, a2acc);
@@ -517,27 +516,27 @@ extern "C" int gnm_node_bwd_stats(int64_t N, int H, const float* z, const float*
 
 extern "C" int gnm_node_bwd_apply(int64_t N, int H, const float* z, const float* stat_h,
                                   const float* bstat_h, const float* gamma_h, const float* gh_out,
-                                  const float* hf, const float* inv_f, const float* hb,
-                                  const float* inv_b, float* gP, float* Q, void* stream) {
-  GNM_CHECK_ARG(N >= 0 && z && stat_h && bstat_h && gamma_h && gh_out && hf && inv_f && hb && inv_b && gP && Q,
+                                  const float* inv_f, const float* inv_b, float* gP, float* Q, void* stream) {
+  GNM_CHECK_ARG(N >= 0 && z && stat_h && bstat_h && gamma_h && gh_out && inv_f && inv_b && gP && Q,
                 "node_bwd_apply: null/neg argument");
   GNM_DISPATCH_H(H, hipLaunchKernelGGL(node_bwd_apply_k<HH>, dim3(ew_grid(N * (HH / 4))), dim3(kBlock),
                                        0, (hipStream_t)stream, N, z, stat_h, bstat_h, gamma_h, gh_out,
-                                       hf, inv_f, hb, inv_b, gP, Q));
+                                       inv_f, inv_b, gP, Q));
   GNM_LAUNCH_CHECK("node_bwd_apply");
   return 0;
 }
 
 extern "C" int gnm_edge_bwd_dst(int64_t N, int64_t E, int H, const float* e_out, const float* t,
                                 const float* stat_e, float* ge, const float* P, const float* Q,
+                                const float* hf, const float* hb,
                                 const int32_t* isrc, const int32_t* in_ptr, float* gP, float* Ud,
                                 float* Td, double* partials, int* nblk_out, void* stream) {
-  GNM_CHECK_ARG(N >= 0 && E >= 0 && e_out && t && stat_e && ge && P && Q && isrc && in_ptr && gP && Ud && Td &&
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && e_out && t && stat_e && ge && P && Q && hf && hb && isrc && in_ptr && gP && Ud && Td &&
                     partials && nblk_out, "edge_bwd_dst: null/neg argument");
   GNM_DISPATCH_H(H, {
     const int grid = persistent_grid(N, 64, occ_blocks<edge_bwd_dst_k<HH>>());
     const int64_t npb = ceil_div64(N, grid);
-    hipLaunchKernelGGL(edge_bwd_dst_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, e_out, t, stat_e, ge, P, Q, isrc, in_ptr, gP, Ud, Td, partials, npb);
+    hipLaunchKernelGGL(edge_bwd_dst_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, e_out, t, stat_e, ge, P, Q, hf, hb, isrc, in_ptr, gP, Ud, Td, partials, npb);
     *nblk_out = grid;
   });
   GNM_LAUNCH_CHECK("edge_bwd_dst");

@@ -26,6 +26,23 @@ EPS_BN = 1e-5   # nn.BatchNorm1d default (gated_gcn_full.py:55-56)
 
 LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
 
+# What a training forward keeps for the backward pass:
+#   "saved"  every intermediate the backward kernels read: per layer P [N,5H], t [E,H], e_out [E,H], hf, inv_f, hb,
+#            inv_b, z [N,H] (137 GiB at N=1.5 M / E=7.54 M / H=128 / L=8);
+#   "lean"   P and t are NOT kept: the backward of a layer first re-runs the two kernels that produced them
+#            (node projections, then the fused edge-t kernel) from h_in / e_in, which ARE kept (e_in is the previous
+#            layer's e_out).  Bit-identical results (same kernels, same inputs), about 7 GiB less per layer at the
+#            size above, for two extra kernels per layer (+3.3 ms of 25).
+ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
+
+
+def set_activation_mode(mode: str) -> None:
+    global ACTIVATIONS
+    if mode not in ("saved", "lean"):
+        raise _lib.GnmError(f"activation mode {mode!r}: expected 'saved' or 'lean'")
+    ACTIVATIONS = mode
+
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -242,18 +259,15 @@ class LayerSaved:
     stat_h: torch.Tensor = None
 
 
-@on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
-def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True):
-    """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
-    Returns (h_out, e_out, LayerSaved or None)."""
+def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
+    """P = h W5^T + b5 [N,5H] and t = e W3^T + b3 + B1h[src] + B2h[dst] [E,H] (gated_gcn_full.py:107-113,120-121);
+    leaves the BatchNorm partial sums of t in the scratch buffer and their count in nblk."""
     lib = _lib.load()
     dev = h_in.device
     sc = scratch(dev)
     st = _stream()
-    nblk = C.c_int(0)
-    f32 = dict(dtype=torch.float32, device=dev)
-    P = torch.empty(N, 5 * H, **f32)
-    t = torch.empty(E, H, **f32)
+    P = torch.empty(N, 5 * H, dtype=torch.float32, device=dev)
+    t = torch.empty(E, H, dtype=torch.float32, device=dev)
     if H == 128 and FUSED:
         # W-stationary fused MFMA path: projections, then t + BatchNorm partials in one pass
         need = lib.gnm_rowtile_workspace_bytes(5 * H)
@@ -268,6 +282,20 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
         # t += B1h[src] + B2h[dst], BatchNorm statistics over all E edges       (:120-122)
         _call("gnm_edge_t_stats_fwd", E, H, _ptr(t), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
               _ptr(sc.partials), C.byref(nblk), st)
+    return P, t
+
+
+@on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
+def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True):
+    """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
+    Returns (h_out, e_out, LayerSaved or None)."""
+    lib = _lib.load()
+    dev = h_in.device
+    sc = scratch(dev)
+    st = _stream()
+    nblk = C.c_int(0)
+    f32 = dict(dtype=torch.float32, device=dev)
+    P, t = _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk)
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
@@ -296,8 +324,9 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
         _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(h_in), _ptr(h_out), st)
     saved = None
     if save:
-        saved = LayerSaved(h_in=h_in, e_in=e_in, P=P, t=t, stat_e=stat_e, e_out=e_out, hf=hf, inv_f=inv_f,
-                           hb=hb, inv_b=inv_b, z=z, stat_h=stat_h)
+        lean = ACTIVATIONS == "lean"
+        saved = LayerSaved(h_in=h_in, e_in=e_in, P=None if lean else P, t=None if lean else t, stat_e=stat_e, e_out=e_out,
+                           hf=hf, inv_f=inv_f, hb=hb, inv_b=inv_b, z=z, stat_h=stat_h)
     return h_out, e_out, saved
 
 
@@ -312,8 +341,10 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     nblk = C.c_int(0)
     f32 = dict(dtype=torch.float32, device=dev)
     g: Dict[str, torch.Tensor] = {}
+    if s.P is None or s.t is None:      # "lean" activations: rebuild P and t with the kernels that made them
+        s.P, s.t = _proj_and_t(idx, N, E, H, prm, s.h_in, s.e_in, C.c_int(0))
     gP = torch.empty(N, 5 * H, **f32)
-    Q = torch.empty(N, 4 * H, **f32)
+    Q = torch.empty(N, (2 if batch_norm else 4) * H, **f32)     # BatchNorm mode: Qf | Qb; LayerNorm mode keeps Rf, Rb too
     g["W3"] = torch.empty(H, H, **f32)
     if not batch_norm:
         # ---- LayerNorm mode: no global barriers, gt is produced by the by-destination pass ----
@@ -338,12 +369,12 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               C.byref(nblk), st)
         bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
         _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
-              _ptr(gh_out), _ptr(s.hf), _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
+              _ptr(gh_out), _ptr(s.inv_f), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
         # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
         Ud = torch.empty(N, H, **f32)
         Td = torch.empty(N, H, **f32)
         _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
-              _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+              _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
               _ptr(sc.partials), C.byref(nblk), st)
         bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
         corun = CORUN and H == 128 and FUSED and _prof is None

@@ -142,17 +142,17 @@ int gnm_node_update_fwd(int64_t N, int H, const float* z, const float* stat_h, c
 int gnm_node_bwd_stats(int64_t N, int H, const float* z, const float* stat_h, const float* gh_out,
                        double* partials, int* nblk_out, void* stream);
 /* node_bwd_apply: gz = gamma*rstd*(gw - m1 - zhat*m2) -> gP[:,0:H];
- *                 Q[N,4H] = gz*inv_f | gz*inv_f*hf | gz*inv_b | gz*inv_b*hb              */
+ *                 Q[N,2H] = Qf | Qb = gz*inv_f | gz*inv_b                                 */
 int gnm_node_bwd_apply(int64_t N, int H, const float* z, const float* stat_h, const float* bstat_h,
-                       const float* gamma_h, const float* gh_out, const float* hf,
-                       const float* inv_f, const float* hb, const float* inv_b, float* gP, float* Q,
-                       void* stream);
-/* edge_bwd_dst (internal order, by destination):
+                       const float* gamma_h, const float* gh_out, const float* inv_f, const float* inv_b,
+                       float* gP, float* Q, void* stream);
+/* edge_bwd_dst (internal order, by destination), Rf = Qf*hf, Rb = Qb*hb formed from the saved hf / hb rows:
  *   gsigma = Qf[d]*A2h[s] - Rf[d] + Qb[s]*A3h[d] - Rb[s];  ge <- ge + gsigma*sigma*(1-sigma)
  *   gu = ge*[t*scale+shift > 0];  partials (sum gu, sum gu*that)
  *   gP[:,2H:3H][d] = sum sigma*Qb[s];  Ud[d] = sum gu;  Td[d] = sum that                 */
 int gnm_edge_bwd_dst(int64_t N, int64_t E, int H, const float* e_out, const float* t,
                      const float* stat_e, float* ge, const float* P, const float* Q,
+                     const float* hf, const float* hb,
                      const int32_t* isrc, const int32_t* in_ptr, float* gP, float* Ud, float* Td,
                      double* partials, int* nblk_out, void* stream);
 /* edge_bwd_src (by source, after bn_bwd_finalize):

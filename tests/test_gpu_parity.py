@@ -789,6 +789,43 @@ def test_train_loop_matches_the_reference_loop(tmp_path, golden_dir):
     assert r <= 3e-3 and np.abs(got_all - want_all).max() <= hp["lr"]      # no element further than one Adam step
 
 
+def test_lean_activation_mode_is_bit_identical_and_smaller():
+    """engine.set_activation_mode("lean"): P [N,5H] and t [E,H] are not kept for the backward but rebuilt by the
+    kernels that made them.  Same kernels on the same inputs: logits, loss and every gradient bit-identical to
+    the default mode; the peak memory of a training step drops by about 2 of the ~5.3 [E,H]-sized tensors a
+    layer keeps."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(60000, 128, 6, 2, dev)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    e, pe, y = (torch.from_numpy(inp[k]).to(dev) for k in ("e", "pe", "y"))
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    g.index()
+
+    def run(mode):
+        engine.set_activation_mode(mode)
+        try:
+            model.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            s = model(g, None, e, pe)
+            loss = crit(s.squeeze(-1), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            peak = torch.cuda.max_memory_allocated() - base
+            return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}, peak
+        finally:
+            engine.set_activation_mode("saved")
+    s0, l0, g0, p0 = run("saved")
+    s1, l1, g1, p1 = run("lean")
+    assert torch.equal(s0, s1) and l0 == l1 and all(torch.equal(g0[k], g1[k]) for k in g0)
+    unit = 4.0 * src.size * 128
+    print(f"peak memory of one training step: saved {p0 / unit:.1f} [E,H] units, lean {p1 / unit:.1f}")
+    assert p1 < p0 - 6 * 1.5 * unit          # ~2 units per layer (t, and P = 5N/E units), 6 layers, with slack
+
+
 @pytest.mark.default_mode_only
 def test_chr1_scale_inference_at_size():
     """BASELINE config 5 at its size (chr1 = 4.03 x chr19 -> R=3 M reads, N=6 M nodes, E~30 M edges,
