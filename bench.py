@@ -265,6 +265,7 @@ def main():
     pe = torch.from_numpy(inp["pe"]).to(dev)
     y = torch.from_numpy(inp["y"]).to(dev)
     crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    model.flatten_parameters()                      # one parameter buffer in the engine's layout; the gradients follow it
     flat = dp.FlatGradients(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 

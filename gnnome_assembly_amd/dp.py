@@ -9,12 +9,26 @@ gradient (826,033 floats = 3.3 MB at H=128/L=8), latency-bound on xGMI."""
 from __future__ import annotations
 
 import os
-from typing import Iterable
+import weakref
+from typing import Iterable, Optional
 
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_process_group", "FlatGradients", "shard_graphs", "steps_per_epoch"]
+__all__ = ["init_process_group", "FlatGradients", "shard_graphs", "steps_per_epoch", "fresh_flat_gradients"]
+
+_live = weakref.WeakSet()      # the FlatGradients objects alive in this process
+
+
+def fresh_flat_gradients(params) -> "Optional[FlatGradients]":
+    """The FlatGradients whose buffer holds the .grad of EVERY tensor in `params`, if it has been zeroed since its
+    last use (so that writing a gradient into it equals accumulating it); None otherwise."""
+    if not params:
+        return None
+    for fg in _live:
+        if fg.fresh and fg.owns(params):
+            return fg
+    return None
 
 
 def init_process_group(backend: str | None = None):
@@ -45,6 +59,10 @@ class FlatGradients:
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
+        if all(hasattr(p, "_gnm_slot") for p in self.params):
+            # a model flattened by models.flatten_parameters: follow its layout, so that the five stacked projection
+            # gradients of a layer are one [5H,H] block the kernels can write directly
+            self.params.sort(key=lambda p: p._gnm_slot)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
@@ -53,9 +71,17 @@ class FlatGradients:
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
             o += p.numel()
+        self.fresh = True          # all zeros: a kernel may WRITE a gradient instead of accumulating it
+        self._ids = {id(p) for p in self.params}
+        _live.add(self)
+
+    def owns(self, params) -> bool:
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.grads.numel() * 4
+        return all(id(p) in self._ids and p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params)
 
     def zero_(self):
         self.flat.zero_()
+        self.fresh = True
         for p in self.params:       # autograd may have replaced a view; re-bind is cheap
             if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
                     p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:

@@ -216,11 +216,11 @@ def bn_finalize(partials, nblk, count, H, gamma, beta):
     return stat
 
 
-def bn_bwd_finalize(partials, nblk, count, H, device):
+def bn_bwd_finalize(partials, nblk, count, H, device, gg=None, gb=None):
     lib = _lib.load()
     bstat = torch.empty(2, H, dtype=torch.float32, device=device)
-    gg = torch.empty(H, dtype=torch.float32, device=device)
-    gb = torch.empty(H, dtype=torch.float32, device=device)
+    gg = torch.empty(H, dtype=torch.float32, device=device) if gg is None else gg
+    gb = torch.empty(H, dtype=torch.float32, device=device) if gb is None else gb
     _call("gnm_bn_bwd_finalize", _ptr(partials), nblk, count, H, _ptr(bstat), _ptr(gg), _ptr(gb),
                                        _stream())
     return bstat, gg, gb
@@ -331,9 +331,14 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
 
 
 @on_device_of(lambda idx, N, E, H, prm, s, gh_out, *a, **k: gh_out)
-def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True):
+def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True,
+                   out: Optional[Dict[str, torch.Tensor]] = None):
     """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
-    and is OVERWRITTEN with d loss / d e_in.  Returns (gh_in, ge, grads dict)."""
+    and is OVERWRITTEN with d loss / d e_in.  Returns (gh_in, ge, grads dict).  `out` (optional) names the tensors
+    the parameter gradients are written INTO (keys W5 b5 W3 b3 gamma_e beta_e gamma_h beta_h; contiguous blocks,
+    e.g. views of a flat gradient buffer) instead of fresh allocations."""
+    out = out or {}
+    new = lambda key, *shape: out[key] if key in out else torch.empty(*shape, dtype=torch.float32, device=gh_out.device)  # noqa: E731
     lib = _lib.load()
     dev = gh_out.device
     sc = scratch(dev)
@@ -345,29 +350,29 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         s.P, s.t = _proj_and_t(idx, N, E, H, prm, s.h_in, s.e_in, C.c_int(0))
     gP = torch.empty(N, 5 * H, **f32)
     Q = torch.empty(N, (2 if batch_norm else 4) * H, **f32)     # BatchNorm mode: Qf | Qb; LayerNorm mode keeps Rf, Rb too
-    g["W3"] = torch.empty(H, H, **f32)
+    g["W3"] = new("W3", H, H)
     if not batch_norm:
         # ---- LayerNorm mode: no global barriers, gt is produced by the by-destination pass ----
         _call("gnm_ln_node_bwd", N, H, _ptr(s.z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(gh_out), _ptr(s.hf),
               _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), _ptr(sc.partials), C.byref(nblk), st)
-        _, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
+        _, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
         gt = torch.empty(E, H, **f32)
         _call("gnm_ln_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(prm.gamma_e), _ptr(prm.beta_e),
               _ptr(ge), _ptr(s.P), _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt),
               _ptr(sc.partials), C.byref(nblk), st)
-        _, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
+        _, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
         _call("gnm_ln_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q), _ptr(idx["out_ptr"]),
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
         del Q
         gemm(TN, gt, s.e_in, g["W3"])
-        g["b3"] = colsum(gt)
+        g["b3"] = colsum(gt, out.get("b3"))
         gemm(NN, gt, prm.W3, ge, resid=ge)
         del gt
     else:
         # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
         _call("gnm_node_bwd_stats", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
               C.byref(nblk), st)
-        bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev)
+        bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
         _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
               _ptr(gh_out), _ptr(s.inv_f), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
         # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
@@ -376,13 +381,13 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
               _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
               _ptr(sc.partials), C.byref(nblk), st)
-        bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev)
+        bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
         corun = CORUN and H == 128 and FUSED and _prof is None
         if corun:
             # fused edge backward (MFMA-bound) on the side stream, one workgroup per CU, writing a fresh ge ...
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             sc2 = scratch(dev, "side")
-            g["b3"] = torch.empty(H, **f32)
+            g["b3"] = new("b3", H)
             ge_new = torch.empty_like(ge)
             need = lib.gnm_edge_bwd_fused_workspace_bytes()
             ws2 = sc2.ws(need)
@@ -404,7 +409,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             ge = ge_new
         # gt, B_3 gradients, ge_in = ge_tot + gt W3
         elif H == 128 and FUSED:
-            g["b3"] = torch.empty(H, **f32)
+            g["b3"] = new("b3", H)
             need = lib.gnm_edge_bwd_fused_workspace_bytes()
             ws = sc.ws(need)
             _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
@@ -414,14 +419,14 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(gt), st)
             gemm(TN, gt, s.e_in, g["W3"])
-            g["b3"] = colsum(gt)
+            g["b3"] = colsum(gt, out.get("b3"))
             gemm(NN, gt, prm.W3, ge, resid=ge)
             del gt
     # node projections backward
-    g["W5"] = torch.empty(5 * H, H, **f32)
+    g["W5"] = new("W5", 5 * H, H)
     gh_in = torch.empty(N, H, **f32)
     if H == 128 and FUSED:
-        g["b5"] = torch.empty(5 * H, **f32)
+        g["b5"] = new("b5", 5 * H)
         need = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
         ws = sc.ws(need)
         _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh_out), _ptr(gh_in), _ptr(ws), need, st)
@@ -429,7 +434,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               _ptr(sc.partials), _ptr(ws), need, st)
     else:
         gemm(TN, gP, s.h_in, g["W5"])
-        g["b5"] = colsum(gP)
+        g["b5"] = colsum(gP, out.get("b5"))
         gemm(NN, gP, prm.W5, gh_in, resid=gh_out)
     return gh_in, ge, g
 
@@ -476,8 +481,9 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
 
 
 @on_device_of(lambda idx, N, E, H, W1, W2, s, gscores: gscores)
-def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores):
-    """Returns (gx [N,H], ge [E,H] fresh buffer, grads dict W1,b1,W2,b2)."""
+def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores, out: Optional[Dict[str, torch.Tensor]] = None):
+    """Returns (gx [N,H], ge [E,H] fresh buffer, grads dict W1,b1,W2,b2); `out` as in layer_backward."""
+    out = out or {}
     lib = _lib.load()
     dev = s.x.device
     sc = scratch(dev)
@@ -489,7 +495,7 @@ def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores):
     gscores = _f32c(gscores.reshape(-1))
     ghid = s.hid   # in place
     fused = H == 128 and HS == 64 and FUSED
-    gW1 = torch.empty(HS, 3 * H, **f32)
+    gW1 = out["W1"] if "W1" in out else torch.empty(HS, 3 * H, **f32)
     if fused:
         # one pass: ghid (in place), ge = ghid W1e, gW1e, and the gW2 / gb1 / gb2 column sums
         ge = torch.empty(E, H, **f32)
@@ -499,18 +505,23 @@ def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores):
         ws = sc.ws(need)
         _call("gnm_predictor_fused_bwd", E, H, HS, _ptr(ghid), _ptr(gscores), _ptr(idx["perm"]), _ptr(W2), _ptr(s.e),
               _ptr(W1[:, 2 * H:]), W1.stride(0), _ptr(ge), _ptr(gW1e), _ptr(gsums), _ptr(sc.partials), _ptr(ws), need, st)
-        g["W2"] = gsums[0:HS].reshape(1, HS).clone()
-        g["b1"] = gsums[HS:2 * HS].clone()
-        g["b2"] = gsums[2 * HS:2 * HS + 1].clone()
+        def keep(key, src):
+            if key in out:
+                out[key].copy_(src.reshape(out[key].shape))
+                return out[key]
+            return src.clone()
+        g["W2"] = keep("W2", gsums[0:HS].reshape(1, HS))
+        g["b1"] = keep("b1", gsums[HS:2 * HS])
+        g["b2"] = keep("b2", gsums[2 * HS:2 * HS + 1])
         gW1[:, 2 * H:] = gW1e
     else:
         _call("gnm_predictor_score_bwd", E, HS, _ptr(ghid), _ptr(gscores), _ptr(W2), _ptr(idx["perm"]),
                                                _ptr(sc.partials), C.byref(nblk), st)
         red = torch.empty(2, HS, **f32)
         _call("gnm_reduce_partials", _ptr(sc.partials), nblk.value, 2, HS, _ptr(red), st)
-        g["W2"] = red[0:1].clone()
-        g["b2"] = red[1, 0:1].clone()
-        g["b1"] = colsum(ghid)
+        g["W2"] = out["W2"].copy_(red[0:1]) if "W2" in out else red[0:1].clone()
+        g["b2"] = out["b2"].copy_(red[1, 0:1]) if "b2" in out else red[1, 0:1].clone()
+        g["b1"] = colsum(ghid, out.get("b1"))
     gPn = torch.empty(N, 2 * HS, **f32)
     _call("gnm_seg_sum_rows", N, HS, _ptr(ghid), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]),
                                     _ptr(gPn), 2 * HS, st)
@@ -552,11 +563,26 @@ class ModelSaved:
     pred: PredSaved = None
 
 
+def stacked(ts):
+    """cat(ts, 0) -- as a VIEW when the tensors already sit back to back in one storage (parameters and gradients
+    flattened by models.flatten_parameters / dp.FlatGradients), which saves the copy kernel per layer and pass."""
+    t0 = ts[0]
+    adjacent = all(t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] for t in ts) and all(
+        a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+        and a.data_ptr() + a.numel() * a.element_size() == b.data_ptr() for a, b in zip(ts[:-1], ts[1:]))
+    if not adjacent:
+        return torch.cat(ts, 0)
+    rows = sum(t.shape[0] for t in ts)
+    size = (rows,) + tuple(t0.shape[1:])
+    stride = t0.stride()
+    return torch.as_strided(t0, size, stride)
+
+
 def layer_params(P: Dict[str, torch.Tensor], i: int) -> LayerParams:
     p = f"gnn.convs.{i}."
     return LayerParams(
-        W5=torch.cat([P[p + k + ".weight"] for k in LIN5], 0),
-        b5=torch.cat([P[p + k + ".bias"] for k in LIN5], 0),
+        W5=stacked([P[p + k + ".weight"] for k in LIN5]),
+        b5=stacked([P[p + k + ".bias"] for k in LIN5]),
         W3=P[p + "B_3.weight"], b3=P[p + "B_3.bias"],
         gamma_e=P[p + "bn_e.weight"], beta_e=P[p + "bn_e.bias"],
         gamma_h=P[p + "bn_h.weight"], beta_h=P[p + "bn_h.bias"])
@@ -604,40 +630,68 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     return scores, ms
 
 
+def grad_targets(out: Dict[str, torch.Tensor], i: int) -> Optional[Dict[str, torch.Tensor]]:
+    """The write-into map of layer_backward for layer i from per-parameter gradient tensors, if the five stacked
+    weights / biases are back to back (they are in dp.FlatGradients over a flattened model); else None."""
+    p = f"gnn.convs.{i}."
+    w = [out[p + k + ".weight"] for k in LIN5]
+    b = [out[p + k + ".bias"] for k in LIN5]
+    W5, b5 = stacked(w), stacked(b)
+    if W5.data_ptr() != w[0].data_ptr() or b5.data_ptr() != b[0].data_ptr():
+        return None
+    return {"W5": W5, "b5": b5, "W3": out[p + "B_3.weight"], "b3": out[p + "B_3.bias"],
+            "gamma_e": out[p + "bn_e.weight"], "beta_e": out[p + "bn_e.bias"],
+            "gamma_h": out[p + "bn_h.weight"], "beta_h": out[p + "bn_h.bias"]}
+
+
 @on_device_of(lambda graph, P, num_layers, ms, gscores, *a, **k: gscores)
-def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores, batch_norm: bool = True):
-    """Gradients of every parameter (keys = state_dict keys) from d loss / d scores."""
+def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores, batch_norm: bool = True,
+                   out: Optional[Dict[str, torch.Tensor]] = None):
+    """Gradients of every parameter (keys = state_dict keys) from d loss / d scores.  With `out` (state_dict key ->
+    contiguous tensor of the parameter's shape, e.g. the .grad views of dp.FlatGradients) the kernels write the
+    gradients straight into those tensors and the same tensors are returned."""
     dev = ms.pe.device
     idx = graph.index(dev)
     N, E = graph.num_nodes(), graph.num_edges()
     H = P["linear_pe.weight"].shape[0]
     f32 = dict(dtype=torch.float32, device=dev)
     G: Dict[str, torch.Tensor] = {}
+    tgt = (lambda k, like: out[k]) if out else (lambda k, like: torch.empty_like(like))    # noqa: E731
+    pout = {"W1": out["predictor.W1.weight"], "b1": out["predictor.W1.bias"], "W2": out["predictor.W2.weight"],
+            "b2": out["predictor.W2.bias"]} if out else None
     gh, ge, gp = predictor_backward(idx, N, E, H, P["predictor.W1.weight"], P["predictor.W2.weight"],
-                                    ms.pred, gscores)
+                                    ms.pred, gscores, pout)
     G["predictor.W1.weight"], G["predictor.W1.bias"] = gp["W1"], gp["b1"]
     G["predictor.W2.weight"], G["predictor.W2.bias"] = gp["W2"], gp["b2"]
     ms.pred = None
     for i in reversed(range(num_layers)):
         p = f"gnn.convs.{i}."
-        gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm)
+        lout = grad_targets(out, i) if out else None
+        gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout)
         ms.layers[i] = None     # release this layer's activations
         for j, k in enumerate(LIN5):
             G[p + k + ".weight"] = gl["W5"][j * H:(j + 1) * H]
             G[p + k + ".bias"] = gl["b5"][j * H:(j + 1) * H]
+        if out and lout is None:          # the caller's targets are not stacked: copy the two stacked results over
+            for j, k in enumerate(LIN5):
+                G[p + k + ".weight"] = out[p + k + ".weight"].copy_(G[p + k + ".weight"])
+                G[p + k + ".bias"] = out[p + k + ".bias"].copy_(G[p + k + ".bias"])
+            for key, name in (("W3", "B_3.weight"), ("b3", "B_3.bias"), ("gamma_e", "bn_e.weight"), ("beta_e", "bn_e.bias"),
+                              ("gamma_h", "bn_h.weight"), ("beta_h", "bn_h.bias")):
+                gl[key] = out[p + name].copy_(gl[key])
         G[p + "B_3.weight"], G[p + "B_3.bias"] = gl["W3"], gl["b3"]
         G[p + "bn_e.weight"], G[p + "bn_e.bias"] = gl["gamma_e"], gl["beta_e"]
         G[p + "bn_h.weight"], G[p + "bn_h.bias"] = gl["gamma_h"], gl["beta_h"]
     # encoders backward
     lib = _lib.load()
-    G["linear_pe.weight"] = torch.empty_like(P["linear_pe.weight"])
+    G["linear_pe.weight"] = tgt("linear_pe.weight", P["linear_pe.weight"])
     gemm(TN, gh, ms.pe, G["linear_pe.weight"])
-    G["linear_pe.bias"] = colsum(gh)
-    G["linear2_edge.weight"] = torch.empty_like(P["linear2_edge.weight"])
-    G["linear1_edge.weight"] = torch.empty_like(P["linear1_edge.weight"])
+    G["linear_pe.bias"] = colsum(gh, out["linear_pe.bias"] if out else None)
+    G["linear2_edge.weight"] = tgt("linear2_edge.weight", P["linear2_edge.weight"])
+    G["linear1_edge.weight"] = tgt("linear1_edge.weight", P["linear1_edge.weight"])
     if ms.a1 is None:      # fused encoder: every encoder gradient from one pass over ge
-        G["linear2_edge.bias"] = torch.empty_like(P["linear2_edge.bias"])
-        G["linear1_edge.bias"] = torch.empty_like(P["linear1_edge.bias"])
+        G["linear2_edge.bias"] = tgt("linear2_edge.bias", P["linear2_edge.bias"])
+        G["linear1_edge.bias"] = tgt("linear1_edge.bias", P["linear1_edge.bias"])
         need = lib.gnm_edge_encoder_bwd_workspace_bytes()
         ws = scratch(dev).ws(need)
         _call("gnm_edge_encoder_bwd", E, H, ms.e_raw.shape[1], P["linear1_edge.weight"].shape[0], _ptr(ge),
@@ -646,12 +700,12 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
               _ptr(G["linear2_edge.weight"]), _ptr(G["linear2_edge.bias"]), _ptr(ws), need, _stream())
     else:
         gemm(TN, ge, ms.a1, G["linear2_edge.weight"])
-        G["linear2_edge.bias"] = colsum(ge)
+        G["linear2_edge.bias"] = colsum(ge, out["linear2_edge.bias"] if out else None)
         ga1 = torch.empty_like(ms.a1)
         gemm(NN, ge, P["linear2_edge.weight"], ga1)
         _call("gnm_relu_mask_f32", ga1.numel(), _ptr(ga1), _ptr(ms.a1), _stream())
         gemm(TN, ga1, ms.e_int, G["linear1_edge.weight"])
-        G["linear1_edge.bias"] = colsum(ga1)
+        G["linear1_edge.bias"] = colsum(ga1, out["linear1_edge.bias"] if out else None)
     return G
 
 

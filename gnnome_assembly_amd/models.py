@@ -4,9 +4,57 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import engine, layers
+from . import dp, engine, layers
 
-__all__ = ["GraphGatedGCNModel", "BCEWithLogitsLoss"]
+__all__ = ["GraphGatedGCNModel", "BCEWithLogitsLoss", "flatten_parameters"]
+
+
+def _engine_order(names):
+    """Parameter names in the order the kernels like them in memory: per layer the five stacked projection weights
+    (A_1 A_2 A_3 B_1 B_2: one [5H,H] operand), their five biases ([5H]), then the rest; encoders and predictor last."""
+    rank = {}
+    for k in names:
+        parts = k.split(".")
+        if parts[0] == "gnn":
+            layer, mod, kind = int(parts[2]), parts[3], parts[4]
+            if mod in engine.LIN5:
+                rank[k] = (0, layer, 0 if kind == "weight" else 1, engine.LIN5.index(mod))
+            else:
+                rank[k] = (0, layer, 2, names.index(k))
+        else:
+            rank[k] = (1, 0, 0, names.index(k))
+    return sorted(names, key=lambda k: rank[k])
+
+
+def flatten_parameters(model: nn.Module) -> torch.Tensor:
+    """Move every parameter of `model` into ONE contiguous fp32 buffer (values preserved; each parameter becomes a
+    view of it) laid out in _engine_order, so that the engine takes [5H,H] / [5H] views of the stacked projection
+    parameters instead of torch.cat-ing them on every pass, and dp.FlatGradients (which follows the same order)
+    can hand the kernels gradient targets of the same shape.  Returns the buffer.  state_dict keys, optimizers
+    and load_state_dict are unaffected; model.to(device) un-flattens (the next forward flattens again)."""
+    named = dict(model.named_parameters())
+    order = _engine_order(list(named))
+    dev = next(iter(named.values())).device
+    flat = torch.empty(sum(p.numel() for p in named.values()), dtype=torch.float32, device=dev)
+    o = 0
+    with torch.no_grad():
+        for slot, k in enumerate(order):
+            p = named[k]
+            v = flat[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            p._gnm_slot = slot
+            o += p.numel()
+    model._gnm_flat = flat
+    return flat
+
+
+def _is_flat(model: nn.Module) -> bool:
+    flat = getattr(model, "_gnm_flat", None)
+    if flat is None:
+        return False
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    return all(p.device == flat.device and lo <= p.data_ptr() < hi for p in model.parameters())
 
 
 class _ModelFn(torch.autograd.Function):
@@ -20,12 +68,24 @@ class _ModelFn(torch.autograd.Function):
         P = {k: v.detach() for k, v in zip(names, flat)}
         scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need, batch_norm)
         ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L, ctx.bn = graph, saved, P, names, num_layers, batch_norm
+        ctx.params = flat if need else None
         return scores
 
     @staticmethod
     def backward(ctx, gscores):
         if ctx.saved is None:
             raise RuntimeError("GraphGatedGCNModel: backward called twice or forward ran without grad")
+        # Fast path: every .grad is a view of a dp.FlatGradients buffer that has been zeroed since its last use
+        # (the training loops call flat.zero_() before each backward) -> the kernels write the gradients straight
+        # into those views and autograd is told "no gradient": accumulating x into zeros is x, and the ~140
+        # accumulation kernels per step disappear.  Anything else takes the ordinary autograd route.
+        fg = dp.fresh_flat_gradients(ctx.params)
+        if fg is not None and all(ctx.needs_input_grad[7:]):
+            out = {k: p.grad for k, p in zip(ctx.names, ctx.params)}
+            engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores, ctx.bn, out=out)
+            fg.fresh = False
+            ctx.saved = None
+            return (None,) * (7 + len(ctx.names))
         G = engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores, ctx.bn)
         ctx.saved = None
         return (None, None, None, None, None, None, None) + tuple(G[k] for k in ctx.names)
@@ -48,7 +108,15 @@ class GraphGatedGCNModel(nn.Module):
         self.num_layers = num_layers
         self.batch_norm = bool(batch_norm)
 
+    def flatten_parameters(self) -> torch.Tensor:
+        """See models.flatten_parameters.  Call it after .to(device) and BEFORE building dp.FlatGradients so that the
+        gradient buffer follows the same layout (forward() does it on its own otherwise, but a FlatGradients made
+        earlier then keeps state_dict order and the kernels' stacked gradients are copied instead of written in place)."""
+        return flatten_parameters(self)
+
     def forward(self, graph, x, e, pe):
+        if pe.is_cuda and not _is_flat(self):
+            flatten_parameters(self)          # once per device placement: stacked-parameter views instead of torch.cat
         names, flat = zip(*self.named_parameters())
         need = torch.is_grad_enabled() and any(p.requires_grad for p in flat)
         if torch.is_grad_enabled() and (e.requires_grad or pe.requires_grad):

@@ -134,6 +134,7 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     best_state = copy.deepcopy(model.state_dict())                                              # train.py:203
+    model.flatten_parameters()
     flat = dp.FlatGradients(model.parameters())
     optimizer = torch.optim.Adam(model.parameters(), lr=hp["lr"])                               # train.py:209
     criterion = models.BCEWithLogitsLoss(pos_weight=1.0 / ratio)                                # train.py:210-211

@@ -36,6 +36,7 @@ def main():
     pw = torch.tensor([float(inp["pos_weight"])], dtype=torch.float64, device=dev)
     dist.all_reduce(pw)
     crit = G.BCEWithLogitsLoss(float(pw.item()) / world)
+    model.flatten_parameters()
     flat = dp.FlatGradients(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     flat.zero_()

@@ -789,6 +789,35 @@ def test_train_loop_matches_the_reference_loop(tmp_path, golden_dir):
     assert r <= 3e-3 and np.abs(got_all - want_all).max() <= hp["lr"]      # no element further than one Adam step
 
 
+def test_flat_gradient_fast_path_equals_autograd_accumulation():
+    """With parameters flattened (models.flatten_parameters) and a zeroed dp.FlatGradients the backward kernels write
+    every gradient straight into the flat buffer (no autograd accumulation kernels).  Same kernels, so the
+    result is bit-identical to the ordinary .grad accumulation; without zero_() in between a second backward
+    accumulates as autograd does."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import dp
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(3000, 128, 3, 4, dev)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    e, pe, y = (torch.from_numpy(inp[k]).to(dev) for k in ("e", "pe", "y"))
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    crit(model(g, None, e, pe).squeeze(-1), y).backward()                 # ordinary autograd accumulation
+    ref = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.flatten_parameters()
+    flat = dp.FlatGradients(model.parameters())
+    named = dict(model.named_parameters())
+    a = [named[f"gnn.convs.1.{k}.weight"].grad for k in ("A_1", "A_2", "A_3", "B_1", "B_2")]
+    assert all(x.data_ptr() + x.numel() * 4 == y_.data_ptr() for x, y_ in zip(a[:-1], a[1:]))   # one [5H,H] block
+    flat.zero_()
+    assert flat.fresh
+    crit(model(g, None, e, pe).squeeze(-1), y).backward()
+    assert not flat.fresh
+    assert all(torch.equal(p.grad, ref[k]) for k, p in named.items())
+    crit(model(g, None, e, pe).squeeze(-1), y).backward()                 # not zeroed: accumulates (autograd route)
+    assert all(torch.equal(p.grad, 2 * ref[k]) for k, p in named.items())
+    assert all(flat.flat.data_ptr() <= p.grad.data_ptr() < flat.flat.data_ptr() + flat.flat.numel() * 4 for p in named.values())
+
+
 def test_lean_activation_mode_is_bit_identical_and_smaller():
     """engine.set_activation_mode("lean"): P [N,5H] and t [E,H] are not kept for the backward but rebuilt by the
     kernels that made them.  Same kernels on the same inputs: logits, loss and every gradient bit-identical to
