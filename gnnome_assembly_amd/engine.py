@@ -480,7 +480,7 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     return scores, saved
 
 
-@on_device_of(lambda idx, N, E, H, W1, W2, s, gscores: gscores)
+@on_device_of(lambda idx, N, E, H, W1, W2, s, gscores, *a, **k: gscores)
 def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores, out: Optional[Dict[str, torch.Tensor]] = None):
     """Returns (gx [N,H], ge [E,H] fresh buffer, grads dict W1,b1,W2,b2); `out` as in layer_backward."""
     out = out or {}
