@@ -77,6 +77,8 @@ def op_model(op: str, N: int, E: int, H: int):
         "gnm_edge_bwd_gt": (3 * eh, 0.0),                     # ge, t in; gt out
         "gnm_edge_t_fused_fwd": (2 * eh + 2 * nh, 2.0 * E * H * H),        # e_in in, t out, B1h/B2h rows
         "gnm_edge_bwd_fused": (4 * eh, 4.0 * E * H * H),                   # ge in/out, t, e_in; NN + TN
+        # fused(i) chained with dst(i-1): ge'(i), t(i), e_out(i-1), t(i-1) in; ge'(i-1) out; node rows as edge_bwd_dst
+        "gnm_edge_bwd_chain": (5 * eh + 9 * nh, 4.0 * E * H * H),
         "gnm_node_proj_fwd": (6 * nh, 2.0 * N * H * 5 * H),                # h in, P out
         "gnm_node_proj_bwd_nn": (7 * nh, 2.0 * N * H * 5 * H),             # gP, gh_out in; gh_in out
         "gnm_node_proj_bwd_tn": (6 * nh, 2.0 * N * H * 5 * H),             # gP, h_in in
@@ -106,6 +108,7 @@ def op_model(op: str, N: int, E: int, H: int):
 TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 OP_KERNELS = {
     "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_fused_k<MmB3>", "edge_bwd_tr_k"]},
+    "gnm_edge_bwd_chain": ["edge_bwd_chain_k"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
     "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
     "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3_k"]},

@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "gnm_common.h"
+#include "gnm_tr.h"
 
 namespace gnm {
 
@@ -1480,6 +1481,45 @@ extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, co
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd: workspace too small");
   return g_matmul_mode ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
                        : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
+}
+
+namespace gnm {
+int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st);   // gnm_tr.hip
+}
+extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void);
+
+// The fused edge backward of layer i chained with the by-destination backward pass of layer i-1 (gnm.h).
+extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
+                                  const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
+                                  const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
+                                  const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
+                                  const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
+                                  const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
+                                  int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "edge_bwd_chain: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(g_matmul_mode == 1, "edge_bwd_chain: only built for the bf16x3 matmul mode");
+  GNM_CHECK_ARG(N > 0 && E > 0 && ge && ge_out && t_hi && e_mid && stat_hi && bstat_hi && gamma_hi && W3_hi && gW3_hi &&
+                    gb3_hi && partials_hi && t_lo && stat_lo && P_lo && Q_lo && hf_lo && hb_lo && isrc && idst && in_ptr &&
+                    gP_lo && Ud_lo && Td_lo && partials_lo && nblk_out && partials_hi != partials_lo,
+                "edge_bwd_chain: null / aliased argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "edge_bwd_chain: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  ChainArgs a{};
+  a.E = E; a.N = N;
+  a.ge = ge; a.ge_out = ge_out; a.t_hi = t_hi; a.e_mid = e_mid;
+  a.stat_hi = stat_hi; a.bstat_hi = bstat_hi; a.gamma_hi = gamma_hi;
+  a.slab = slab; a.partials = partials_hi;
+  a.t_lo = t_lo; a.stat_lo = stat_lo; a.P_lo = P_lo; a.Q_lo = Q_lo; a.hf_lo = hf_lo; a.hb_lo = hb_lo;
+  a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
+  a.gP_lo = gP_lo; a.Ud_lo = Ud_lo; a.Td_lo = Td_lo; a.partials_lo = partials_lo;
+  const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st);
+  GNM_LAUNCH_CHECK("edge_bwd_chain");
+  hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3_hi);
+  GNM_LAUNCH_CHECK("edge_bwd_chain slab reduce");
+  *nblk_out = grid;
+  return gnm_reduce_partials(partials_hi, grid, 1, FH, gb3_hi, stream) ? -3 : 0;
 }
 
 extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void) {

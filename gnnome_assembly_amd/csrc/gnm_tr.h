@@ -139,4 +139,18 @@ __device__ __forceinline__ void mfb16(floatx16& acc, const bf16x8& a, const bf16
 __device__ __forceinline__ constexpr int b3_pa(int t) { return t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0; }
 __device__ __forceinline__ constexpr int b3_pb(int t) { return t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0; }
 
+// arguments of edge_bwd_chain_k (gnm_tr.hip)
+struct ChainArgs {
+  int64_t E, N;
+  // layer i: gt from (ge, t_hi); gW3(i) against e_mid = e_in(i) = e_out(i-1)
+  const float* ge; float* ge_out; const float* t_hi; const float* e_mid;
+  const float* stat_hi; const float* bstat_hi; const float* gamma_hi; const bf16x8* Wp;
+  float* slab; double* partials;                     // [grid][128][128] partial gW3(i), [grid][128] column sums of gt
+  // layer i-1: by-destination backward
+  const float* t_lo; const float* stat_lo; const float* P_lo; const float* Q_lo; const float* hf_lo; const float* hb_lo;
+  const int32_t* isrc; const int32_t* idst; const int32_t* in_ptr;
+  float* gP_lo; float* Ud_lo; float* Td_lo; double* partials_lo;   // gP[:,2H:3H], [N,H], [N,H], [grid][2][128]
+  int64_t nodes_per_block;
+};
+
 }  // namespace gnm

@@ -387,6 +387,297 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
   return grid;
 }
 
+// ------------------------------------------------------------------------------------------
+// CHAINED edge backward: the fused edge backward of layer i and the by-destination backward pass of layer i-1 in
+// one sweep over the destination-sorted edge rows.
+//
+// Layer i's fused kernel ends by writing ge_in(i) = d loss / d e_out(i-1); layer i-1's by-destination pass begins
+// by reading exactly those rows, in the same order, together with e_out(i-1) -- which the fused kernel has just
+// read as e_in(i).  Run back to back they move 4 + 4 [E,H] streams; chained, the rows stay on chip:
+//     read ge'(i), t(i), e_out(i-1), t(i-1);  write ge'(i-1)            (5 streams, 3 fewer)
+// and the matrix-core work (TN + NN, what bounds the fused kernel) runs under the gather / normalise work of the
+// by-destination pass (what that pass waits on) instead of beside a half idle memory system.
+// Per 16-row tile: phases 0 / TN / NN of edge_bwd_tr_k; then each thread takes its two rows of ge(i-1) = ge'(i) +
+// gt W3 from the row image and does edge_bwd_dst_k's per-edge arithmetic (gated_gcn_full.py:122-130 backward)
+// with the node rows gathered through isrc / idst; the per-destination sums (gA3h, Ud, Td) and the BatchNorm
+// column sums of layer i-1 are taken by 256 column walkers over three [16,128] fp32 images of the per-edge
+// terms, sequentially in edge order -- no atomics, deterministic.  A workgroup owns a contiguous range of
+// destination NODES (its rows are in_ptr[v0] .. in_ptr[v1]), so every segment sum is complete inside it.
+// ------------------------------------------------------------------------------------------
+
+// One 512-thread workgroup per CU (8 waves, two per SIMD): thread (row = tid >> 5, 4 columns) owns ONE row of the
+// tile in phase 0 and in the by-destination arithmetic; wave w owns output columns 16w .. 16w+15 of gt W3 (48
+// weight-fragment registers) and the 64 x 32 block (w >> 2, w & 3) of gW3 (32 accumulator registers) -- half the
+// pinned registers of the 4-wave kernel, which leaves room for the software pipeline this kernel lives on: the
+// four row streams AND the six gathered node rows of the NEXT tile are requested a tile ahead, so that no phase
+// waits on memory (the eight waves share every barrier, there is no second workgroup to hide a wait).
+constexpr int CT = 512;                    // threads per workgroup
+constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 4 * ER * SW * 4 + 3 * 2 * ER * 4;
+
+struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
+
+__global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CH_LDS];
+  unsigned char* ig = lds;                                               // gt images
+  unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
+  float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // residual ge rows, then ge + gt W3 (row layout)
+  float* cs = og + ER * EOP;                                             // layer i:   mu, rstd, scale, shift, m1, m2, c
+  float* cl = cs + 7 * SW;                                               // layer i-1: mu, rstd, scale, shift
+  float* v1 = cl + 4 * SW;                                               // sigma * Qb[src]
+  float* v2 = v1 + ER * SW;                                              // gu
+  float* v3 = v2 + ER * SW;                                              // that
+  float* tl = v3 + ER * SW;                                              // t(i-1) rows (written and read by the same thread)
+  int* sd = reinterpret_cast<int*>(tl + ER * SW);                        // ring of 3 tiles x [src 16 | dst 16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 2, wc = wave & 3;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t v0 = (int64_t)chunk * a.nodes_per_block < a.N ? (int64_t)chunk * a.nodes_per_block : a.N;
+  const int64_t v1n = v0 + a.nodes_per_block < a.N ? v0 + a.nodes_per_block : a.N;
+  const int64_t rb = a.in_ptr[v0], re = a.in_ptr[v1n];                   // this workgroup's rows
+  const int64_t ntile = (re - rb + ER - 1) / ER;
+  const int row = tid >> 5, lc4 = (tid & 31) * 4;                        // this thread's row of every tile
+  for (int c = tid; c < SW; c += CT) {
+    cs[c] = a.stat_hi[c];
+    cs[SW + c] = a.stat_hi[SW + c];
+    cs[2 * SW + c] = a.stat_hi[2 * SW + c];
+    cs[3 * SW + c] = a.stat_hi[3 * SW + c];
+    cs[4 * SW + c] = a.bstat_hi[c];
+    cs[5 * SW + c] = a.bstat_hi[SW + c];
+    cs[6 * SW + c] = a.gamma_hi[c] * a.stat_hi[SW + c];
+    cl[c] = a.stat_lo[c];
+    cl[SW + c] = a.stat_lo[SW + c];
+    cl[2 * SW + c] = a.stat_lo[2 * SW + c];
+    cl[3 * SW + c] = a.stat_lo[3 * SW + c];
+  }
+  W3Frag16 wf;
+  {
+    const bf16x8* p = a.Wp + ((int64_t)wave * (SW / 32) * 3) * 64 + lane;
+#pragma unroll
+    for (int kc = 0; kc < SW / 32; ++kc)
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) wf.w[kc][s_] = p[(kc * 3 + s_) * 64];
+  }
+  floatx16 tn[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tn[x][e] = 0.f;
+  double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;       // column sums of gt for columns lc4 .. lc4+3
+  const int trq0 = simg_tr_base(lane, 0), trq1 = simg_tr_base(lane, 1);   // transpose-read bases (gnm_tr.h)
+  const int ni = lane & 15, ng = lane >> 4;
+  const int nnb = ni * SPITCH + ((((ni & 3) << 2) | (ng ^ (swz(ni) & 3))) << 4);
+  // column walkers: column wcol; role 0 sums sigma*Qb (-> gA3h), 1 that (-> Td), 2 gu (-> Ud), 3 the BatchNorm column
+  // sums of layer i-1 (sum gu, sum gu*that, fp64)
+  const int wcol = tid & (SW - 1), role = tid >> 7;
+  int64_t cur = v0 - 1;                     // node whose segment is being summed (v0 - 1: none yet)
+  float acc0 = 0.f;
+  double s_gu = 0.0, s_gut = 0.0;
+  float* const wout = role == 0 ? a.gP_lo + 2 * SW + wcol : role == 1 ? a.Td_lo + wcol : a.Ud_lo + wcol;
+  const int64_t wpitch = role == 0 ? 5 * SW : SW;
+  auto flush_to = [&](int64_t nxt) __attribute__((always_inline)) {      // close `cur`, zero the nodes before `nxt`
+    if (role < 3) {
+      if (cur >= v0) wout[cur * wpitch] = acc0;
+      for (int64_t v = cur + 1; v < nxt; ++v) wout[v * wpitch] = 0.f;    // nodes without in-edges
+    }
+    cur = nxt;
+    acc0 = 0.f;
+  };
+  __syncthreads();
+
+  float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
+  float4 ga2, gqb, ghb, gqf, ghf, ga3;       // the node rows of this thread's edge: A2h[s] Qb[s] hb[s] | Qf[d] hf[d] A3h[d]
+  int fs = 0, fd = 0;                        // source / destination node of this thread's row TWO tiles ahead (in flight)
+  // Software pipeline (every request is issued a full tile before its first use; sd is a ring of three tiles):
+  //   after the first barrier of tile k:   indices of tile k+2 (registers), row streams of tile k+1 (registers)
+  //   phase 0 of tile k+1:                 indices of tile k+2 -> sd ring;  rows of tile k+1 -> images
+  //   after the gather arithmetic of k+1:  node rows of tile k+2 through sd (registers, used a tile later)
+  // wave-uniform tile base + 32-bit lane offset; rows past the end of the chunk are clamped (never stored)
+  auto clamp_row = [&](int64_t k) __attribute__((always_inline)) {
+    const int64_t left = re - (rb + k * ER);                             // >= 1
+    const int nv = left < ER ? (int)left : ER;
+    return row < nv ? row : nv - 1;
+  };
+  auto prefetch_idx = [&](int64_t k) __attribute__((always_inline)) {
+    const int64_t r = rb + k * ER + clamp_row(k);
+    fs = a.isrc[r];
+    fd = a.idst[r];
+  };
+  auto prefetch_rows = [&](int64_t k) __attribute__((always_inline)) {
+    const int64_t r0 = rb + k * ER;
+    const int o = clamp_row(k) * SW + lc4;
+    pg = ld4(a.ge + r0 * SW + o);
+    pt = ld4(a.t_hi + r0 * SW + o);
+    pe_ = ld4(a.e_mid + r0 * SW + o);
+    pl = ld4_nt(a.t_lo + r0 * SW + o);
+  };
+  auto gather = [&](int64_t s, int64_t d) __attribute__((always_inline)) {   // node rows of the edge s -> d
+    ga2 = ld4(a.P_lo + s * (5 * SW) + SW + lc4);
+    gqb = ld4(a.Q_lo + s * (2 * SW) + SW + lc4);
+    ghb = ld4(a.hb_lo + s * SW + lc4);
+    gqf = ld4(a.Q_lo + d * (2 * SW) + lc4);
+    ghf = ld4(a.hf_lo + d * SW + lc4);
+    ga3 = ld4(a.P_lo + d * (5 * SW) + 2 * SW + lc4);
+  };
+
+  if (ntile > 0) {
+    prefetch_idx(0);
+    const int s0 = fs, d0 = fd;
+    if ((tid & 31) == 0) {
+      sd[row] = s0;
+      sd[ER + row] = d0;
+    }
+    if (ntile > 1) prefetch_idx(1);                 // written to the ring in phase 0 of tile 0
+    prefetch_rows(0);
+    gather(s0, d0);
+  }
+  for (int64_t k = 0; k < ntile; ++k) {
+    const int64_t r0 = rb + k * ER;
+    const int nvalid = re - r0 < ER ? (int)(re - r0) : ER;
+    const int* sdk = sd + (int)(k % 3) * 2 * ER;
+    // ---- phase 0: gt row and e row -> split images; residual ge row -> og; t(i-1) row -> tl; indices -> sd ----
+    {
+      const float4 mu = ld4(cs + lc4), rs = ld4(cs + SW + lc4), sc = ld4(cs + 2 * SW + lc4),
+                   sh = ld4(cs + 3 * SW + lc4), m1 = ld4(cs + 4 * SW + lc4), m2 = ld4(cs + 5 * SW + lc4),
+                   cc = ld4(cs + 6 * SW + lc4);
+      st4(og + row * EOP + lc4, pg);
+      st4(tl + row * SW + lc4, pl);
+      const float4 gu = gate4(fma4(pt, sc, sh), pg);
+      float4 gt = cc * (gu - m1 - ((pt - mu) * rs) * m2);
+      if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
+      cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
+      simg_stage(ig, EIMG, row, lc4, gt);
+      simg_stage(ie, EIMG, row, lc4, pe_);
+      if ((tid & 31) == 0 && k + 1 < ntile) {       // indices of tile k+1 (requested a tile ago) -> ring
+        int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
+        sdn[row] = fs;
+        sdn[ER + row] = fd;
+      }
+    }
+    __syncthreads();   // images, residual rows, the next tile's indices ready
+    if (k + 2 < ntile) prefetch_idx(k + 2);
+    if (k + 1 < ntile) prefetch_rows(k + 1);      // a tile ahead: in flight under the MFMAs and the gather arithmetic
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- TN: gW3[n][c] += sum_rows gt[row][n] e[row][c], this wave's 64 x 32 block (transpose reads) ----
+    {
+      int tr0 = trq0, tr1 = trq1;
+      asm volatile("" : "+v"(tr0), "+v"(tr1));
+      bf16x8 fa[2][3];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+          fa[x][s_] = simg_col_frag2(ig + s_ * EIMG, tr0 ^ ((2 * wn + x) << 6), tr1 ^ ((2 * wn + x) << 6));
+#pragma unroll
+      for (int sb = 0; sb < 3; ++sb) {
+        const bf16x8 fb = simg_col_frag2(ie + sb * EIMG, tr0 ^ (wc << 6), tr1 ^ (wc << 6));
+#pragma unroll
+        for (int sa = 0; sa < 3; ++sa) {
+          if (sa + sb > 2) continue;               // the three products below 2^-24 are dropped
+          mfb16(tn[0], fa[0][sa], fb);
+          mfb16(tn[1], fa[1][sa], fb);
+        }
+      }
+    }
+    // ---- NN: acc = gt W3 (16 rows x this wave's 16 columns), joined with the residual rows in og ----
+    {
+      floatx4_acc acc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < SW / 32; ++kc) {
+        bf16x8 fa[3];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) fa[s_] = *reinterpret_cast<const bf16x8*>(ig + s_ * EIMG + (nnb ^ (kc << 6)));
+        mfb16s(acc, fa[2], wf.w[kc][0]);
+        mfb16s(acc, fa[0], wf.w[kc][2]);
+        mfb16s(acc, fa[1], wf.w[kc][1]);
+        mfb16s(acc, fa[1], wf.w[kc][0]);
+        mfb16s(acc, fa[0], wf.w[kc][1]);
+        mfb16s(acc, fa[0], wf.w[kc][0]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) og[(4 * ng + e) * EOP + wave * 16 + ni] += acc[e];
+    }
+    __syncthreads();   // og = ge(i-1) rows complete; every wave is done with the gt images
+    // ---- by-destination backward of layer i-1 on this thread's row (edge_bwd_dst_k's arithmetic) ----
+    {
+      const float4 mu = ld4(cl + lc4), rs = ld4(cl + SW + lc4), sc = ld4(cl + 2 * SW + lc4), sh = ld4(cl + 3 * SW + lc4);
+      const float4 ge4 = ld4(og + row * EOP + lc4);
+      const float4 tt = ld4(tl + row * SW + lc4);
+      float4 sg, dsg;
+      sigmoid_grad4(simg_load_f32(ie, EIMG, row, lc4), sg, dsg);
+      const float4 gsig = fma4(gqf, ga2, fma4(gqb, ga3, f4(0.f) - gqf * ghf - gqb * ghb));
+      const float4 g = fma4(gsig, dsg, ge4);
+      if (row < nvalid) st4_nt(a.ge_out + (r0 + row) * SW + lc4, g);
+      st4(v1 + row * SW + lc4, sg * gqb);
+      st4(v2 + row * SW + lc4, gate4(fma4(tt, sc, sh), g));
+      st4(v3 + row * SW + lc4, (tt - mu) * rs);
+    }
+    if (k + 1 < ntile) {                           // the next tile's node rows, through the ring (written before this tile's first barrier)
+      const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
+      gather(sdn[row], sdn[ER + row]);
+    }
+    __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
+    // ---- column walkers: segment sums by destination node, BatchNorm column sums of layer i-1 ----
+    {
+      const float* vsrc = role == 0 ? v1 : role == 1 ? v3 : v2;
+      for (int r = 0; r < nvalid; ++r) {
+        const int64_t d = sdk[ER + r];
+        if (d != cur) flush_to(d);
+        const float x = vsrc[r * SW + wcol];
+        acc0 += x;
+        if (role == 3) {
+          s_gu += (double)x;
+          s_gut += (double)x * (double)v3[r * SW + wcol];
+        }
+      }
+    }
+    // no barrier: a wave reaches the next tile's post-phase-0 barrier only after its own walk, v1 - v3 are rewritten
+    // after that barrier, sd is a ring of three; what the next phase 0 writes before it (images, og, tl) was last
+    // read by the SAME thread (same row / column mapping) or before this tile's second barrier (gt images)
+  }
+  flush_to(v1n);                                   // the last segment, and trailing nodes without in-edges
+
+  float* sl = a.slab + (size_t)chunk * SW * SW;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = (2 * wn + x) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+      sl[m * SW + wc * 32 + li] = tn[x][e];
+    }
+  if (role == 3) {
+    a.partials_lo[(size_t)(chunk * 2 + 0) * SW + wcol] = s_gu;
+    a.partials_lo[(size_t)(chunk * 2 + 1) * SW + wcol] = s_gut;
+  }
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(lds);          // 16 row slots x 128 columns = 16 KB (the images are dead)
+  red[row * SW + lc4 + 0] = cg0;
+  red[row * SW + lc4 + 1] = cg1;
+  red[row * SW + lc4 + 2] = cg2;
+  red[row * SW + lc4 + 3] = cg3;
+  __syncthreads();
+  if (tid < SW) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int k = 0; k < ER; ++k) s_ += red[k * SW + tid];
+    a.partials[(size_t)chunk * SW + tid] = s_;
+  }
+}
+
+// returns the grid size (= number of gW3 slabs / partial rows of both kinds)
+int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st) {
+  hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
+  ChainArgs a = in;
+  a.Wp = (const bf16x8*)wpack;
+  const int grid = persistent_grid(a.N, 64, 1);        // one 512-thread workgroup per CU
+  a.nodes_per_block = (a.N + grid - 1) / grid;
+  hipLaunchKernelGGL(edge_bwd_chain_k, dim3(grid), dim3(CT), 0, st, a);
+  return grid;
+}
+
 int tn_tr_rows_per_tile() { return TRR; }
 int tn_tr_occupancy() { return occ_blocks<tn_tr_k>(); }
 void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* slab, double* partials,

@@ -439,6 +439,105 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     return gh_in, ge, g
 
 
+# The chained backward schedule (H = 128, BatchNorm, bf16x3 matmul mode): the fused edge backward of layer i runs in
+# ONE kernel with the by-destination pass of layer i-1 (gnm_edge_bwd_chain: 5 [E,H] streams instead of 4 + 4, the
+# matrix-core work under the gather arithmetic).  GNM_CHAIN=0 / engine.CHAIN = False goes back to layer_backward.
+CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
+
+
+def chain_eligible(H: int, batch_norm: bool) -> bool:
+    return CHAIN and FUSED and H == 128 and batch_norm and not CORUN and _lib.get_matmul_mode() == "bf16x3"
+
+
+def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tensor], L: int, saved: List[LayerSaved],
+                            gh, ge, outs: List[Optional[Dict[str, torch.Tensor]]]):
+    """Backward of the L-layer stack (layers L-1 .. 0), same arithmetic as L x layer_backward, other schedule:
+        node(L-1), dst(L-1);   then for i = L-1 .. 0:   finalize_e(i), src(i), proj(i),
+                                                         i > 0:  node(i-1), CHAIN[fused(i) + dst(i-1)]
+                                                         i = 0:  fused(0)
+    `ge` is updated in place through all layers.  Returns (gh_in of layer 0, ge_in of layer 0, [grads dict per layer]);
+    saved[i] is released as soon as layer i is done.  outs[i]: write-into targets as in layer_backward (or None)."""
+    lib = _lib.load()
+    dev = gh.device
+    sc, sc2 = scratch(dev), scratch(dev, "side")
+    st = _stream()
+    f32 = dict(dtype=torch.float32, device=dev)
+    grads: List[Dict[str, torch.Tensor]] = [dict() for _ in range(L)]
+    prms = [None] * L
+
+    def tgt(i, key, *shape):
+        o = outs[i] or {}
+        return o[key] if key in o else torch.empty(*shape, **f32)
+
+    def ensure(i):
+        if prms[i] is None:
+            prms[i] = layer_params(P, i)
+        s = saved[i]
+        if s.P is None or s.t is None:      # "lean" activations
+            s.P, s.t = _proj_and_t(idx, N, E, H, prms[i], s.h_in, s.e_in, C.c_int(0))
+        return prms[i], s
+
+    def node(i, gh_out):
+        """BatchNorm_h backward of layer i -> gP[:, 0:H] = gz, Q = Qf | Qb."""
+        prm, s = ensure(i)
+        o = outs[i] or {}
+        nblk = C.c_int(0)
+        gP = torch.empty(N, 5 * H, **f32)
+        Q = torch.empty(N, 2 * H, **f32)
+        _call("gnm_node_bwd_stats", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials), C.byref(nblk), st)
+        bstat_h, grads[i]["gamma_h"], grads[i]["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev,
+                                                                          o.get("gamma_h"), o.get("beta_h"))
+        _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
+              _ptr(gh_out), _ptr(s.inv_f), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
+        return gP, Q
+
+    need_f = lib.gnm_edge_bwd_fused_workspace_bytes()
+    need_p = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
+    i = L - 1
+    prm, s = ensure(i)
+    gP, Q = node(i, gh)
+    Ud, Td = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
+    nblk = C.c_int(0)
+    _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
+          _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+          _ptr(sc.partials), C.byref(nblk), st)
+    while True:
+        prm, s = prms[i], saved[i]
+        o = outs[i] or {}
+        g = grads[i]
+        bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, o.get("gamma_e"), o.get("beta_e"))
+        _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+              _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
+              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), st)
+        del Ud, Td, Q
+        g["W5"], g["b5"] = tgt(i, "W5", 5 * H, H), tgt(i, "b5", 5 * H)
+        gh_in = torch.empty(N, H, **f32)
+        ws = sc.ws(max(need_p, need_f))
+        _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
+        _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
+              _ptr(sc.partials), _ptr(ws), need_p, st)
+        del gP
+        gh = gh_in
+        g["W3"], g["b3"] = tgt(i, "W3", H, H), tgt(i, "b3", H)
+        if i == 0:
+            _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
+                  _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need_f, st)
+            saved[0] = None
+            break
+        j = i - 1
+        prm_j, s_j = ensure(j)
+        gP, Q = node(j, gh)
+        Ud, Td = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
+        _call("gnm_edge_bwd_chain", N, E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
+              _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc2.partials),
+              _ptr(s_j.t), _ptr(s_j.stat_e), _ptr(s_j.P), _ptr(Q), _ptr(s_j.hf), _ptr(s_j.hb),
+              _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td), _ptr(sc.partials),
+              C.byref(nblk), _ptr(ws), need_f, st)
+        saved[i] = None         # release layer i's activations
+        i = j
+    return gh, ge, grads
+
+
 # ---------------------------------------------------------------------------------------
 # predictor (score_predictor.py:12-25), split-W1 form
 # ---------------------------------------------------------------------------------------
@@ -664,11 +763,18 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     G["predictor.W1.weight"], G["predictor.W1.bias"] = gp["W1"], gp["b1"]
     G["predictor.W2.weight"], G["predictor.W2.bias"] = gp["W2"], gp["b2"]
     ms.pred = None
+    louts = [grad_targets(out, i) if out else None for i in range(num_layers)]
+    chained = None
+    if chain_eligible(H, batch_norm):
+        gh, ge, chained = layers_backward_chained(idx, N, E, H, P, num_layers, ms.layers, gh, ge, louts)
     for i in reversed(range(num_layers)):
         p = f"gnn.convs.{i}."
-        lout = grad_targets(out, i) if out else None
-        gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout)
-        ms.layers[i] = None     # release this layer's activations
+        lout = louts[i]
+        if chained is not None:
+            gl = chained[i]
+        else:
+            gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout)
+            ms.layers[i] = None     # release this layer's activations
         for j, k in enumerate(LIN5):
             G[p + k + ".weight"] = gl["W5"][j * H:(j + 1) * H]
             G[p + k + ".bias"] = gl["b5"][j * H:(j + 1) * H]

@@ -221,6 +221,19 @@ int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, c
                          double* partials, int* nblk_out, void* ws, size_t ws_bytes, void* stream);
 int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, const float* W, const float* b,
                       float* Pout, void* ws, size_t ws_bytes, void* stream);
+/* edge_bwd_chain (bf16x3 mode, H = 128): gnm_edge_bwd_fused of layer i ("hi": ge, t_hi, e_mid = e_in(i) = e_out(i-1),
+ * stat/bstat/gamma/W3 of layer i -> gW3_hi, gb3_hi) CHAINED with gnm_edge_bwd_dst of layer i-1 ("lo": t_lo, stat_lo,
+ * P_lo, Q_lo, hf_lo, hb_lo -> gP_lo[:,2H:3H], Ud_lo, Td_lo, BatchNorm partials in partials_lo, *nblk_out rows) in
+ * one sweep: ge_out (may alias ge) receives what gnm_edge_bwd_dst would have written after gnm_edge_bwd_fused, the
+ * intermediate d loss / d e_out(i-1) never leaves the chip.  partials_hi: scratch, >= gnm_max_partial_blocks()*128
+ * doubles, distinct from partials_lo.  ws as gnm_edge_bwd_fused.  autograd of gated_gcn_full.py:113,120-130      */
+int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
+                       const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
+                       const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
+                       const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
+                       const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
+                       const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
+                       int* nblk_out, void* ws, size_t ws_bytes, void* stream);
 size_t gnm_node_proj_bwd_workspace_bytes(int ncols);
 int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
                       const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,
