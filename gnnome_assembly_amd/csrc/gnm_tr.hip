@@ -471,19 +471,18 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // column walkers: column wcol; role 0 sums sigma*Qb (-> gA3h), 1 that (-> Td), 2 gu (-> Ud), 3 the BatchNorm column
   // sums of layer i-1 (sum gu, sum gu*that, fp64)
   const int wcol = tid & (SW - 1), role = tid >> 7;
-  int64_t cur = v0 - 1;                     // node whose segment is being summed (v0 - 1: none yet)
+  int64_t cur = -1;                         // node whose segment is being summed
   float acc0 = 0.f;
   double s_gu = 0.0, s_gut = 0.0;
-  float* const wout = role == 0 ? a.gP_lo + 2 * SW + wcol : role == 1 ? a.Td_lo + wcol : a.Ud_lo + wcol;
-  const int64_t wpitch = role == 0 ? 5 * SW : SW;
-  auto flush_to = [&](int64_t nxt) __attribute__((always_inline)) {      // close `cur`, zero the nodes before `nxt`
-    if (role < 3) {
-      if (cur >= v0) wout[cur * wpitch] = acc0;
-      for (int64_t v = cur + 1; v < nxt; ++v) wout[v * wpitch] = 0.f;    // nodes without in-edges
-    }
-    cur = nxt;
-    acc0 = 0.f;
-  };
+  // Every walker step STORES the running sum to its node's output row (the last store of a segment holds the
+  // whole sum; a node's ~5 stores meet in L2): no branch, so the loop body stays free of conditional memory
+  // operations and hipcc keeps COUNTED vmcnt waits for the prefetched rows (a store under a branch costs vmcnt(0)
+  // = a full drain of the software pipeline on every tile).  Role 3 stores into a slot of partials_lo that is
+  // rewritten at the end.  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
+  float* const wout = role == 0 ? a.gP_lo + 2 * SW + wcol : role == 1 ? a.Td_lo + wcol : role == 2 ? a.Ud_lo + wcol
+                      : reinterpret_cast<float*>(a.partials_lo + (size_t)chunk * 2 * SW) + wcol;
+  const int64_t wpitch = role == 0 ? 5 * SW : role == 3 ? 0 : SW;
+  float* const dummy_row = a.slab + (size_t)chunk * SW * SW + lc4;     // target of the stores of rows past the chunk
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
@@ -494,6 +493,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   //   phase 0 of tile k+1:                 indices of tile k+2 -> sd ring;  rows of tile k+1 -> images
   //   after the gather arithmetic of k+1:  node rows of tile k+2 through sd (registers, used a tile later)
   // wave-uniform tile base + 32-bit lane offset; rows past the end of the chunk are clamped (never stored)
+  const int64_t klast = ntile - 1;
   auto clamp_row = [&](int64_t k) __attribute__((always_inline)) {
     const int64_t left = re - (rb + k * ER);                             // >= 1
     const int nv = left < ER ? (int)left : ER;
@@ -528,9 +528,16 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       sd[row] = s0;
       sd[ER + row] = d0;
     }
-    if (ntile > 1) prefetch_idx(1);                 // written to the ring in phase 0 of tile 0
+    prefetch_idx(klast < 1 ? klast : 1);            // written to the ring in phase 0 of tile 0
     prefetch_rows(0);
+    // hipcc merges the vector-memory scoreboard of the loop entry with the back edge's and keeps the weaker
+    // guarantee.  Throw-away stores (into this workgroup's slab, rewritten at the end) give the entry the queue a
+    // steady-state iteration leaves behind -- row loads | 1 store | 6 gathers | 16 walker stores -- so that phase 0
+    // waits with a COUNTED vmcnt for the row loads only and the gathers / stores stay in flight.
+    st4(dummy_row, f4(0.f));
     gather(s0, d0);
+#pragma unroll
+    for (int r = 0; r < ER; ++r) dummy_row[SW * (1 + r)] = 0.f;
   }
   for (int64_t k = 0; k < ntile; ++k) {
     const int64_t r0 = rb + k * ER;
@@ -549,15 +556,17 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
       simg_stage(ig, EIMG, row, lc4, gt);
       simg_stage(ie, EIMG, row, lc4, pe_);
-      if ((tid & 31) == 0 && k + 1 < ntile) {       // indices of tile k+1 (requested a tile ago) -> ring
+      if ((tid & 31) == 0) {                        // indices of tile k+1 (requested a tile ago) -> ring
         int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
         sdn[row] = fs;
         sdn[ER + row] = fd;
       }
     }
     __syncthreads();   // images, residual rows, the next tile's indices ready
-    if (k + 2 < ntile) prefetch_idx(k + 2);
-    if (k + 1 < ntile) prefetch_rows(k + 1);      // a tile ahead: in flight under the MFMAs and the gather arithmetic
+    // a tile (two for the indices) ahead, in flight under the MFMAs and the gather arithmetic; past the end the
+    // last tile is requested again instead of branching around the loads
+    prefetch_idx(k + 2 < klast ? k + 2 : klast);
+    prefetch_rows(k + 1 < klast ? k + 1 : klast);
     __builtin_amdgcn_sched_barrier(0);
     // ---- TN: gW3[n][c] += sum_rows gt[row][n] e[row][c], this wave's 64 x 32 block (transpose reads) ----
     {
@@ -610,27 +619,36 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       sigmoid_grad4(simg_load_f32(ie, EIMG, row, lc4), sg, dsg);
       const float4 gsig = fma4(gqf, ga2, fma4(gqb, ga3, f4(0.f) - gqf * ghf - gqb * ghb));
       const float4 g = fma4(gsig, dsg, ge4);
-      if (row < nvalid) st4_nt(a.ge_out + (r0 + row) * SW + lc4, g);
+      st4_nt(row < nvalid ? a.ge_out + (r0 + row) * SW + lc4 : dummy_row, g);
       st4(v1 + row * SW + lc4, sg * gqb);
       st4(v2 + row * SW + lc4, gate4(fma4(tt, sc, sh), g));
       st4(v3 + row * SW + lc4, (tt - mu) * rs);
     }
-    if (k + 1 < ntile) {                           // the next tile's node rows, through the ring (written before this tile's first barrier)
+    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
     }
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
     // ---- column walkers: segment sums by destination node, BatchNorm column sums of layer i-1 ----
     {
-      const float* vsrc = role == 0 ? v1 : role == 1 ? v3 : v2;
-      for (int r = 0; r < nvalid; ++r) {
-        const int64_t d = sdk[ER + r];
-        if (d != cur) flush_to(d);
-        const float x = vsrc[r * SW + wcol];
-        acc0 += x;
-        if (role == 3) {
+      const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wcol;
+      int dn[ER];
+      float xs[ER], ts[ER];
+#pragma unroll
+      for (int r = 0; r < ER; ++r) {                // all LDS reads up front (a dependent read per step cost ~2000 cycles a tile)
+        dn[r] = sdk[ER + r];
+        xs[r] = vsrc[r * SW];
+        ts[r] = v3[r * SW + wcol];
+      }
+#pragma unroll
+      for (int r = 0; r < ER; ++r) {
+        const float x = r < nvalid ? xs[r] : 0.f;   // rows past the chunk repeat its last row's indices: they add nothing
+        acc0 = (dn[r] != cur ? 0.f : acc0) + x;
+        cur = dn[r];
+        wout[cur * wpitch] = acc0;
+        if (role == 3) {                              // wave-uniform, no memory operation inside
           s_gu += (double)x;
-          s_gut += (double)x * (double)v3[r * SW + wcol];
+          s_gut += (double)x * (double)ts[r];
         }
       }
     }
@@ -638,7 +656,6 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     // after that barrier, sd is a ring of three; what the next phase 0 writes before it (images, og, tl) was last
     // read by the SAME thread (same row / column mapping) or before this tile's second barrier (gt images)
   }
-  flush_to(v1n);                                   // the last segment, and trailing nodes without in-edges
 
   float* sl = a.slab + (size_t)chunk * SW * SW;
 #pragma unroll
@@ -667,6 +684,32 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   }
 }
 
+// gA3h / Ud / Td rows of the nodes WITHOUT in-edges (the column walkers only ever store to nodes that own rows)
+__global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const int32_t* __restrict__ in_ptr,
+                                                             float* __restrict__ gP, float* __restrict__ Ud,
+                                                             float* __restrict__ Td) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int64_t stride = (int64_t)gridDim.x * 4 * 64;
+  for (int64_t base = wave0; base < N; base += stride) {
+    const int64_t v = base + lane;
+    const bool empty = v < N && in_ptr[v + 1] == in_ptr[v];
+    unsigned long long m = __ballot(empty);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int64_t u = base + b;
+      const int c4 = (lane & 31) * 4;
+      if (lane < 32) {
+        st4(gP + u * (5 * SW) + 2 * SW + c4, f4(0.f));
+        st4(Td + u * SW + c4, f4(0.f));
+      } else {
+        st4(Ud + u * SW + c4, f4(0.f));
+      }
+    }
+  }
+}
+
 // returns the grid size (= number of gW3 slabs / partial rows of both kinds)
 int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st) {
   hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
@@ -674,6 +717,7 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   a.Wp = (const bf16x8*)wpack;
   const int grid = persistent_grid(a.N, 64, 1);        // one 512-thread workgroup per CU
   a.nodes_per_block = (a.N + grid - 1) / grid;
+  hipLaunchKernelGGL(zero_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo);
   hipLaunchKernelGGL(edge_bwd_chain_k, dim3(grid), dim3(CT), 0, st, a);
   return grid;
 }

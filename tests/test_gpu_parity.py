@@ -853,7 +853,8 @@ def test_lean_activation_mode_is_bit_identical_and_smaller():
     assert torch.equal(s0, s1) and l0 == l1 and all(torch.equal(g0[k], g1[k]) for k in g0)
     unit = 4.0 * src.size * 128
     print(f"peak memory of one training step: saved {p0 / unit:.1f} [E,H] units, lean {p1 / unit:.1f}")
-    assert p1 < p0 - 6 * 1.5 * unit          # ~2 units per layer (t, and P = 5N/E units), 6 layers, with slack
+    assert p1 < p0 - 6 * 1.0 * unit          # ~2 units per layer (t, and P = 5N/E units), 6 layers; the backward rebuilds
+                                             # them for at most two layers at a time
 
 
 @pytest.mark.default_mode_only
