@@ -2,6 +2,8 @@
 //
 //   tn_tr_k     weight gradient of a Linear whose input is 128 wide:  gW[cg] = A[:, cg]^T B,  gb[cg] = sum A[:, cg]
 //               (autograd of gated_gcn_full.py:107-112 and of the predictor's node halves, score_predictor.py:13-17)
+#include <stdlib.h>
+
 #include "gnm_tr.h"
 
 namespace gnm {
@@ -416,6 +418,8 @@ constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 4 * E
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
 
+// ABL (timing experiments only, results wrong when non-zero): bit 0 no column walk, bit 1 no gather arithmetic, bit 2 no MFMAs
+template <int ABL>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CH_LDS];
   unsigned char* ig = lds;                                               // gt images
@@ -470,18 +474,20 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   const int nnb = ni * SPITCH + ((((ni & 3) << 2) | (ng ^ (swz(ni) & 3))) << 4);
   // column walkers: column wcol; role 0 sums sigma*Qb (-> gA3h), 1 that (-> Td), 2 gu (-> Ud), 3 the BatchNorm column
   // sums of layer i-1 (sum gu, sum gu*that, fp64)
-  const int wcol = tid & (SW - 1), role = tid >> 7;
+  // column walkers: threads 0-95 (waves 0 and 1), one float4 of columns each; role = tid >> 5: 0 sums sigma*Qb
+  // (-> gA3h), 1 that (-> Td), 2 gu (-> Ud).  The BatchNorm column sums of layer i-1 (sum gu, sum gu*that, fp64:
+  // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
+  const bool walker = tid < 96, bnsum = tid >= 128 && tid < 256;
+  const int role = (tid >> 5) & 3, wc4 = (tid & 31) * 4;
   int64_t cur = -1;                         // node whose segment is being summed
-  float acc0 = 0.f;
-  double s_gu = 0.0, s_gut = 0.0;
+  float4 acc0 = f4(0.f);
+  double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};
   // Every walker step STORES the running sum to its node's output row (the last store of a segment holds the
-  // whole sum; a node's ~5 stores meet in L2): no branch, so the loop body stays free of conditional memory
-  // operations and hipcc keeps COUNTED vmcnt waits for the prefetched rows (a store under a branch costs vmcnt(0)
-  // = a full drain of the software pipeline on every tile).  Role 3 stores into a slot of partials_lo that is
-  // rewritten at the end.  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
-  float* const wout = role == 0 ? a.gP_lo + 2 * SW + wcol : role == 1 ? a.Td_lo + wcol : role == 2 ? a.Ud_lo + wcol
-                      : reinterpret_cast<float*>(a.partials_lo + (size_t)chunk * 2 * SW) + wcol;
-  const int64_t wpitch = role == 0 ? 5 * SW : role == 3 ? 0 : SW;
+  // whole sum; a node's ~5 stores meet in L2): no data-dependent branch around a memory operation, so hipcc keeps
+  // COUNTED vmcnt waits for the prefetched rows (a store under such a branch costs vmcnt(0) = a full drain of the
+  // software pipeline on every tile).  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
+  float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
+  const int64_t wpitch = role == 0 ? 5 * SW : SW;
   float* const dummy_row = a.slab + (size_t)chunk * SW * SW + lc4;     // target of the stores of rows past the chunk
   __syncthreads();
 
@@ -532,12 +538,14 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     prefetch_rows(0);
     // hipcc merges the vector-memory scoreboard of the loop entry with the back edge's and keeps the weaker
     // guarantee.  Throw-away stores (into this workgroup's slab, rewritten at the end) give the entry the queue a
-    // steady-state iteration leaves behind -- row loads | 1 store | 6 gathers | 16 walker stores -- so that phase 0
+    // steady-state iteration leaves behind -- row loads | 1 store | 16 walker stores (threads 0-95) | 6 gathers -- so that phase 0
     // waits with a COUNTED vmcnt for the row loads only and the gathers / stores stay in flight.
     st4(dummy_row, f4(0.f));
-    gather(s0, d0);
+    if (walker) {
 #pragma unroll
-    for (int r = 0; r < ER; ++r) dummy_row[SW * (1 + r)] = 0.f;
+      for (int r = 0; r < ER; ++r) st4(dummy_row + SW * (1 + r), f4(0.f));
+    }
+    gather(s0, d0);
   }
   for (int64_t k = 0; k < ntile; ++k) {
     const int64_t r0 = rb + k * ER;
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     prefetch_rows(k + 1 < klast ? k + 1 : klast);
     __builtin_amdgcn_sched_barrier(0);
     // ---- TN: gW3[n][c] += sum_rows gt[row][n] e[row][c], this wave's 64 x 32 block (transpose reads) ----
-    {
+    if (!(ABL & 4)) {
       int tr0 = trq0, tr1 = trq1;
       asm volatile("" : "+v"(tr0), "+v"(tr1));
       bf16x8 fa[2][3];
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       }
     }
     // ---- NN: acc = gt W3 (16 rows x this wave's 16 columns), joined with the residual rows in og ----
-    {
+    if (!(ABL & 4)) {
       floatx4_acc acc;
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] = 0.f;
@@ -615,8 +623,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       const float4 mu = ld4(cl + lc4), rs = ld4(cl + SW + lc4), sc = ld4(cl + 2 * SW + lc4), sh = ld4(cl + 3 * SW + lc4);
       const float4 ge4 = ld4(og + row * EOP + lc4);
       const float4 tt = ld4(tl + row * SW + lc4);
-      float4 sg, dsg;
-      sigmoid_grad4(simg_load_f32(ie, EIMG, row, lc4), sg, dsg);
+      float4 sg = ge4, dsg = tt;
+      if (!(ABL & 2)) sigmoid_grad4(simg_load_f32(ie, EIMG, row, lc4), sg, dsg);
       const float4 gsig = fma4(gqf, ga2, fma4(gqb, ga3, f4(0.f) - gqf * ghf - gqb * ghb));
       const float4 g = fma4(gsig, dsg, ge4);
       st4_nt(row < nvalid ? a.ge_out + (r0 + row) * SW + lc4 : dummy_row, g);
@@ -624,33 +632,44 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       st4(v2 + row * SW + lc4, gate4(fma4(tt, sc, sh), g));
       st4(v3 + row * SW + lc4, (tt - mu) * rs);
     }
+    __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
+    // ---- column walkers (waves 0 and 1) and BatchNorm sums (waves 2 and 3); the rest go on to the next phase 0 ----
+    if (!(ABL & 1) && walker) {
+      const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4;
+#pragma unroll
+      for (int r4 = 0; r4 < ER; r4 += 4) {          // four rows' LDS reads up front, then the dependent chain
+        int dn[4];
+        float4 xs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dn[q] = sdk[ER + r4 + q];
+          xs[q] = ld4(vsrc + (r4 + q) * SW);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // rows past the chunk repeat its last row's indices and add nothing
+          const float4 x = r4 + q < nvalid ? xs[q] : f4(0.f);
+          acc0 = (dn[q] != cur ? f4(0.f) : acc0) + x;
+          cur = dn[q];
+          st4(wout + cur * wpitch, acc0);
+        }
+      }
+    }
+    if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only
+      const int rg = 4 * role;                       // rows rg .. rg+3 of the tile
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 x = ld4(v2 + (rg + q) * SW + wc4);
+        const float4 th = ld4(v3 + (rg + q) * SW + wc4);
+        if (rg + q >= nvalid) x = f4(0.f);
+        s_gu[0] += (double)x.x; s_gu[1] += (double)x.y; s_gu[2] += (double)x.z; s_gu[3] += (double)x.w;
+        s_gut[0] += (double)x.x * (double)th.x; s_gut[1] += (double)x.y * (double)th.y;
+        s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
+      }
+    }
     {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
-    }
-    __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
-    // ---- column walkers: segment sums by destination node, BatchNorm column sums of layer i-1 ----
-    {
-      const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wcol;
-      int dn[ER];
-      float xs[ER], ts[ER];
-#pragma unroll
-      for (int r = 0; r < ER; ++r) {                // all LDS reads up front (a dependent read per step cost ~2000 cycles a tile)
-        dn[r] = sdk[ER + r];
-        xs[r] = vsrc[r * SW];
-        ts[r] = v3[r * SW + wcol];
-      }
-#pragma unroll
-      for (int r = 0; r < ER; ++r) {
-        const float x = r < nvalid ? xs[r] : 0.f;   // rows past the chunk repeat its last row's indices: they add nothing
-        acc0 = (dn[r] != cur ? 0.f : acc0) + x;
-        cur = dn[r];
-        wout[cur * wpitch] = acc0;
-        if (role == 3) {                              // wave-uniform, no memory operation inside
-          s_gu += (double)x;
-          s_gut += (double)x * (double)ts[r];
-        }
-      }
     }
     // no barrier: a wave reaches the next tile's post-phase-0 barrier only after its own walk, v1 - v3 are rewritten
     // after that barrier, sd is a ring of three; what the next phase 0 writes before it (images, og, tl) was last
@@ -665,11 +684,21 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       const int m = (2 * wn + x) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
       sl[m * SW + wc * 32 + li] = tn[x][e];
     }
-  if (role == 3) {
-    a.partials_lo[(size_t)(chunk * 2 + 0) * SW + wcol] = s_gu;
-    a.partials_lo[(size_t)(chunk * 2 + 1) * SW + wcol] = s_gut;
-  }
   __syncthreads();
+  {   // BatchNorm column sums of layer i-1: four row groups (threads 128-255) -> one row of partials_lo each
+    double* bnr = reinterpret_cast<double*>(lds);      // [4 groups][2][128] doubles = 8 KB (the images are dead)
+    if (bnsum) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bnr[(role * 2 + 0) * SW + wc4 + j] = s_gu[j];
+        bnr[(role * 2 + 1) * SW + wc4 + j] = s_gut[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * SW)
+      a.partials_lo[(size_t)chunk * 2 * SW + tid] = (bnr[tid] + bnr[2 * SW + tid]) + (bnr[4 * SW + tid] + bnr[6 * SW + tid]);
+    __syncthreads();
+  }
   double* red = reinterpret_cast<double*>(lds);          // 16 row slots x 128 columns = 16 KB (the images are dead)
   red[row * SW + lc4 + 0] = cg0;
   red[row * SW + lc4 + 1] = cg1;
@@ -718,7 +747,14 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   const int grid = persistent_grid(a.N, 64, 1);        // one 512-thread workgroup per CU
   a.nodes_per_block = (a.N + grid - 1) / grid;
   hipLaunchKernelGGL(zero_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo);
-  hipLaunchKernelGGL(edge_bwd_chain_k, dim3(grid), dim3(CT), 0, st, a);
+  static const int abl = getenv("GNM_CHAIN_ABL") ? atoi(getenv("GNM_CHAIN_ABL")) : 0;     // timing experiments only
+  switch (abl) {
+    case 1: hipLaunchKernelGGL(edge_bwd_chain_k<1>, dim3(grid), dim3(CT), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(edge_bwd_chain_k<2>, dim3(grid), dim3(CT), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(edge_bwd_chain_k<4>, dim3(grid), dim3(CT), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(edge_bwd_chain_k<7>, dim3(grid), dim3(CT), 0, st, a); break;
+    default: hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);
+  }
   return grid;
 }
 
