@@ -35,9 +35,20 @@ __global__ __launch_bounds__(kBlock) void edge_encoder_fwd_k(int64_t E, const fl
 #pragma unroll
   for (int q = 0; q < EQ; ++q) { w1a[q] = W1[2 * q]; w1b[q] = W1[2 * q + 1]; bq[q] = b1[q]; }
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * 2;
-  for (int64_t j = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 2 + sub; j < E; j += stride) {
-    const int64_t k = perm[j];
-    const float x0 = e_raw[2 * k], x1 = e_raw[2 * k + 1];
+  // The row's two features come through a dependent pair of loads (perm[j], then e_raw[perm[j]]): ~2 memory
+  // latencies per iteration with nothing to overlap them was what bounded this kernel (1.5 ms for one [E,H]
+  // write).  Software pipeline: the index two iterations ahead and the features one iteration ahead are in flight
+  // under the arithmetic (clamped, branch-free).
+  const int64_t Elast = E - 1;
+  const int64_t j0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 2 + sub;
+  auto clampj = [&](int64_t j) __attribute__((always_inline)) { return j < Elast ? j : Elast; };
+  int64_t kn = perm[clampj(j0)];
+  float2 xn = *reinterpret_cast<const float2*>(e_raw + 2 * kn);
+  kn = perm[clampj(j0 + stride)];
+  for (int64_t j = j0; j < E; j += stride) {
+    const float x0 = xn.x, x1 = xn.y;
+    xn = *reinterpret_cast<const float2*>(e_raw + 2 * kn);
+    kn = perm[clampj(j + 2 * stride)];
     float o0 = bb.x, o1 = bb.y, o2 = bb.z, o3 = bb.w;
 #pragma unroll
     for (int q = 0; q < EQ; ++q) {
@@ -77,10 +88,20 @@ __global__ __launch_bounds__(kBlock) void edge_encoder_bwd_k(int64_t E, const fl
   float gb2_0 = 0.f, gb2_1 = 0.f, gb2_2 = 0.f, gb2_3 = 0.f, gw1_0 = 0.f, gw1_1 = 0.f, gb1_ = 0.f;
   const int q0 = (lr >> 1) & 15;     // the hidden unit this lane owns after the reduce-scatter
   const bool bit4 = lr & 16, bit3 = lr & 8, bit2 = lr & 4, bit1 = lr & 2;
-  for (int64_t j = r0 + wave * 2 + sub; j < r1; j += kWavesPerBlock * 2) {
-    const int64_t k = perm[j];
-    const float x0 = e_raw[2 * k], x1 = e_raw[2 * k + 1];
-    const float4 g = ld4(ge0 + j * EH + c4);
+  // software pipeline as in the forward kernel: index two iterations ahead, features and the gradient row one ahead
+  const int64_t Elast = E - 1;
+  const int64_t j0 = r0 + wave * 2 + sub;
+  auto clampj = [&](int64_t j) __attribute__((always_inline)) { return j < Elast ? j : Elast; };
+  int64_t kn = perm[clampj(j0)];
+  float2 xn = *reinterpret_cast<const float2*>(e_raw + 2 * kn);
+  float4 gn = ld4(ge0 + clampj(j0) * EH + c4);
+  kn = perm[clampj(j0 + kWavesPerBlock * 2)];
+  for (int64_t j = j0; j < r1; j += kWavesPerBlock * 2) {
+    const float x0 = xn.x, x1 = xn.y;
+    const float4 g = gn;
+    xn = *reinterpret_cast<const float2*>(e_raw + 2 * kn);
+    gn = ld4(ge0 + clampj(j + kWavesPerBlock * 2) * EH + c4);
+    kn = perm[clampj(j + 2 * kWavesPerBlock * 2)];
     float p[EQ];
     float apre_q0 = 0.f;
 #pragma unroll

@@ -13,6 +13,8 @@ for c, key, nk in (("FETCH_SIZE", "fetch_kib", "n_f"), ("WRITE_SIZE", "write_kib
         if r["Counter_Name"] != c:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void gnm::", "").replace("gnm::", "")
+        if k.startswith("edge_bwd_chain_k"):
+            k = "edge_bwd_chain_k"
         res[k][key] += float(r["Counter_Value"])
         res[k][nk] += 1
 table = {}
@@ -22,9 +24,11 @@ for k, v in res.items():
     f = 2.0 * v["fetch_kib"] * 1024 / v["n_f"]     # gfx950: FETCH_SIZE counts 64 B per 128-B request
     w = v["write_kib"] * 1024 / v["n_w"]
     table[k] = {"fetch_gb": f / 1e9, "write_gb": w / 1e9, "total_gb": (f + w) / 1e9, "launches": v["n_f"]}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py "
-                     "(one layer fwd+bwd, E=7540278, N=1500000, H=128); FETCH_SIZE doubled (gfx950)",
-           "workload": {"edges": 7540278, "nodes": 1500000, "hidden": 128},   # microbench defaults (R=750k, seed 0)
+commit = sys.argv[3] if len(sys.argv) > 3 else "unknown"
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/collect_traffic.sh) on one bench.py "
+                     "step (E=7540278, N=1500000, H=128, L=8, bf16x3 matmul mode); FETCH_SIZE doubled (gfx950)",
+           "commit": commit,
+           "workload": {"edges": 7540278, "nodes": 1500000, "hidden": 128, "matmul": "bf16x3"},   # bench.py defaults (R=750k, seed 0)
            "per_launch": table}, open(out, "w"), indent=1, sort_keys=True)
 for k, v in sorted(table.items(), key=lambda kv: -kv[1]["total_gb"])[:20]:
     print(f"{k:40s} fetch={v['fetch_gb']:7.2f} GB write={v['write_gb']:7.2f} GB total={v['total_gb']:7.2f} GB")
