@@ -1579,8 +1579,7 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
   const bool tr = g_matmul_mode && g_tn_variant == 1;
   const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : g_matmul_mode ? TR3 : FTR);
   const int occ = tr ? tn_tr_occupancy() : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
-  const int cap_ = occupancy_cap();                 // gnm_set_occupancy_cap: leave room for a co-running kernel
-  int nslot = (num_cus() * (cap_ > 0 && occ > cap_ ? cap_ : occ)) / ncg;
+  int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
   nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)

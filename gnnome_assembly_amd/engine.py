@@ -443,10 +443,6 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
 # ONE kernel with the by-destination pass of layer i-1 (gnm_edge_bwd_chain: 5 [E,H] streams instead of 4 + 4, the
 # matrix-core work under the gather arithmetic).  GNM_CHAIN=0 / engine.CHAIN = False goes back to layer_backward.
 CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
-# Inside that schedule: the weight-gradient kernel of the node projections (gW5 = gP^T h_in, matrix-core bound, 2.4 TB/s
-# of HBM) has no consumer before the optimizer step, so it runs on a side stream, capped at two workgroups per CU,
-# BESIDE the next layer's node backward / chained edge kernel / by-source pass (HBM bound, matrix cores idle).
-TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
@@ -497,9 +493,6 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
 
     need_f = lib.gnm_edge_bwd_fused_workspace_bytes()
     need_p = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
-    side = _side_stream(dev) if (TN_SIDE and _prof is None) else None
-    main = torch.cuda.current_stream()
-    held: List[torch.Tensor] = []
     i = L - 1
     prm, s = ensure(i)
     gP, Q = node(i, gh)
@@ -521,21 +514,8 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
         gh_in = torch.empty(N, H, **f32)
         ws = sc.ws(max(need_p, need_f))
         _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
-        if side is not None:
-            main.wait_stream(side)                  # the previous layer's TN is done with ITS gP / scratch
-            held.clear()
-            side.wait_stream(main)                  # gP complete (by-source pass)
-            held.extend((gP, s.h_in))               # alive until the side stream is done with them
-            sc3 = scratch(dev, "tn")                # its own scratch: sc2 serves the chained kernel on the main stream
-            ws3 = sc3.ws(need_p)
-            lib.gnm_set_occupancy_cap(2)
-            _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
-                                                _ptr(sc3.partials), _ptr(ws3), need_p, C.c_void_p(side.cuda_stream)),
-                       "gnm_node_proj_bwd_tn")
-            lib.gnm_set_occupancy_cap(0)
-        else:
-            _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
-                  _ptr(sc.partials), _ptr(ws), need_p, st)
+        _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
+              _ptr(sc.partials), _ptr(ws), need_p, st)
         del gP
         gh = gh_in
         g["W3"], g["b3"] = tgt(i, "W3", H, H), tgt(i, "b3", H)
@@ -543,9 +523,6 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need_f, st)
             saved[0] = None
-            if side is not None:
-                main.wait_stream(side)
-                held.clear()
             break
         j = i - 1
         prm_j, s_j = ensure(j)
@@ -557,8 +534,6 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
               _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td), _ptr(sc.partials),
               C.byref(nblk), _ptr(ws), need_f, st)
         saved[i] = None         # release layer i's activations
-        if ACTIVATIONS == "lean":
-            s_j.P = None        # rebuilt for the by-destination pass only; nothing after it reads P
         i = j
     return gh, ge, grads
 
