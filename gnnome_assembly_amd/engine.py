@@ -534,6 +534,8 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
               _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td), _ptr(sc.partials),
               C.byref(nblk), _ptr(ws), need_f, st)
         saved[i] = None         # release layer i's activations
+        if ACTIVATIONS == "lean":
+            s_j.P = None        # rebuilt for the by-destination pass only; nothing after it reads P
         i = j
     return gh, ge, grads
 
