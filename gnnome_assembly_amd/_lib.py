@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnm.so")
+LIB_PATH = os.environ.get("GNM_LIBRARY") or os.path.join(_HERE, "libgnm.so")   # GNM_LIBRARY: A/B against another build (tools)
 
 _lib = None
 

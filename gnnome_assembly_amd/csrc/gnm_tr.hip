@@ -488,7 +488,9 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // software pipeline on every tile).  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
   float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
   const int64_t wpitch = role == 0 ? 5 * SW : SW;
-  float* const dummy_row = a.slab + (size_t)chunk * SW * SW + lc4;     // target of the stores of rows past the chunk
+  // target of the throw-away stores (rows past the chunk, scoreboard equalisation): a slab of its own BEHIND the
+  // gridDim.x slabs that carry results -- a late throw-away store must never meet this workgroup's final slab store
+  float* const dummy_row = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + lc4;
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
@@ -660,8 +662,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 x = ld4(v2 + (rg + q) * SW + wc4);
-        const float4 th = ld4(v3 + (rg + q) * SW + wc4);
-        if (rg + q >= nvalid) x = f4(0.f);
+        float4 th = ld4(v3 + (rg + q) * SW + wc4);
+        if (rg + q >= nvalid) { x = f4(0.f); th = f4(0.f); }     // replaced, never multiplied by zero (0 * NaN)
         s_gu[0] += (double)x.x; s_gu[1] += (double)x.y; s_gu[2] += (double)x.z; s_gu[3] += (double)x.w;
         s_gut[0] += (double)x.x * (double)th.x; s_gut[1] += (double)x.y * (double)th.y;
         s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
