@@ -342,9 +342,9 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
 
   if (tb0 < tb1) prefetch(tb0);
   // throw-away stores behind the first prefetch make the loop-entry scoreboard equal to the back edge's (counted
-  // vmcnt instead of vmcnt(0): see edge_bwd_fused_k in gnm_fused.hip); the slab is rewritten at the end
+  // vmcnt instead of vmcnt(0): see edge_bwd_fused_k in gnm_fused.hip), into a slab behind the gridDim.x result slabs
 #pragma unroll
-  for (int it = 0; it < 2; ++it) st4(slab + (size_t)chunk * SW * SW + (lrow + 8 * it) * SW + lc4, f4(0.f));
+  for (int it = 0; it < 2; ++it) st4(slab + (size_t)(gridDim.x + chunk) * SW * SW + (lrow + 8 * it) * SW + lc4, f4(0.f));
   for (int64_t tile = tb0; tile < nfull; ++tile) body(tile_tag<true>{}, tile);
   if (nfull < tb1 && nfull >= tb0) body(tile_tag<false>{}, nfull);
 
