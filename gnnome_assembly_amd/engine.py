@@ -501,6 +501,8 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
           _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
           _ptr(sc.partials), C.byref(nblk), st)
+    if ACTIVATIONS == "lean":
+        s.P = None              # as below: only the by-destination pass reads the rebuilt P
     while True:
         prm, s = prms[i], saved[i]
         o = outs[i] or {}
