@@ -1132,6 +1132,114 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// General row GEMM in split mode (the hidden sizes the fused 128-wide kernels are not built for, e.g. the reference's
+// own default 256):  Y[r][cls*128 + c] = sum_cg X[r][cg*128 + k] Wblk[cls][cg][k][c]  (+ bias, + R, relu)
+// with K = ncg * 128 and N = ncls * 128.  The kernel above with an output-column class per workgroup: the ncls
+// workgroups of a row chunk sit on one XCD (workgroup b runs on XCD b % 8) and read the same X rows through its L2.
+// R may be Y (ge = ge + gt W3 in place): a thread reads its R elements before it stores the same Y elements.
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kBlock, 2) void gemm_rows_b3_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, int ncls, const void* __restrict__ Wp,
+    const float* __restrict__ bias, const float* R, int64_t ldr, int relu, float* Y, int64_t ldy, int nchunk,
+    int64_t groups_per_chunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);
+  static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;
+  const int cls = jj % ncls, chunk = xcd * (nchunk / kXcds) + jj / ncls;
+  const int64_t ngroups = (M + NR3 * T - 1) / (NR3 * T);
+  const int64_t g0 = (int64_t)chunk * groups_per_chunk;
+  const int64_t g1 = min(ngroups, g0 + groups_per_chunk);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  float4 pre[T][4];
+  auto prefetch = [&](float4 (&buf)[4], int64_t g, int cg, int tl) __attribute__((always_inline)) {
+    if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
+    const int64_t r0 = (g * T + tl) * NR3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  if (g0 < g1) {
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) prefetch(pre[tl], g0, 0, tl);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t t0 = g * T;
+    floatx16 acc[T];
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
+    for (int cg = 0; cg < ncg; ++cg) {
+      MmB3::Frag wf;
+      MmB3::load_w(wf, Wp, (cls * ncg + cg) * 4 + wave, lane);
+#pragma unroll
+      for (int tl = 0; tl < T; ++tl) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        __syncthreads();
+        prefetch(pre[tl], g, cg + 1, tl);
+        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) {
+      const int64_t r0 = (t0 + tl) * NR3;
+      const float4 bv = bias ? ld4(bias + cls * FH + lc4) : f4(0.f);
+      float4 rr[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        rr[it] = R ? ld4(R + clampi(r0 + lrow + 8 * it, Mlast) * ldr + cls * FH + lc4) + bv : bv;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xs[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[tl][e];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        float4 v = ld4(xs + row * FP + lc4) + rr[it];
+        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (grow < M) st4(Y + grow * ldy + cls * FH + lc4, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// fragment blocks of the [K = ncg*128] x [N = ncls*128] weight for gemm_rows_b3_k: block ((cls*ncg + cg)*4 + wv) in the
+// layout of pack_w3_k;  NT: W is [N,K] row-major (y = x W^T),  NN: W is [K,N] row-major (y = x W)
+__global__ void pack_w3_gen_k(const float* __restrict__ W, int64_t ld, int ncls, int ncg, int nn, bf16x8* __restrict__ Wp) {
+  const int total = ncls * ncg * 4 * BKC * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % BKC, blk = idx / (64 * BKC);
+    const int wv = blk & 3, cg = (blk >> 2) % ncg, cls = (blk >> 2) / ncg;
+    const int i = lane & 31, g = lane >> 5;
+    const int64_t n = (int64_t)cls * FH + wv * 32 + i;
+    bf16x8 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = (int64_t)cg * FH + 16 * c + 8 * g + j;
+      const float x = nn ? W[k * ld + n] : W[n * ld + k];
+      const __bf16 h = (__bf16)x;
+      const float r1 = x - (float)h;
+      const __bf16 m = (__bf16)r1;
+      hi[j] = h;
+      mid[j] = m;
+      lo[j] = (__bf16)(r1 - (float)m);
+    }
+    bf16x8* o = Wp + ((int64_t)(blk * BKC + c) * 3) * 64 + lane;
+    o[0] = hi;
+    o[64] = mid;
+    o[128] = lo;
+  }
+}
+
 // slab[(cg*nslot + slot)][n][c] = sum over the slot's rows of A[row][cg*128+n] * B[row][c];
 // partials[(cg*nslot + slot)][128] = column sums of A[:, cg*128 ..]
 template <class MM>
@@ -1374,6 +1482,24 @@ __global__ void slab_reduce_k(const float* __restrict__ slab, int nslab, int tot
   }
 }
 
+// out[m * ldc + n] = sum_b slab[b][m][n] for one 128 x 128 block, fixed order -> deterministic
+__global__ void slab_reduce_ld_k(const float* __restrict__ slab, int nslab, float* __restrict__ out, int64_t ldc) {
+  constexpr int total = FH * FH;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* p = slab + i;
+    int b = 0;
+    for (; b + 3 < nslab; b += 4) {
+      a0 += p[(size_t)b * total];
+      a1 += p[(size_t)(b + 1) * total];
+      a2 += p[(size_t)(b + 2) * total];
+      a3 += p[(size_t)(b + 3) * total];
+    }
+    for (; b < nslab; ++b) a0 += p[(size_t)b * total];
+    out[(int64_t)(i / FH) * ldc + (i % FH)] = (a0 + a1) + (a2 + a3);
+  }
+}
+
 }  // namespace gnm
 
 using namespace gnm;
@@ -1383,8 +1509,8 @@ static inline int64_t cdiv_(int64_t a, int64_t b) { return (a + b - 1) / b; }
 namespace gnm {   // gnm_tr.hip: the split-mode TN kernel on swizzled row-major images + transpose reads
 int tn_tr_rows_per_tile();
 int tn_tr_occupancy();
-void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* slab, double* partials,
-                  int nslot, int64_t tiles_per_slot, hipStream_t st);
+void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, int64_t ldb, int ncgb, float* slab,
+                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st);
 size_t edge_bwd_tr_pack_bytes();
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
@@ -1585,7 +1711,7 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
   nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
   if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
   if (tr)
-    tn_tr_launch(N, A, lda, ncg, B, slab, partials, nslot, cdiv_(ntiles, nslot), st);
+    tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st);
   else if (g_matmul_mode)
     hipLaunchKernelGGL(tn_colgroup32_b3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
                        nslot, cdiv_(ntiles, nslot));
@@ -1601,6 +1727,70 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
   GNM_LAUNCH_CHECK("tn_colgroup reduce");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Split-mode route of gnm_gemm_f32 (gnm_gemm.hip) for the big-M shapes whose other two dimensions are multiples of
+// 128: NT / NN through gemm_rows_b3_k, TN through tn_tr_k with (A group, B group) classes.  Returns 1 = done,
+// 0 = not eligible (the caller runs the fp32-MFMA kernel), < 0 = error.
+// ------------------------------------------------------------------------------------------
+namespace gnm {
+static bool gemm_b3_shape_ok(int mode, int64_t M, int64_t N, int64_t K) {
+  if (!g_matmul_mode) return false;
+  if (mode == GNM_GEMM_TN) return K >= 4096 && M > 0 && N > 0 && M % FH == 0 && N % FH == 0 && (M / FH) * (N / FH) <= 64;
+  return M >= 2048 && N > 0 && K > 0 && N % FH == 0 && K % FH == 0 && (N / FH) * (K / FH) <= 256;
+}
+static int gemm_b3_tn_slots(int64_t rows, int ncls) {
+  const int64_t ntiles = cdiv_(rows, tn_tr_rows_per_tile());
+  int nslot = (num_cus() * tn_tr_occupancy()) / ncls;
+  if (nslot > kMaxPartialBlocks / ncls) nslot = kMaxPartialBlocks / ncls;
+  if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
+  nslot = nslot / kXcds * kXcds;
+  if (nslot < kXcds) nslot = kXcds;
+  return nslot;
+}
+size_t gemm_b3_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
+  if (!gemm_b3_shape_ok(mode, M, N, K)) return 0;
+  if (mode == GNM_GEMM_TN) {
+    const int ncls = (int)((M / FH) * (N / FH));
+    const size_t blocks = (size_t)ncls * gemm_b3_tn_slots(K, ncls);
+    return blocks * FH * FH * sizeof(float) + blocks * FH * sizeof(double);
+  }
+  return (size_t)(N / FH) * (K / FH) * 4 * MmB3::kPackBytes;
+}
+int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                float* C, int64_t ldc, const float* bias, const float* resid, int64_t ldr, int relu, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+  if (!gemm_b3_shape_ok(mode, M, N, K)) return 0;
+  auto al = [](const void* p, int64_t ld) { return (uintptr_t)p % 16 == 0 && ld % 4 == 0; };
+  if (!al(A, lda) || !ws || ws_bytes < gemm_b3_workspace_bytes(mode, M, N, K)) return 0;
+  if (mode == GNM_GEMM_TN) {            // C[M,N] = A[K,M]^T B[K,N]
+    if (bias || resid || relu || !al(B, ldb)) return 0;
+    const int ncga = (int)(M / FH), ncgb = (int)(N / FH), ncls = ncga * ncgb;
+    const int nslot = gemm_b3_tn_slots(K, ncls);
+    const int64_t ntiles = cdiv_(K, tn_tr_rows_per_tile());
+    float* slab = (float*)ws;
+    double* partials = (double*)((char*)ws + (size_t)ncls * nslot * FH * FH * sizeof(float));
+    tn_tr_launch(K, A, lda, ncga, B, ldb, ncgb, slab, partials, nslot, cdiv_(ntiles, nslot), st);
+    for (int cls = 0; cls < ncls; ++cls)
+      hipLaunchKernelGGL(slab_reduce_ld_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cls * nslot * FH * FH,
+                         nslot, C + (int64_t)(cls / ncgb) * FH * ldc + (cls % ncgb) * FH, ldc);
+    return hipGetLastError() == hipSuccess ? 1 : -2;
+  }
+  if (!al(C, ldc) || (resid && !al(resid, ldr)) || (bias && (uintptr_t)bias % 16 != 0)) return 0;
+  const int ncls = (int)(N / FH), ncg = (int)(K / FH);
+  hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, B, ldb, ncls, ncg, mode == GNM_GEMM_NN ? 1 : 0,
+                     (bf16x8*)ws);
+  constexpr int T = 4;
+  const int64_t ngroups = cdiv_(M, NR3 * T);
+  int nchunk = (num_cus() * occ_blocks<gemm_rows_b3_k<T>>()) / ncls;
+  if ((int64_t)nchunk > ngroups) nchunk = (int)ngroups;
+  nchunk = nchunk / kXcds * kXcds;
+  if (nchunk < kXcds) nchunk = kXcds;
+  hipLaunchKernelGGL((gemm_rows_b3_k<T>), dim3(nchunk * ncls), dim3(kBlock), 0, st, M, A, lda, ncg, ncls, (const void*)ws,
+                     bias, resid, ldr, relu, C, ldc, nchunk, cdiv_(ngroups, nchunk));
+  return hipGetLastError() == hipSuccess ? 1 : -2;
+}
+}  // namespace gnm
 
 // gh_in = gh_out + gP W  (W [ncols,128] row-major, ncols % 128 == 0);  gW = gP^T h_in;  gb = sum gP.
 // ws: packed W (ncols/32 fragment blocks) + slabs [ncg][nslot][128][128]; partials double[ncg*nslot][128]

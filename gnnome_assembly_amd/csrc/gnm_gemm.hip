@@ -225,10 +225,19 @@ static void plan_split(int mode, int64_t M, int64_t N, int64_t K, int* splits, i
 
 using namespace gnm;
 
+namespace gnm {   // gnm_fused.hip: the split-mode (bf16x3) route for big-M shapes with 128-multiple other dimensions
+size_t gemm_b3_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
+int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                float* C, int64_t ldc, const float* bias, const float* resid, int64_t ldr, int relu, void* ws,
+                size_t ws_bytes, hipStream_t st);
+}
+
 extern "C" size_t gnm_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
   int splits; int64_t kps;
   plan_split(mode, M, N, K, &splits, &kps);
-  return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  const size_t f32 = splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  const size_t b3 = gemm_b3_workspace_bytes(mode, M, N, K);
+  return f32 > b3 ? f32 : b3;
 }
 
 extern "C" int gnm_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -238,6 +247,11 @@ extern "C" int gnm_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const flo
   GNM_CHECK_ARG(mode >= 0 && mode <= 2, "gemm_f32: mode %d", mode);
   GNM_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C, "gemm_f32: null/neg argument");
   if (M == 0 || N == 0) return 0;
+  {
+    const int rc = gemm_b3_try(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, resid, ldr, relu, ws, ws_bytes, (hipStream_t)stream);
+    if (rc < 0) { GNM_LAUNCH_CHECK("gemm_f32 (split route)"); return rc; }
+    if (rc > 0) return 0;
+  }
   GemmArgs a;
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.bias = bias; a.resid = resid; a.ldr = ldr; a.relu = relu; a.slab = nullptr;

@@ -17,8 +17,9 @@ constexpr int TRIMG = TRR * SPITCH;         // bytes per image (8 KB)
 // the 128 x 128 result (64 accumulator registers).  Two or three workgroups share a CU, so one's split / staging
 // VALU work and HBM waits run under the others' MFMAs.
 __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __restrict__ A, int64_t lda, int ncg,
-                                                     const float* __restrict__ B, float* __restrict__ slab,
-                                                     double* __restrict__ partials, int nslot, int64_t tiles_per_slot) {
+                                                     const float* __restrict__ B, int64_t ldb, int ncgb,
+                                                     float* __restrict__ slab, double* __restrict__ partials, int nslot,
+                                                     int64_t tiles_per_slot) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[6 * TRIMG];
   unsigned char* ia = lds;
   unsigned char* ib = lds + 3 * TRIMG;
@@ -29,7 +30,10 @@ __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __r
   // The ncg workgroups of a slot read the same B rows: keep them on one XCD (workgroup b runs on XCD b % 8) so
   // that the tile comes out of that XCD's L2 instead of HBM ncg times.  nslot % 8 == 0.
   const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;
-  const int cg = jj % ncg, slot = xcd * (nslot / kXcds) + jj / ncg;
+  // class = (column group of A, column group of B); ncgb = 1, ldb = 128 is the original one-group-of-B case
+  const int ncls = ncg * ncgb;
+  const int cls = jj % ncls, slot = xcd * (nslot / kXcds) + jj / ncls;
+  const int cg = cls / ncgb, cgb = cls - cg * ncgb;
   const int64_t ntiles = (M + TRR - 1) / TRR;
   const int64_t tb0 = (int64_t)slot * tiles_per_slot;
   const int64_t tb1 = tb0 + tiles_per_slot < ntiles ? tb0 + tiles_per_slot : ntiles;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __r
       int64_t r = r0 + lrow + 8 * it;
       r = r < Mlast ? r : Mlast;
       pa[it] = ld4_nt(A + r * lda + cg * SW + lc4);
-      pb[it] = ld4(B + r * SW + lc4);        // shared by the ncg workgroups of the slot through L2
+      pb[it] = ld4(B + r * ldb + cgb * SW + lc4);        // shared by the workgroups of the slot through L2
     }
   };
   if (tb0 < tb1) prefetch(tb0);
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __r
     }
   }
   // C / D layout of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-  float* sl = slab + (size_t)(cg * nslot + slot) * SW * SW;
+  float* sl = slab + (size_t)(cls * nslot + slot) * SW * SW;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __r
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k * SW + tid];
-    partials[(size_t)(cg * nslot + slot) * SW + tid] = s;
+    partials[(size_t)(cls * nslot + slot) * SW + tid] = s;
   }
 }
 
@@ -762,10 +766,10 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
 
 int tn_tr_rows_per_tile() { return TRR; }
 int tn_tr_occupancy() { return occ_blocks<tn_tr_k>(); }
-void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* slab, double* partials,
-                  int nslot, int64_t tiles_per_slot, hipStream_t st) {
-  hipLaunchKernelGGL(tn_tr_k, dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, slab, partials, nslot,
-                     tiles_per_slot);
+void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, int64_t ldb, int ncgb, float* slab,
+                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st) {
+  hipLaunchKernelGGL(tn_tr_k, dim3(nslot * ncg * ncgb), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, ncgb, slab, partials,
+                     nslot, tiles_per_slot);
 }
 
 }  // namespace gnm

@@ -89,12 +89,15 @@ def test_library_loaded_and_device():
     print("CUs:", lib.gnm_num_cus(), torch.cuda.get_device_name(0))
 
 
-@pytest.mark.mode_independent
 @pytest.mark.parametrize("mode,M,N,K", [
     (0, 256, 128, 128), (0, 1000, 640, 128), (0, 777, 64, 128), (0, 300, 128, 18), (0, 513, 16, 2),
     (1, 256, 128, 128), (1, 1000, 128, 640), (1, 333, 16, 128), (1, 500, 128, 64),
     (2, 128, 128, 4096), (2, 640, 128, 5000), (2, 64, 128, 3001), (2, 128, 18, 1000), (2, 16, 2, 777),
     (2, 128, 128, 100000),
+    # big-M shapes with 128-multiple other dimensions: the split-mode route (gemm_rows_b3_k / tn_tr_k classes) under
+    # bf16x3, the fp32-MFMA kernel under f32 -- the shapes of a hidden-256 model (the reference's default width)
+    (0, 5000, 256, 256), (0, 3001, 1280, 256), (0, 2048, 128, 128), (1, 4100, 256, 256), (1, 2500, 256, 1280),
+    (2, 256, 256, 9000), (2, 1280, 256, 5003), (2, 256, 128, 4096),
 ])
 def test_gemm_f32(mode, M, N, K):
     from gnnome_assembly_amd import engine
