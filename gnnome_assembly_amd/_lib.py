@@ -26,6 +26,8 @@ SIGNATURES = {
     "gnm_graph_build_index": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_gemm_f32_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64]),
     "gnm_gemm_f32": (_i32, [_i32, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
+    "gnm_gemm_tn_colsum_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gnm_gemm_tn_colsum": (_i32, [_i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _sz, _p]),
     "gnm_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "gnm_colsum_f32": (_i32, [_i64, _i64, _p, _i64, _p, _p, _sz, _p]),
     "gnm_gather_rows_f32": (_i32, [_i64, _i64, _p, _p, _p, _p]),

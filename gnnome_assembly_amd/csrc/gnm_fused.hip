@@ -1790,6 +1790,19 @@ int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64
                      bias, resid, ldr, relu, C, ldc, nchunk, cdiv_(ngroups, nchunk));
   return hipGetLastError() == hipSuccess ? 1 : -2;
 }
+// the same TN product plus the column sums of A (a Linear's bias gradient beside its weight gradient): tn_tr_k keeps them
+// in fp64 per workgroup anyway
+int gemm_b3_tn_colsum_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                          int64_t ldc, float* colsum, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int rc = gemm_b3_try(GNM_GEMM_TN, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, 0, ws, ws_bytes, st);
+  if (rc != 1) return rc;
+  const int ncga = (int)(M / FH), ncgb = (int)(N / FH), ncls = ncga * ncgb;
+  const int nslot = gemm_b3_tn_slots(K, ncls);
+  const double* partials = (const double*)((const char*)ws + (size_t)ncls * nslot * FH * FH * sizeof(float));
+  for (int cga = 0; cga < ncga; ++cga)
+    if (gnm_reduce_partials(partials + (size_t)(cga * ncgb) * nslot * FH, nslot, 1, FH, colsum + (size_t)cga * FH, (void*)st)) return -3;
+  return 1;
+}
 }  // namespace gnm
 
 // gh_in = gh_out + gP W  (W [ncols,128] row-major, ncols % 128 == 0);  gW = gP^T h_in;  gb = sum gP.

@@ -230,6 +230,8 @@ size_t gemm_b3_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
 int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                 float* C, int64_t ldc, const float* bias, const float* resid, int64_t ldr, int relu, void* ws,
                 size_t ws_bytes, hipStream_t st);
+int gemm_b3_tn_colsum_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                          int64_t ldc, float* colsum, void* ws, size_t ws_bytes, hipStream_t st);
 }
 
 extern "C" size_t gnm_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
@@ -281,4 +283,24 @@ extern "C" int gnm_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const flo
     GNM_LAUNCH_CHECK("gemm_f32 split-K reduce");
   }
   return 0;
+}
+
+// C[M,N] = A[K,M]^T B[K,N] and colsum[m] = sum_k A[k][m]: weight and bias gradient of a Linear in one call
+// (one pass over A where the split-mode kernel applies, gnm_gemm_f32 + gnm_colsum_f32 otherwise).
+extern "C" size_t gnm_gemm_tn_colsum_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const size_t a = gnm_gemm_f32_workspace_bytes(GNM_GEMM_TN, M, N, K), b = gnm_colsum_workspace_bytes(K, M);
+  return a > b ? a : b;
+}
+
+extern "C" int gnm_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                                  int64_t ldb, float* C, int64_t ldc, float* colsum, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  GNM_CHECK_ARG(M > 0 && N > 0 && K >= 0 && A && B && C && colsum, "gemm_tn_colsum: null/neg argument");
+  GNM_CHECK_ARG(ws_bytes >= gnm_gemm_tn_colsum_workspace_bytes(M, N, K) && (ws || ws_bytes == 0),
+                "gemm_tn_colsum: workspace too small");
+  const int rc = gemm_b3_tn_colsum_try(M, N, K, A, lda, B, ldb, C, ldc, colsum, ws, ws_bytes, (hipStream_t)stream);
+  if (rc < 0) { GNM_LAUNCH_CHECK("gemm_tn_colsum (split route)"); return rc; }
+  if (rc > 0) return 0;
+  const int r2 = gnm_gemm_f32(GNM_GEMM_TN, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, 0, ws, ws_bytes, stream);
+  return r2 ? r2 : gnm_colsum_f32(K, M, A, lda, colsum, ws, ws_bytes, stream);
 }

@@ -195,6 +195,28 @@ def gemm(mode: int, A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, bias=Non
     return C_
 
 
+@on_device_of(lambda A, *a, **k: A)
+def gemm_tn_colsum(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = A^T B and the column sums of A (weight and bias gradient of a Linear: A = grad of its output [rows, out],
+    B = its input [rows, in]); returns the column sums."""
+    lib = _lib.load()
+    _chk_dev(A, B, C_, out)
+    for t in (A, B, C_):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+            raise _lib.GnmError("gemm_tn_colsum: operands must be 2-D float32 with unit inner stride")
+    K, M = A.shape
+    K2, N = B.shape
+    if K != K2 or tuple(C_.shape) != (M, N):
+        raise _lib.GnmError(f"gemm_tn_colsum: shape mismatch A={tuple(A.shape)} B={tuple(B.shape)} C={tuple(C_.shape)}")
+    if out is None:
+        out = torch.empty(M, dtype=torch.float32, device=A.device)
+    need = lib.gnm_gemm_tn_colsum_workspace_bytes(M, N, K)
+    ws = scratch(A.device).ws(need) if need else None
+    _call("gnm_gemm_tn_colsum", M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_), C_.stride(0), _ptr(out),
+          _ptr(ws), need, _stream(), tag=f"gemm_TN+colsum[{M}x{N}x{K}]" if _prof is not None else None)
+    return out
+
+
 @on_device_of(lambda X, *a, **k: X)
 def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
@@ -364,8 +386,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         _call("gnm_ln_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q), _ptr(idx["out_ptr"]),
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
         del Q
-        gemm(TN, gt, s.e_in, g["W3"])
-        g["b3"] = colsum(gt, out.get("b3"))
+        g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
         gemm(NN, gt, prm.W3, ge, resid=ge)
         del gt
     else:
@@ -418,8 +439,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             gt = torch.empty(E, H, **f32)
             _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(gt), st)
-            gemm(TN, gt, s.e_in, g["W3"])
-            g["b3"] = colsum(gt, out.get("b3"))
+            g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
             gemm(NN, gt, prm.W3, ge, resid=ge)
             del gt
     # node projections backward
@@ -433,8 +453,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
               _ptr(sc.partials), _ptr(ws), need, st)
     else:
-        gemm(TN, gP, s.h_in, g["W5"])
-        g["b5"] = colsum(gP, out.get("b5"))
+        g["b5"] = gemm_tn_colsum(gP, s.h_in, g["W5"], out.get("b5"))
         gemm(NN, gP, prm.W5, gh_in, resid=gh_out)
     return gh_in, ge, g
 

@@ -97,6 +97,13 @@ size_t gnm_colsum_workspace_bytes(int64_t M, int64_t W);
 int gnm_colsum_f32(int64_t M, int64_t W, const float* X, int64_t ld, float* out,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* Weight AND bias gradient of a Linear in one call (autograd of nn.Linear under loss.backward(), train.py:257):
+ * C[M,N] = A[K,M]^T B[K,N], colsum[m] = sum_k A[k][m].  One pass over A where the split-mode kernel applies
+ * (bf16x3 matmul mode, M and N multiples of 128, K >= 4096), gnm_gemm_f32(TN) + gnm_colsum_f32 otherwise. */
+size_t gnm_gemm_tn_colsum_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gnm_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, float* colsum, void* ws, size_t ws_bytes, void* stream);
+
 /* out[j, 0:W] = X[idx[j], 0:W]  (edge features: caller edge-id order -> internal order) */
 int gnm_gather_rows_f32(int64_t M, int64_t W, const float* X, const int32_t* idx, float* out,
                         void* stream);

@@ -126,6 +126,24 @@ def test_gemm_f32(mode, M, N, K):
     assert float(big[:, :4].abs().max()) == 0.0 and float(big[:, 4 + N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 9000), (1280, 256, 5003), (128, 128, 4096), (64, 128, 3001), (128, 18, 1000)])
+def test_gemm_tn_colsum(M, N, K):
+    """gnm_gemm_tn_colsum: a Linear's weight and bias gradient in one call (split route where it applies, gemm + colsum
+    otherwise) against fp64."""
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    rng = np.random.default_rng(M + N + K)
+    A = (rng.standard_normal((K, M)) * np.exp(rng.standard_normal((K, 1)))).astype(np.float32)   # rows of mixed magnitude
+    B = (rng.standard_normal((K, N)) + 0.25).astype(np.float32)
+    big = torch.full((M, N + 4), float("nan"), device=dev)
+    C_ = big[:, :N]
+    cs = engine.gemm_tn_colsum(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), C_)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    assert rel_l2(C_.cpu().double().numpy(), ref) <= 2e-6
+    assert rel_l2(cs.cpu().double().numpy(), A.astype(np.float64).sum(0)) <= 2e-6
+    assert bool(torch.isnan(big[:, N:]).all())
+
+
 # -----------------------------------------------------------------------------------------
 # one layer, kernel by kernel, against the oracle's hand-derived decomposition
 # -----------------------------------------------------------------------------------------
