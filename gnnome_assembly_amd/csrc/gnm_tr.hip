@@ -753,14 +753,17 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   const int grid = persistent_grid(a.N, 64, 1);        // one 512-thread workgroup per CU
   a.nodes_per_block = (a.N + grid - 1) / grid;
   hipLaunchKernelGGL(zero_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo);
-  static const int abl = getenv("GNM_CHAIN_ABL") ? atoi(getenv("GNM_CHAIN_ABL")) : 0;     // timing experiments only
+#ifdef GNM_TIMING_ABLATIONS      // builds for timing experiments only: the ablated kernels give wrong results
+  static const int abl = getenv("GNM_CHAIN_ABL") ? atoi(getenv("GNM_CHAIN_ABL")) : 0;
   switch (abl) {
-    case 1: hipLaunchKernelGGL(edge_bwd_chain_k<1>, dim3(grid), dim3(CT), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(edge_bwd_chain_k<2>, dim3(grid), dim3(CT), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(edge_bwd_chain_k<4>, dim3(grid), dim3(CT), 0, st, a); break;
-    case 7: hipLaunchKernelGGL(edge_bwd_chain_k<7>, dim3(grid), dim3(CT), 0, st, a); break;
-    default: hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);
+    case 1: hipLaunchKernelGGL(edge_bwd_chain_k<1>, dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 2: hipLaunchKernelGGL(edge_bwd_chain_k<2>, dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 4: hipLaunchKernelGGL(edge_bwd_chain_k<4>, dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 7: hipLaunchKernelGGL(edge_bwd_chain_k<7>, dim3(grid), dim3(CT), 0, st, a); return grid;
+    default: break;
   }
+#endif
+  hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);
   return grid;
 }
 
