@@ -113,6 +113,9 @@ def load():
         if mode not in MATMUL_MODES:
             raise GnmError(f"GNM_MATMUL={mode!r}: expected one of {sorted(MATMUL_MODES)}")
         check(lib.gnm_set_matmul_mode(MATMUL_MODES[mode]), "gnm_set_matmul_mode")
+    for kv in filter(None, os.environ.get("GNM_VARIANTS", "").split(",")):   # kernel-generation A/B (gnm_debug_set_variant)
+        k, _, v = kv.partition("=")
+        check(lib.gnm_debug_set_variant(k.strip().encode(), int(v)), "gnm_debug_set_variant")
     return lib
 
 
