@@ -79,8 +79,8 @@ class GatedGCN_1d(nn.Module):
             # the reference silently drops the residual (gated_gcn_full.py:41-42); the model never
             # builds such a layer (processor.py:11-12) and the HIP path does not implement it.
             raise NotImplementedError("GatedGCN_1d: in_channels != out_channels is outside the hot path")
-        if dropout != 0:
-            raise NotImplementedError("dropout != 0 is never used by the reference (processor.py:12)")
+        if not 0 <= dropout < 1:
+            raise ValueError(f"GatedGCN_1d: dropout={dropout}")
         if not residual:
             # the kernels always add h_in / e_in (gated_gcn_full.py:149-152 with residual=True, the only
             # value the model passes, processor.py:11-12): refuse rather than return a silently different result
@@ -97,7 +97,12 @@ class GatedGCN_1d(nn.Module):
         P = dict(self.named_parameters())
         flat = [P[k] for k in _LAYER_KEYS]
         need = torch.is_grad_enabled() and any(t.requires_grad for t in [h, e] + flat)
-        return _LayerFn.apply(g, need, bool(self.batch_norm), h, e, *flat)
+        h, e = _LayerFn.apply(g, need, bool(self.batch_norm), h, e, *flat)
+        if self.dropout and self.training:
+            # gated_gcn_full.py:154: dropout on the node output only, after the residual.  Never enabled by the model
+            # (processor.py:12 passes no dropout), so it is not fused: the mask comes from torch's generator on h's device
+            h = torch.nn.functional.dropout(h, self.dropout, training=True)
+        return h, e
 
 
 class GraphGatedGCN(nn.Module):

@@ -335,6 +335,36 @@ def test_fused_bce_matches_torch():
 # stand-alone modules (edge-id order at every module boundary, like DGL)
 # -----------------------------------------------------------------------------------------
 
+@pytest.mark.mode_independent
+def test_standalone_layer_dropout():
+    """gated_gcn_full.py:154: dropout on the node output after the residual, training mode only (never enabled by the
+    model).  Kept elements are the p = 0 output scaled by 1/(1-p), e is untouched, eval mode is the p = 0 output."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    dev = _dev()
+    H = 64
+    src, dst, n = synth.make_graph(300, seed=5)
+    rng = np.random.default_rng(5)
+    h0 = torch.from_numpy(rng.standard_normal((n, H)).astype(np.float32)).to(dev)
+    e0 = torch.from_numpy(rng.standard_normal((src.size, H)).astype(np.float32)).to(dev)
+    graph = G.AssemblyGraph(src, dst, n).to(dev)
+    torch.manual_seed(0)
+    plain = G.layers.GatedGCN_1d(H, H, True).to(dev)
+    drop = G.layers.GatedGCN_1d(H, H, True, dropout=0.5).to(dev)
+    drop.load_state_dict(plain.state_dict())
+    h_ref, e_ref = plain(graph, h0, e0)
+    hd, ed = drop(graph, h0.clone().requires_grad_(True), e0)
+    kept = hd != 0
+    frac = float(kept.float().mean())
+    assert 0.4 < frac < 0.6, frac
+    assert torch.equal(ed, e_ref)
+    assert torch.allclose(hd[kept], 2.0 * h_ref[kept], rtol=0, atol=0)
+    hd.sum().backward()                                   # the mask is part of the autograd graph
+    drop.eval()
+    he, _ = drop(graph, h0, e0)
+    assert torch.equal(he, h_ref)
+
+
 def test_standalone_modules_match_oracle():
     import gnnome_assembly_amd as G
     from oracle import gatedgcn_oracle as orc
