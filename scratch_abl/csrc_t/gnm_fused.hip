@@ -1,0 +1,1877 @@
+// W-stationary fused MFMA kernels for H = 128 (gfx950).
+//
+// The [E,128] x [128,128] contractions of the layer have intensity 32 FLOP/B -- right at the
+// fp32-MFMA / HBM balance point of the chip -- so a separate GEMM that writes its result and a
+// separate elementwise pass that re-reads it pay the [E,H] stream twice.  These kernels keep
+// the 64 KB weight matrix in VGPRs (each of the 4 waves owns 32 output columns = 64 VGPRs of
+// B fragments), stream 64-row tiles through LDS once, and do the surrounding elementwise /
+// gather / statistics work around the MFMAs:
+//
+//   rowtile_nt_k<EDGE>   t = e W3^T + b3 + B1h[src] + B2h[dst], BatchNorm column sums
+//                        (gated_gcn_full.py:113,120-122) -- replaces gemm + edge_t_stats;
+//                        node mode: P = h W5^T + b5 over the five 128-column groups (:107-112)
+//   edge_bwd_fused_k     gt = gamma*rstd*(gu - m1 - that*m2); ge_in = ge + gt W3;
+//                        gW3 += gt^T e_in; gb3 += sum gt   (autograd of :113,:122)
+//                        -- replaces edge_bwd_gt + two GEMMs + a column sum (9 -> 4 streams)
+//   rowtile_nn_acc_k / tn_colgroup_k   autograd of the 5-way node projection (:107-112)
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  Lane (i = l&31, g = l>>5) supplies A[i][k'],
+// B[k'][i] with k' = g; contraction indices are permuted as k = 8q + 4g + r so that one
+// ds_read_b128 feeds four MFMAs; C/D: col = l&31, row = (e&3) + 8*(e>>2) + 4*g.
+// LDS row pitch 132 floats: ds_read_b128 fragment reads are bank-conflict-free.  Accumulators
+// are transposed through LDS so that every global access is a whole 512-byte row (one float4
+// per lane).
+//
+// Pipelining: every HBM row a tile needs is prefetched one tile ahead into registers, under the
+// MFMA phases.  The steady-state loop only runs FULL tiles and is free of divergent branches
+// (addresses are clamped instead of predicated), so hipcc can count the vector-memory queue:
+// the wait for the prefetched rows is vmcnt(#stores issued after them), not vmcnt(0) -- with a
+// predicated epilogue it waited for the previous tile's stores to drain on every iteration.
+// The (at most one) ragged tile of a workgroup runs through a predicated copy of the body.
+#include <string.h>
+#include <type_traits>
+
+#include "gnm_common.h"
+#include "gnm_tr.h"
+
+namespace gnm {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int FH = 128;          // hidden width these kernels are built for
+constexpr int FTR = 64;          // rows per tile
+constexpr int FP = FH + 4;       // LDS row pitch (floats)
+constexpr int FKQ = FH / 8;      // 16 k-quads
+
+using full_t = std::true_type;
+using ragged_t = std::false_type;
+
+// Pack a [rows,128]-shaped weight into MFMA B-fragment order:
+//   NT (y = x W^T):  Wp[cb][q][lane][r] = W[(cb*32 + (lane&31)) * ld + 8q + 4(lane>>5) + r]
+//   NN (y = x W):    Wp[cb][q][lane][r] = W[(8q + 4(lane>>5) + r) * ld + cb*32 + (lane&31)]
+// cb = 32-column block of the output; one float4 per (cb, q, lane).
+__global__ void pack_w_k(const float* __restrict__ W, int64_t ld, int ncb, int nn, float* __restrict__ Wp) {
+  const int total = ncb * FKQ * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, q = (idx >> 6) % FKQ, cb = idx / (64 * FKQ);
+    const int i = lane & 31, g = lane >> 5;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 8 * q + 4 * g + r;
+      v[r] = nn ? W[(int64_t)k * ld + cb * 32 + i] : W[(int64_t)(cb * 32 + i) * ld + k];
+    }
+    reinterpret_cast<float4*>(Wp)[idx] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__device__ __forceinline__ void mfma4(floatx16& acc, const float4& a, const float4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+}
+
+// acc0/acc1 += (rows 0-31 / 32-63 of the LDS tile) x (this wave's 32 weight columns), K = 128.
+// Fragment reads are software-pipelined one k-quad ahead; the sched_barriers keep hipcc from
+// hoisting all 32 fragment reads (128 VGPRs) or sinking them right in front of their MFMAs.
+__device__ __forceinline__ void mma_tile64(const float* __restrict__ lds, const float4 (&wf)[FKQ],
+                                           floatx16& acc0, floatx16& acc1, int li, int lg) {
+  const float* p0 = lds + li * FP + 4 * lg;
+  const float* p1 = lds + (32 + li) * FP + 4 * lg;
+  float4 a0 = ld4(p0), a1 = ld4(p1);
+#pragma unroll
+  for (int q = 0; q < FKQ; ++q) {
+    float4 n0 = a0, n1 = a1;
+    if (q + 1 < FKQ) {
+      n0 = ld4(p0 + 8 * (q + 1));
+      n1 = ld4(p1 + 8 * (q + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(acc0, a0, wf[q]);
+    mfma4(acc1, a1, wf[q]);
+    a0 = n0;
+    a1 = n1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// tn[a][b] += gt-tile^T x e-tile over 64 rows: this wave's 64 x 64 block (wn, wc) of the 128 x 128 result
+__device__ __forceinline__ void mma_tn64(const float* __restrict__ as, const float* __restrict__ bs,
+                                         floatx16 (&tn)[2][2], int wn, int wc, int li, int lg) {
+#pragma unroll
+  for (int q = 0; q < FTR / 8; ++q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 8 * q + 4 * lg + r;
+      const float a0 = as[row * FP + (2 * wn) * 32 + li];
+      const float a1 = as[row * FP + (2 * wn + 1) * 32 + li];
+      const float b0 = bs[row * FP + (2 * wc) * 32 + li];
+      const float b1 = bs[row * FP + (2 * wc + 1) * 32 + li];
+      tn[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, tn[0][0], 0, 0, 0);
+      tn[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, tn[0][1], 0, 0, 0);
+      tn[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, tn[1][0], 0, 0, 0);
+      tn[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, tn[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// MFMA accumulator layout -> row image in LDS
+__device__ __forceinline__ void acc_to_lds(float* __restrict__ o, const floatx16& acc0, const floatx16& acc1,
+                                           int wave, int li, int lg) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * lg;
+    o[row * FP + wave * 32 + li] = acc0[e];
+    o[(32 + row) * FP + wave * 32 + li] = acc1[e];
+  }
+}
+
+__device__ __forceinline__ int64_t clampi(int64_t r, int64_t hi) { return r < hi ? r : hi; }
+
+// ------------------------------------------------------------------------------------------
+// Matmul policies of the row-tile kernels (how a 64 x 128 fp32 tile meets a 128 x 32 weight block)
+//
+//   MmF32   v_mfma_f32_32x32x2_f32 on the fp32 tile image (gnm_set_matmul_mode(0)).
+//   MmB3    fp32 x fp32 as SIX bf16 MFMAs (v_mfma_f32_32x32x16_bf16, 8x the fp32 rate):
+//           x = x1 + x2 + x3 exactly, with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+//           (3 x 8 significand bits = fp32's 24), every product x_i * w_j is exact in the fp32
+//           accumulator, and the three products below 2^-24 |x w| (x2 w3, x3 w2, x3 w3) are
+//           dropped -- the same order as ONE fp32 rounding of the product.  Accumulation stays
+//           fp32.  The default (gnm_set_matmul_mode(0) selects MmF32); inf inputs give NaN (inf - inf in the split).
+// A policy stages tile rows into its LDS image(s), keeps this wave's weight block as fragments in
+// VGPRs, and accumulates rows 0-31 / 32-63 of the tile into acc0 / acc1.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BP = FH + 8;          // bf16 image row pitch (272 B): ds_read_b128 fragment reads conflict-free
+constexpr int BIMG = FTR * BP;      // elements per bf16 image
+constexpr int BKC = FH / 16;        // 8 k-chunks of 16
+
+struct MmF32 {
+  static constexpr int kImgBytes = FTR * FP * 4;
+  static constexpr bool kSplit = false;
+  static constexpr size_t kPackBytes = (size_t)FKQ * 64 * 16;        // per 32-column weight block
+  static constexpr int kTnBytes = 2 * FTR * FP * 4;                  // TN operands: two fp32 row images
+  // tile row of the it-th float4 of thread-row lrow in the coalesced image
+  static __device__ __forceinline__ int row(int lrow, int it) { return lrow + 8 * it; }
+  struct Frag { float4 w[FKQ]; };
+  static __device__ __forceinline__ void load_w(Frag& f, const void* Wp, int blk, int lane) {
+    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)blk * FKQ) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < FKQ; ++q) f.w[q] = p[q * 64];
+  }
+  static __device__ __forceinline__ void stage(void* img, int row, int c4, const float4& v) {
+    st4(reinterpret_cast<float*>(img) + row * FP + c4, v);
+  }
+  static __device__ __forceinline__ void mma(const void* img, const Frag& f, floatx16& acc0, floatx16& acc1,
+                                             int li, int lg) {
+    mma_tile64(reinterpret_cast<const float*>(img), f.w, acc0, acc1, li, lg);
+  }
+};
+
+__device__ __forceinline__ void split3(const float4& v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r1 = x[j] - (float)h;      // exact
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;        // exact, fits 8 bits
+    hi[j] = h;
+    mid[j] = m;
+    lo[j] = (__bf16)r2;
+  }
+}
+
+__device__ __forceinline__ void mfb(floatx16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+struct MmB3 {
+  static constexpr int kImgBytes = 3 * BIMG * 2;
+  static constexpr bool kSplit = true;
+  static constexpr size_t kPackBytes = (size_t)BKC * 3 * 64 * 16;
+  static constexpr int kTnBytes = 2 * 3 * (FH * (FTR + 8)) * 2;      // TN operands: two transposed split images
+  static __device__ __forceinline__ int row(int lrow, int it) { return 8 * lrow + it; }   // see stage_cols
+  struct Frag { bf16x8 w[BKC][3]; };
+  static __device__ __forceinline__ void load_w(Frag& f, const void* Wp, int blk, int lane) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(Wp) + ((int64_t)blk * BKC * 3) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < BKC; ++c)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) f.w[c][s] = p[(c * 3 + s) * 64];
+  }
+  static __device__ __forceinline__ void stage(void* img, int row, int c4, const float4& v) {
+    bf16x4 hi, mid, lo;
+    split3(v, hi, mid, lo);
+    __bf16* b = reinterpret_cast<__bf16*>(img) + row * BP + c4;
+    *reinterpret_cast<bf16x4*>(b) = hi;
+    *reinterpret_cast<bf16x4*>(b + BIMG) = mid;
+    *reinterpret_cast<bf16x4*>(b + 2 * BIMG) = lo;
+  }
+  // lane (i, g) of chunk c holds k = 16c + 8g .. +7 of row i (A) / of weight column i (B)
+  static __device__ __forceinline__ void mma(const void* img, const Frag& f, floatx16& acc0, floatx16& acc1,
+                                             int li, int lg) {
+    const __bf16* p0 = reinterpret_cast<const __bf16*>(img) + li * BP + 8 * lg;
+    const __bf16* p1 = p0 + 32 * BP;
+    bf16x8 a0[3], a1[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      a0[s] = *reinterpret_cast<const bf16x8*>(p0 + s * BIMG);
+      a1[s] = *reinterpret_cast<const bf16x8*>(p1 + s * BIMG);
+    }
+#pragma unroll
+    for (int c = 0; c < BKC; ++c) {
+      bf16x8 n0[3], n1[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        n0[s] = a0[s];
+        n1[s] = a1[s];
+        if (c + 1 < BKC) {
+          n0[s] = *reinterpret_cast<const bf16x8*>(p0 + s * BIMG + 16 * (c + 1));
+          n1[s] = *reinterpret_cast<const bf16x8*>(p1 + s * BIMG + 16 * (c + 1));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+      mfb(acc0, a0[2], f.w[c][0]); mfb(acc1, a1[2], f.w[c][0]);
+      mfb(acc0, a0[0], f.w[c][2]); mfb(acc1, a1[0], f.w[c][2]);
+      mfb(acc0, a0[1], f.w[c][1]); mfb(acc1, a1[1], f.w[c][1]);
+      mfb(acc0, a0[1], f.w[c][0]); mfb(acc1, a1[1], f.w[c][0]);
+      mfb(acc0, a0[0], f.w[c][1]); mfb(acc1, a1[0], f.w[c][1]);
+      mfb(acc0, a0[0], f.w[c][0]); mfb(acc1, a1[0], f.w[c][0]);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { a0[s] = n0[s]; a1[s] = n1[s]; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// ---- split TN: C[n][c] += sum_row A[row][n] B[row][c], both operands transposed into bf16 images ----
+// A thread of the coalesced tile image owns rows 8*lrow .. +7 x columns lc4 .. +3 (MmB3::row), i.e. for
+// each of its 4 columns 8 CONSECUTIVE contraction indices = one bf16x8 = one ds_write_b128 into the
+// column-major image T[s][slot][row], pitch TP = 72 (9 sixteen-byte units: 16 neighbouring slots hit 16
+// different bank groups).  Neighbouring lanes of the tile image are 4 columns apart, so column c is
+// kept in slot 32*(c & 3) + (c >> 2): the j-th write of lanes 0..31 then goes to 32 consecutive slots
+// (conflict-free; measured 2.5x faster than slot = column), and a fragment read of slots
+// 32*blk .. +31 is conflict-free too.  The price is only a permuted result: MFMA block blk, index i
+// stands for column 4*i + blk (tn_store_slab).
+constexpr int TP = FTR + 8;
+constexpr int TIMG = FH * TP;
+
+struct Split8 { bf16x4 hi[8], mid[8], lo[8]; };   // 8 rows x 4 columns, split
+
+__device__ __forceinline__ void split_rows(const float4 (&v)[8], Split8& s) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) split3(v[it], s.hi[it], s.mid[it], s.lo[it]);
+}
+__device__ __forceinline__ void stage_rows(void* img, int lrow, int lc4, const Split8& s) {
+  __bf16* b = reinterpret_cast<__bf16*>(img) + (8 * lrow) * BP + lc4;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    *reinterpret_cast<bf16x4*>(b + it * BP) = s.hi[it];
+    *reinterpret_cast<bf16x4*>(b + it * BP + BIMG) = s.mid[it];
+    *reinterpret_cast<bf16x4*>(b + it * BP + 2 * BIMG) = s.lo[it];
+  }
+}
+__device__ __forceinline__ void stage_cols(void* timg, int lrow, int lc4, const Split8& s) {
+  __bf16* b = reinterpret_cast<__bf16*>(timg) + (lc4 >> 2) * TP + 8 * lrow;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { h[it] = s.hi[it][j]; m[it] = s.mid[it][j]; l[it] = s.lo[it][j]; }
+    *reinterpret_cast<bf16x8*>(b + j * 32 * TP) = h;
+    *reinterpret_cast<bf16x8*>(b + j * 32 * TP + TIMG) = m;
+    *reinterpret_cast<bf16x8*>(b + j * 32 * TP + 2 * TIMG) = l;
+  }
+}
+// this wave's 64 x 64 block (wn, wc) of the 128 x 128 result, contraction over the tile's 64 rows
+template <bool PIPE>
+__device__ __forceinline__ void mma_tn64_b3(const void* ta, const void* tb, floatx16 (&tn)[2][2], int wn, int wc,
+                                            int li, int lg) {
+  const __bf16* pa = reinterpret_cast<const __bf16*>(ta) + ((2 * wn) * 32 + li) * TP + 8 * lg;
+  const __bf16* pb = reinterpret_cast<const __bf16*>(tb) + ((2 * wc) * 32 + li) * TP + 8 * lg;
+  bf16x8 a[2][3], b[2][3];
+  auto load = [&](int kc, bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        fa[x][s_] = *reinterpret_cast<const bf16x8*>(pa + s_ * TIMG + x * 32 * TP + 16 * kc);
+        fb[x][s_] = *reinterpret_cast<const bf16x8*>(pb + s_ * TIMG + x * 32 * TP + 16 * kc);
+      }
+  };
+  load(0, a, b);
+#pragma unroll
+  for (int kc = 0; kc < FTR / 16; ++kc) {
+    bf16x8 na[2][3], nb[2][3];
+    if (PIPE && kc + 1 < FTR / 16) load(kc + 1, na, nb);   // PIPE: next chunk's fragments under these MFMAs (+48 VGPRs)
+    if (!PIPE && kc > 0) load(kc, a, b);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t_ = 0; t_ < 6; ++t_) {
+      // (A part, B part): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+      const int sa = t_ == 0 ? 2 : (t_ == 2 || t_ == 3) ? 1 : 0;
+      const int sb = t_ == 1 ? 2 : (t_ == 2 || t_ == 4) ? 1 : 0;
+      mfb(tn[0][0], a[0][sa], b[0][sb]);
+      mfb(tn[0][1], a[0][sa], b[1][sb]);
+      mfb(tn[1][0], a[1][sa], b[0][sb]);
+      mfb(tn[1][1], a[1][sa], b[1][sb]);
+    }
+    if (PIPE && kc + 1 < FTR / 16) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) { a[x][s_] = na[x][s_]; b[x][s_] = nb[x][s_]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// this wave's 64 x 64 block of the TN result -> sl[n][c] (128 x 128, row-major)
+template <class MM>
+__device__ __forceinline__ void tn_store_slab(float* __restrict__ sl, const floatx16 (&tn)[2][2], int wn, int wc,
+                                              int li, int lg) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * lg;
+        const int n = MM::kSplit ? 4 * i + (2 * wn + a) : (2 * wn + a) * 32 + i;     // see stage_cols
+        const int c = MM::kSplit ? 4 * li + (2 * wc + b) : (2 * wc + b) * 32 + li;
+        sl[n * FH + c] = tn[a][b][e];
+      }
+}
+
+// rows 0-31 of a split row image x this wave's 32 weight columns (32-row tiles of the two-workgroup kernels)
+__device__ __forceinline__ void mma32_b3(const void* img, int row0, const MmB3::Frag& f, floatx16& acc, int li, int lg) {
+  const __bf16* p0 = reinterpret_cast<const __bf16*>(img) + (row0 + li) * BP + 8 * lg;
+#pragma unroll
+  for (int c = 0; c < BKC; ++c) {
+    bf16x8 a0[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a0[s] = *reinterpret_cast<const bf16x8*>(p0 + s * BIMG + 16 * c);
+    mfb(acc, a0[2], f.w[c][0]);
+    mfb(acc, a0[0], f.w[c][2]);
+    mfb(acc, a0[1], f.w[c][1]);
+    mfb(acc, a0[1], f.w[c][0]);
+    mfb(acc, a0[0], f.w[c][1]);
+    mfb(acc, a0[0], f.w[c][0]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Split-bf16 fragment pack: Wp3[cb][c][s][lane] (bf16x8), s = hi/mid/lo;
+//   NT: element j of lane (i,g) = W[(cb*32 + i) * ld + 16c + 8g + j];  NN: W[(16c + 8g + j) * ld + cb*32 + i]
+__global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int nn, bf16x8* __restrict__ Wp) {
+  const int total = ncb * BKC * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % BKC, cb = idx / (64 * BKC);
+    const int i = lane & 31, g = lane >> 5;
+    bf16x8 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * c + 8 * g + j;
+      const float x = nn ? W[(int64_t)k * ld + cb * 32 + i] : W[(int64_t)(cb * 32 + i) * ld + k];
+      const __bf16 h = (__bf16)x;
+      const float r1 = x - (float)h;
+      const __bf16 m = (__bf16)r1;
+      hi[j] = h;
+      mid[j] = m;
+      lo[j] = (__bf16)(r1 - (float)m);
+    }
+    bf16x8* o = Wp + ((int64_t)(cb * BKC + c) * 3) * 64 + lane;
+    o[0] = hi;
+    o[64] = mid;
+    o[128] = lo;
+  }
+}
+
+static int g_matmul_mode = 1;   // 0: fp32 MFMA, 1: bf16x3 split (default since round 2: same parity bars, 2.7x the matrix rate)
+constexpr size_t kPackBytesPerBlk = MmB3::kPackBytes;   // workspace sizing: the larger of the two
+
+template <class MM>
+static void launch_pack(const float* W, int64_t ld, int ncb, int nn, void* wp, hipStream_t st) {
+  if (MM::kSplit) hipLaunchKernelGGL(pack_w3_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (bf16x8*)wp);
+  else hipLaunchKernelGGL(pack_w_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (float*)wp);
+}
+
+// ------------------------------------------------------------------------------------------
+// Y[:, cg*128 + c] = X W_cg^T + bias   (+ gathers and column statistics when EDGE)
+// One workgroup per CU = one wave per SIMD with the whole 512-entry register file.
+// ------------------------------------------------------------------------------------------
+// NCG (number of 128-column groups) is a template parameter so that the column-group loop unrolls:
+// a loop with a run-time trip count around the stores would defeat the vmcnt counting below.
+template <class MM, bool EDGE, int NCG>
+__global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE && !MM::kSplit)) ? 2 : 1) void rowtile_nt_k(
+    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ Y, int64_t ldy, const float* __restrict__ P,
+    const int32_t* __restrict__ isrc, const int32_t* __restrict__ idst, double* __restrict__ partials,
+    int64_t tiles_per_block, int ncgs) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];   // X tile image(s)
+  constexpr bool INPLACE = EDGE || NCG == 1;  // the output image may overwrite the X image
+  __shared__ float ys[INPLACE ? 4 : FTR * FP];   // node mode: output image (X is reused by 5 column groups)
+  __shared__ int sd[2 * FTR];
+  float* xs = reinterpret_cast<float*>(xraw);   // edge mode: reused as the fp32 output image
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  // ncgs > 1: the output's 128-column groups are spread over workgroups (weights stay in VGPRs for
+  // the whole run); the ncgs workgroups of a row range sit on one XCD and share the X tiles in its L2.
+  int chunk = xcd_chunk(blockIdx.x, gridDim.x), cgb = 0;
+  if (ncgs > 1) {
+    const int xcd = blockIdx.x % kXcds, j = blockIdx.x / kXcds;
+    cgb = j % ncgs;
+    chunk = xcd * (gridDim.x / ncgs / kXcds) + j / ncgs;
+  }
+  const int64_t ntiles = (M + FTR - 1) / FTR;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, M / FTR);      // tiles [tb0, nfull) are full
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;   // this thread's slot in the coalesced tile image
+  const int64_t Mlast = M - 1;
+
+  typename MM::Frag wf;
+  auto load_w = [&](int cg) __attribute__((always_inline)) { MM::load_w(wf, Wp, (cgb + cg) * 4 + wave, lane); };
+  constexpr int ncg = NCG;
+  if (ncg == 1) load_w(0);
+
+  float4 pre[8];
+  int pre_idx = 0;
+  // branch-free: rows past the end are clamped to the last row (their results are never stored)
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile * FTR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const float* px = X + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4;
+      pre[it] = EDGE ? ld4_nt(px) : ld4(px);      // edge rows stream through once; keep L2 for the gathered node rows
+    }
+    if (EDGE) {
+      const int64_t r = clampi(r0 + (tid & (FTR - 1)), Mlast);
+      pre_idx = (tid & FTR) ? idst[r] : isrc[r];     // threads 0-63: src, 64-127: dst (128-255 unused)
+    }
+  };
+
+  Stat4 st;
+  st.zero();
+  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    __syncthreads();   // everyone is done with the previous tile's LDS images
+#pragma unroll
+    for (int it = 0; it < 8; ++it) MM::stage(xraw, lrow + 8 * it, lc4, pre[it]);
+    if (EDGE && tid < 2 * FTR) sd[tid] = pre_idx;
+    __syncthreads();
+    const int64_t r0 = tile * FTR;
+    // gathers of this tile's B1h[src] / B2h[dst] rows: issued now, consumed in the epilogue
+    // (two workgroups per CU in the fp32 edge kernel: the gathers are issued after the MFMAs instead,
+    //  the other workgroup's MFMAs cover their latency, and the kernel fits 256 VGPRs)
+    constexpr bool LATE = EDGE && !MM::kSplit;
+    float4 g1[8], g2[8];
+    if (EDGE && !LATE) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t s_ = sd[row], d_ = sd[FTR + row];
+        g1[it] = ld4(P + s_ * (5 * FH) + 3 * FH + lc4);
+        g2[it] = ld4(P + d_ * (5 * FH) + 4 * FH + lc4);
+      }
+    }
+    prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // next tile's X rows, in flight under the MFMAs
+#pragma unroll
+    for (int cg = 0; cg < ncg; ++cg) {
+      if (ncg > 1) load_w(cg);
+      floatx16 acc0, acc1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+      MM::mma(xraw, wf, acc0, acc1, li, lg);
+      if (LATE) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = lrow + 8 * it;
+          const int64_t s_ = sd[row], d_ = sd[FTR + row];
+          g1[it] = ld4(P + s_ * (5 * FH) + 3 * FH + lc4);
+          g2[it] = ld4(P + d_ * (5 * FH) + 4 * FH + lc4);
+        }
+      }
+      float* os = INPLACE ? xs : ys;
+      if (INPLACE) __syncthreads();         // all waves are done reading the X image
+      else if (cg > 0) __syncthreads();     // previous column group's epilogue is done with ys
+      acc_to_lds(os, acc0, acc1, wave, li, lg);
+      __syncthreads();
+      const float4 b4 = ld4(bias + (cgb + cg) * FH + lc4);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        float4 v = ld4(os + row * FP + lc4) + b4;
+        if (EDGE) v = v + g1[it] + g2[it];
+        if (FULL || grow < M) {
+          if (EDGE) st4_nt(Y + grow * ldy + (cgb + cg) * FH + lc4, v);
+          else st4(Y + grow * ldy + (cgb + cg) * FH + lc4, v);
+          if (EDGE) st.add_prod(v, v);
+        }
+      }
+    }
+  };
+
+  if (tb0 < tb1) prefetch(tb0);
+  if (tb0 < nfull) {
+    // throw-away stores behind the first prefetch (same addresses the first epilogue rewrites):
+    // they make the loop-entry scoreboard equal to the back edge's, see edge_bwd_fused_k
+#pragma unroll
+    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * ldy + cgb * FH + lc4, f4(0.f));
+    for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
+  }
+  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
+  if (EDGE) {
+    __syncthreads();   // the last epilogue is done with the LDS image we reuse for the reduction
+    block_stat_store<FH>(st, reinterpret_cast<double*>(xs), partials, chunk);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-mode edge t kernel with 32-row tiles: t = e W3^T + b3 + B1h[src] + B2h[dst] + BatchNorm sums.
+// 69 KB of LDS and <= 256 VGPRs -> two workgroups per CU (the 64-row version needs 330 registers, and
+// with one wave per SIMD its split staging and epilogue leave the matrix pipe 32 % busy).  The two
+// 32-row halves of the three bf16 images are two tile buffers, the fp32 output image is separate.
+// ------------------------------------------------------------------------------------------
+constexpr int ER3 = 32;
+__global__ __launch_bounds__(kBlock, 2) void edge_t32_b3_k(
+    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
+    const int32_t* __restrict__ idst, double* __restrict__ partials, int64_t tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ float os[ER3 * FP];
+  __shared__ int sd[2][2 * ER3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (M + ER3 - 1) / ER3;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, M / ER3);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  const int32_t* const ibase = (lane & 32) ? idst : isrc;     // lanes 0-31: src of row lane, 32-63: dst of row lane-32
+
+  MmB3::Frag wf;
+  MmB3::load_w(wf, Wp, wave, lane);
+  const float4 b4 = ld4(bias + lc4);
+  float4 pre[2][4];
+  int pidx[2] = {0, 0};
+  auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+    idx = ibase[clampi(r0 + (lane & 31), Mlast)];
+  };
+  Stat4 st;
+  st.zero();
+  auto body = [&](auto tag, float4 (&buf)[4], int& idx, int64_t tile, int hb) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * hb + lrow + 8 * it, lc4, buf[it]);
+    sd[hb][lane] = idx;
+    __syncthreads();
+    float4 g1[4], g2[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t s_ = sd[hb][row], d_ = sd[hb][ER3 + row];
+      g1[it] = ld4(P + s_ * (5 * FH) + 3 * FH + lc4);
+      g2[it] = ld4(P + d_ * (5 * FH) + 4 * FH + lc4);
+    }
+    prefetch(buf, idx, tile + 2);
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    mma32_b3(xraw, 32 * hb, wf, acc, li, lg);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) os[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t grow = r0 + row;
+      const float4 v = ld4(os + row * FP + lc4) + b4 + g1[it] + g2[it];
+      if (FULL || grow < M) {
+        st4_nt(Y + grow * FH + lc4, v);
+        st.add_prod(v, v);
+      }
+    }
+  };
+  if (tb0 < tb1) {
+    prefetch(pre[0], pidx[0], tb0);
+    prefetch(pre[1], pidx[1], tb0 + 1);
+  }
+  int64_t tile = tb0;
+  for (; tile + 2 <= nfull; tile += 2) {
+    body(full_t{}, pre[0], pidx[0], tile, 0);
+    body(full_t{}, pre[1], pidx[1], tile + 1, 1);
+  }
+  // at most one more full tile and one ragged tile
+  int hb = 0;
+  for (; tile < tb1; ++tile, hb ^= 1) {
+    if (hb == 0) body(ragged_t{}, pre[0], pidx[0], tile, 0);
+    else body(ragged_t{}, pre[1], pidx[1], tile, 1);
+  }
+  __syncthreads();
+  block_stat_store<FH>(st, reinterpret_cast<double*>(xraw), partials, chunk);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused edge backward: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
+// ------------------------------------------------------------------------------------------
+template <class MM>
+__global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
+    int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
+    const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
+    const void* __restrict__ Wp,                     // W3 packed NN
+    float* __restrict__ slab,                        // [grid][128][128] partial gW3
+    double* __restrict__ partials,                   // [grid][128]: per-workgroup column sums of gt
+    int64_t tiles_per_block) {
+  // fp32 mode:  [gt row image | e_in row image]                      (the gt image doubles as the NN operand)
+  // split mode: [gt split row images (NN) | gt transposed split | e_in transposed split]   = 159 KB
+  constexpr int kNnBytes = MM::kSplit ? MM::kImgBytes : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kNnBytes + MM::kTnBytes];
+  float* gs = reinterpret_cast<float*>(raw + kNnBytes);          // fp32 mode
+  float* es = gs + FTR * FP;
+  unsigned char* tg = raw + kNnBytes;                            // split mode
+  unsigned char* te = tg + MM::kTnBytes / 2;
+  float* os = reinterpret_cast<float*>(raw);                     // transposed output image (after the MFMAs)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (E + FTR - 1) / FTR;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, E / FTR);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Elast = E - 1;
+
+  // per-column constants of this thread's 4 columns: mu, rstd, scale, shift, m1, m2, c = gamma*rstd
+  const float4 mu = ld4(stat + lc4), rs = ld4(stat + FH + lc4), sc = ld4(stat + 2 * FH + lc4),
+               sh = ld4(stat + 3 * FH + lc4), m1 = ld4(bstat + lc4), m2 = ld4(bstat + FH + lc4),
+               cc = ld4(gamma + lc4) * rs;
+  typename MM::Frag wf;
+  MM::load_w(wf, Wp, wave, lane);
+  floatx16 tn[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
+  double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;   // column sums of gt for columns lc4..lc4+3
+
+  // ge / t / e_in rows of a tile are prefetched one tile ahead (96 VGPRs), under the MFMA phases
+  float4 pg[8], pt[8], pe_[8];
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile * FTR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t o = clampi(r0 + MM::row(lrow, it), Elast) * FH + lc4;
+      pg[it] = ld4(ge + o);
+      pt[it] = ld4(t + o);
+      pe_[it] = ld4(e_in + o);
+    }
+  };
+
+  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * FTR;
+    // ---- phase 0: gt tile and e_in tile into LDS ----
+    float4 gk[8];   // this tile's ge rows, kept for the residual add in the epilogue
+    {
+      float4 gtv[8], evv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const bool ok = FULL || (r0 + MM::row(lrow, it) < E);
+        gk[it] = pg[it];
+        const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
+        float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
+        float4 ev = pe_[it];
+        if (!ok) { gt = f4(0.f); ev = f4(0.f); }
+        cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
+        gtv[it] = gt;
+        evv[it] = ev;
+      }
+      if (MM::kSplit) {
+        Split8 sp;
+        split_rows(gtv, sp);
+        stage_rows(raw, lrow, lc4, sp);
+        stage_cols(tg, lrow, lc4, sp);
+        split_rows(evv, sp);
+        stage_cols(te, lrow, lc4, sp);
+      } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          st4(gs + MM::row(lrow, it) * FP + lc4, gtv[it]);
+          st4(es + MM::row(lrow, it) * FP + lc4, evv[it]);
+        }
+      }
+    }
+    __syncthreads();
+    prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // in flight under the MFMAs below
+    // ---- MFMA phases: acc = gt W3 (this wave: output columns wave*32 .. +31) and
+    //      gW3[n][c] += sum_rows gt[row][n] e_in[row][c] (this wave: 64 x 64 block).  Split mode runs
+    //      the TN part first so that acc is not live across it (register budget). ----
+    floatx16 acc0, acc1;
+    if (MM::kSplit) mma_tn64_b3<false>(tg, te, tn, wn, wc, li, lg);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    MM::mma(MM::kSplit ? (const void*)raw : (const void*)gs, wf, acc0, acc1, li, lg);
+    if (!MM::kSplit) mma_tn64(gs, es, tn, wn, wc, li, lg);
+    __syncthreads();   // operand images are dead: reuse the front of the buffer as the output image
+    acc_to_lds(os, acc0, acc1, wave, li, lg);
+    __syncthreads();
+    // ---- ge_in = ge + gt W3, whole 512-byte rows, one float4 per lane ----
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = MM::row(lrow, it);
+      const int64_t grow = r0 + row;
+      if (FULL || grow < E) st4(ge_out + grow * FH + lc4, ld4(os + row * FP + lc4) + gk[it]);
+    }
+    __syncthreads();   // the buffer is rewritten by the next tile's phase 0
+  };
+
+  if (tb0 < tb1) prefetch(tb0);
+  // hipcc merges the vector-memory scoreboard of the loop entry with that of the back edge and
+  // keeps the weaker guarantee: without stores behind the first prefetch it would wait vmcnt(0)
+  // (= for the previous tile's stores) before the last prefetched row on EVERY iteration.  Eight
+  // throw-away stores into this workgroup's slab (rewritten at the end) make both edges alike.
+#pragma unroll
+  for (int it = 0; it < 8; ++it) st4(slab + (size_t)chunk * FH * FH + (lrow + 8 * it) * FH + lc4, f4(0.f));
+  for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
+  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
+
+  // ---- write the partial gW3 slab and the column sums ----
+  float* sl = slab + (size_t)chunk * FH * FH;
+  tn_store_slab<MM>(sl, tn, wn, wc, li, lg);
+  // 8 row-slots (lrow) x 128 columns -> 128 column sums (the tile images are free now)
+  double* red = reinterpret_cast<double*>(raw);
+  red[lrow * FH + lc4 + 0] = cg0;
+  red[lrow * FH + lc4 + 1] = cg1;
+  red[lrow * FH + lc4 + 2] = cg2;
+  red[lrow * FH + lc4 + 3] = cg3;
+  __syncthreads();
+  if (tid < FH) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k * FH + tid];
+    partials[(size_t)chunk * FH + tid] = s;
+  }
+}
+
+// fp32 variant with 32-row tiles: 236 VGPRs and 37 KB of LDS, so TWO workgroups share a CU and one's
+// gt prologue / epilogue runs under the other's MFMAs (the 64-row kernel above holds 416 registers
+// and leaves the matrix pipe idle during those phases: 68 % busy).
+constexpr int FTR2 = 32;
+
+__global__ __launch_bounds__(kBlock, 2) void edge_bwd_fused32_k(
+    int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
+    const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
+    const void* __restrict__ Wp, float* __restrict__ slab, double* __restrict__ partials, int64_t tiles_per_block) {
+  __shared__ float gs[FTR2 * FP];      // gt tile, later the transposed output image
+  __shared__ float es[FTR2 * FP];      // e_in tile
+  __shared__ float cs[7 * FH];         // mu, rstd, scale, shift, m1, m2, c = gamma*rstd
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (E + FTR2 - 1) / FTR2;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, E / FTR2);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Elast = E - 1;
+  for (int c = tid; c < FH; c += kBlock) {
+    cs[c] = stat[c];
+    cs[FH + c] = stat[FH + c];
+    cs[2 * FH + c] = stat[2 * FH + c];
+    cs[3 * FH + c] = stat[3 * FH + c];
+    cs[4 * FH + c] = bstat[c];
+    cs[5 * FH + c] = bstat[FH + c];
+    cs[6 * FH + c] = gamma[c] * stat[FH + c];
+  }
+  MmF32::Frag wf;
+  MmF32::load_w(wf, Wp, wave, lane);
+  floatx16 tn[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
+  double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;
+  __syncthreads();
+
+  float4 pg[4], pt[4], pe_[4];
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile * FTR2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t o = clampi(r0 + lrow + 8 * it, Elast) * FH + lc4;
+      pg[it] = ld4(ge + o);
+      pt[it] = ld4(t + o);
+      pe_[it] = ld4(e_in + o);
+    }
+  };
+  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * FTR2;
+    float4 gk[4];
+    {
+      const float4 mu = ld4(cs + lc4), rs = ld4(cs + FH + lc4), sc = ld4(cs + 2 * FH + lc4),
+                   sh = ld4(cs + 3 * FH + lc4), m1 = ld4(cs + 4 * FH + lc4), m2 = ld4(cs + 5 * FH + lc4),
+                   cc = ld4(cs + 6 * FH + lc4);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = lrow + 8 * it;
+        const bool ok = FULL || (r0 + row < E);
+        gk[it] = pg[it];
+        const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
+        float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
+        float4 ev = pe_[it];
+        if (!ok) { gt = f4(0.f); ev = f4(0.f); }
+        cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
+        st4(gs + row * FP + lc4, gt);
+        st4(es + row * FP + lc4, ev);
+      }
+    }
+    __syncthreads();
+    prefetch(tile + 1 < tb1 ? tile + 1 : tile);
+    // ---- acc = gt W3 (32 rows x this wave's 32 columns) ----
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    {
+      const float* p0 = gs + li * FP + 4 * lg;
+      float4 a0 = ld4(p0);
+#pragma unroll
+      for (int q = 0; q < FKQ; ++q) {
+        float4 n0 = a0;
+        if (q + 1 < FKQ) n0 = ld4(p0 + 8 * (q + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(acc, a0, wf.w[q]);
+        a0 = n0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- gW3[n][c] += sum_rows gt[row][n] e_in[row][c] over the tile's 32 rows ----
+    {
+      const float* ga = gs + 4 * lg * FP + li;
+      const float* eb = es + 4 * lg * FP + li;
+#pragma unroll
+      for (int q = 0; q < FTR2 / 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (8 * q + r) * FP;
+          const float a0 = ga[o + (2 * wn) * 32], a1 = ga[o + (2 * wn + 1) * 32];
+          const float b0 = eb[o + (2 * wc) * 32], b1 = eb[o + (2 * wc + 1) * 32];
+          tn[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, tn[0][0], 0, 0, 0);
+          tn[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, tn[0][1], 0, 0, 0);
+          tn[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, tn[1][0], 0, 0, 0);
+          tn[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, tn[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();   // gt / e_in images are dead: reuse gs as the transposed output image
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gs[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t grow = r0 + row;
+      if (FULL || grow < E) st4(ge_out + grow * FH + lc4, ld4(gs + row * FP + lc4) + gk[it]);
+    }
+    __syncthreads();
+  };
+  if (tb0 < tb1) prefetch(tb0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) st4(slab + (size_t)chunk * FH * FH + (lrow + 8 * it) * FH + lc4, f4(0.f));   // see edge_bwd_fused_k
+  for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
+  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
+
+  tn_store_slab<MmF32>(slab + (size_t)chunk * FH * FH, tn, wn, wc, li, lg);
+  double* red = reinterpret_cast<double*>(gs);     // 8 row-slots x 128 doubles = 8 KB
+  red[lrow * FH + lc4 + 0] = cg0;
+  red[lrow * FH + lc4 + 1] = cg1;
+  red[lrow * FH + lc4 + 2] = cg2;
+  red[lrow * FH + lc4 + 3] = cg3;
+  __syncthreads();
+  if (tid < FH) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_ += red[k * FH + tid];
+    partials[(size_t)chunk * FH + tid] = s_;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// node-level backward of the 5-way projection (autograd of gated_gcn_full.py:107-112):
+//   rowtile_nn_acc_k   gh_in = gh_out + gP W5            (K = 5*128, accumulated over 5 groups)
+//   tn_colgroup_k      gW5[cg] = gP[:,cg]^T h_in, gb5[cg] = sum gP[:,cg]   (5 workgroup classes)
+// ------------------------------------------------------------------------------------------
+template <class MM>
+__global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void rowtile_nn_acc_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const void* __restrict__ Wp,
+    const float* __restrict__ R, float* __restrict__ Y, int64_t tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (M + FTR - 1) / FTR;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, M / FTR);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  float4 pre[8];
+  auto prefetch = [&](int64_t tile, int cg) __attribute__((always_inline)) {
+    const int64_t r0 = tile * FTR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) pre[it] = ld4(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * FTR;
+    float4 rr[8];   // residual rows, consumed in the epilogue
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rr[it] = ld4(R + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    for (int cg = 0; cg < ncg; ++cg) {
+      typename MM::Frag wf;
+      MM::load_w(wf, Wp, cg * 4 + wave, lane);
+      __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+      for (int it = 0; it < 8; ++it) MM::stage(xraw, lrow + 8 * it, lc4, pre[it]);
+      __syncthreads();
+      if (cg + 1 < ncg) prefetch(tile, cg + 1);
+      else prefetch(tile + 1 < tb1 ? tile + 1 : tile, 0);
+      MM::mma(xraw, wf, acc0, acc1, li, lg);
+    }
+    __syncthreads();
+    acc_to_lds(xs, acc0, acc1, wave, li, lg);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t grow = r0 + row;
+      if (FULL || grow < M) st4(Y + grow * FH + lc4, ld4(xs + row * FP + lc4) + rr[it]);
+    }
+  };
+  if (tb0 < tb1) prefetch(tb0, 0);
+  if (tb0 < nfull) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * FH + lc4, f4(0.f));   // see edge_bwd_fused_k
+    for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
+  }
+  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
+}
+
+// Split-mode variant: the weight fragments of a column group (96 VGPRs) are loaded once per GROUP of
+// T row tiles whose accumulators stay in registers -- in split mode the MFMAs are cheap enough that
+// re-reading 5 x 96 KB of fragments from L2 for every 64-row tile was the bound.
+template <class MM, int T>
+__global__ __launch_bounds__(kBlock, 1) void rowtile_nn_group_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const void* __restrict__ Wp,
+    const float* __restrict__ R, float* __restrict__ Y, int64_t groups_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ngroups = (M + FTR * T - 1) / (FTR * T);
+  const int64_t g0 = (int64_t)chunk * groups_per_block;
+  const int64_t g1 = min(ngroups, g0 + groups_per_block);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  // Two steps (tile, column group) of rows in flight: with cheap MFMAs one step is shorter than the
+  // HBM latency.  T is even, so the buffer parity of a step is its tile index within the group.
+  static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
+  float4 pre[2][8];
+  auto prefetch = [&](float4 (&buf)[8], int64_t g, int cg, int tl) __attribute__((always_inline)) {
+    if (tl >= T) { tl -= T; ++cg; }
+    if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
+    const int64_t r0 = (g * T + tl) * FTR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) buf[it] = ld4(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  if (g0 < g1) {
+    prefetch(pre[0], g0, 0, 0);
+    prefetch(pre[1], g0, 0, 1);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t t0 = g * T;
+    floatx16 acc[T][2];
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[tl][0][e] = 0.f; acc[tl][1][e] = 0.f; }
+    for (int cg = 0; cg < ncg; ++cg) {
+      typename MM::Frag wf;
+      MM::load_w(wf, Wp, cg * 4 + wave, lane);
+#pragma unroll
+      for (int tl = 0; tl < T; ++tl) {
+        __syncthreads();   // previous fragment reads are done
+#pragma unroll
+        for (int it = 0; it < 8; ++it) MM::stage(xraw, lrow + 8 * it, lc4, pre[tl & 1][it]);
+        __syncthreads();
+        prefetch(pre[tl & 1], g, cg, tl + 2);
+        MM::mma(xraw, wf, acc[tl][0], acc[tl][1], li, lg);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) {
+      const int64_t r0 = (t0 + tl) * FTR;
+      float4 rr[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) rr[it] = ld4(R + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+      __syncthreads();
+      acc_to_lds(xs, acc[tl][0], acc[tl][1], wave, li, lg);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        if (grow < M) st4(Y + grow * FH + lc4, ld4(xs + row * FP + lc4) + rr[it]);
+      }
+    }
+  }
+}
+
+// The same with 32-row tiles: 26 KB of LDS and <= 256 VGPRs -> two workgroups per CU, so that the split
+// staging of one overlaps the MFMAs of the other.
+constexpr int NR3 = 32;
+template <int T>
+__global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const void* __restrict__ Wp,
+    const float* __restrict__ R, float* __restrict__ Y, int64_t groups_per_block) {
+  // the three bf16 images keep the 64-row layout of MmB3::stage; rows 0-31 / 32-63 are two tile buffers,
+  // so a step needs ONE barrier (the next step stages into the half the slower waves are not reading)
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);                    // later: 32 x 132 fp32 output image
+  static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ngroups = (M + NR3 * T - 1) / (NR3 * T);
+  const int64_t g0 = (int64_t)chunk * groups_per_block;
+  const int64_t g1 = min(ngroups, g0 + groups_per_block);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  // T steps (one whole column group of the row group) of rows in flight: a 32-row step of cheap MFMAs is
+  // far shorter than the HBM latency.  pre[tl] always holds tile tl of the NEXT column group.
+  float4 pre[T][4];
+  auto prefetch = [&](float4 (&buf)[4], int64_t g, int cg, int tl) __attribute__((always_inline)) {
+    if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
+    const int64_t r0 = (g * T + tl) * NR3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  if (g0 < g1) {
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) prefetch(pre[tl], g0, 0, tl);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t t0 = g * T;
+    floatx16 acc[T];
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
+    for (int cg = 0; cg < ncg; ++cg) {
+      MmB3::Frag wf;
+      MmB3::load_w(wf, Wp, cg * 4 + wave, lane);
+#pragma unroll
+      for (int tl = 0; tl < T; ++tl) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        __syncthreads();
+        prefetch(pre[tl], g, cg + 1, tl);
+        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) {
+      const int64_t r0 = (t0 + tl) * NR3;
+      float4 rr[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) rr[it] = ld4(R + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+      __syncthreads();   // MFMAs (first pass) / the previous tile's row reads are done with the image memory
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xs[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[tl][e];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        if (grow < M) st4(Y + grow * FH + lc4, ld4(xs + row * FP + lc4) + rr[it]);
+      }
+    }
+    __syncthreads();   // the output image overlays both tile buffers: done before the next group stages
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// General row GEMM in split mode (the hidden sizes the fused 128-wide kernels are not built for, e.g. the reference's
+// own default 256):  Y[r][cls*128 + c] = sum_cg X[r][cg*128 + k] Wblk[cls][cg][k][c]  (+ bias, + R, relu)
+// with K = ncg * 128 and N = ncls * 128.  The kernel above with an output-column class per workgroup: the ncls
+// workgroups of a row chunk sit on one XCD (workgroup b runs on XCD b % 8) and read the same X rows through its L2.
+// R may be Y (ge = ge + gt W3 in place): a thread reads its R elements before it stores the same Y elements.
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kBlock, 2) void gemm_rows_b3_k(
+    int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, int ncls, const void* __restrict__ Wp,
+    const float* __restrict__ bias, const float* R, int64_t ldr, int relu, float* Y, int64_t ldy, int nchunk,
+    int64_t groups_per_chunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  float* xs = reinterpret_cast<float*>(xraw);
+  static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;
+  const int cls = jj % ncls, chunk = xcd * (nchunk / kXcds) + jj / ncls;
+  const int64_t ngroups = (M + NR3 * T - 1) / (NR3 * T);
+  const int64_t g0 = (int64_t)chunk * groups_per_chunk;
+  const int64_t g1 = min(ngroups, g0 + groups_per_chunk);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  float4 pre[T][4];
+  auto prefetch = [&](float4 (&buf)[4], int64_t g, int cg, int tl) __attribute__((always_inline)) {
+    if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
+    const int64_t r0 = (g * T + tl) * NR3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  if (g0 < g1) {
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) prefetch(pre[tl], g0, 0, tl);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t t0 = g * T;
+    floatx16 acc[T];
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
+    for (int cg = 0; cg < ncg; ++cg) {
+      MmB3::Frag wf;
+      MmB3::load_w(wf, Wp, (cls * ncg + cg) * 4 + wave, lane);
+#pragma unroll
+      for (int tl = 0; tl < T; ++tl) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        __syncthreads();
+        prefetch(pre[tl], g, cg + 1, tl);
+        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) {
+      const int64_t r0 = (t0 + tl) * NR3;
+      const float4 bv = bias ? ld4(bias + cls * FH + lc4) : f4(0.f);
+      float4 rr[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        rr[it] = R ? ld4(R + clampi(r0 + lrow + 8 * it, Mlast) * ldr + cls * FH + lc4) + bv : bv;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xs[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[tl][e];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        float4 v = ld4(xs + row * FP + lc4) + rr[it];
+        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (grow < M) st4(Y + grow * ldy + cls * FH + lc4, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// fragment blocks of the [K = ncg*128] x [N = ncls*128] weight for gemm_rows_b3_k: block ((cls*ncg + cg)*4 + wv) in the
+// layout of pack_w3_k;  NT: W is [N,K] row-major (y = x W^T),  NN: W is [K,N] row-major (y = x W)
+__global__ void pack_w3_gen_k(const float* __restrict__ W, int64_t ld, int ncls, int ncg, int nn, bf16x8* __restrict__ Wp) {
+  const int total = ncls * ncg * 4 * BKC * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % BKC, blk = idx / (64 * BKC);
+    const int wv = blk & 3, cg = (blk >> 2) % ncg, cls = (blk >> 2) / ncg;
+    const int i = lane & 31, g = lane >> 5;
+    const int64_t n = (int64_t)cls * FH + wv * 32 + i;
+    bf16x8 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = (int64_t)cg * FH + 16 * c + 8 * g + j;
+      const float x = nn ? W[k * ld + n] : W[n * ld + k];
+      const __bf16 h = (__bf16)x;
+      const float r1 = x - (float)h;
+      const __bf16 m = (__bf16)r1;
+      hi[j] = h;
+      mid[j] = m;
+      lo[j] = (__bf16)(r1 - (float)m);
+    }
+    bf16x8* o = Wp + ((int64_t)(blk * BKC + c) * 3) * 64 + lane;
+    o[0] = hi;
+    o[64] = mid;
+    o[128] = lo;
+  }
+}
+
+// slab[(cg*nslot + slot)][n][c] = sum over the slot's rows of A[row][cg*128+n] * B[row][c];
+// partials[(cg*nslot + slot)][128] = column sums of A[:, cg*128 ..]
+template <class MM>
+__global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void tn_colgroup_k(
+    int64_t M, const float* __restrict__ A, int64_t lda, int ncg, const float* __restrict__ B,
+    float* __restrict__ slab, double* __restrict__ partials, int nslot, int64_t tiles_per_slot) {
+  __shared__ __attribute__((aligned(16))) unsigned char raw[MM::kTnBytes];
+  float* as = reinterpret_cast<float*>(raw);             // fp32 mode: two row images
+  float* bs = as + FTR * FP;
+  unsigned char* ta = raw;                               // split mode: two transposed images
+  unsigned char* tb = raw + MM::kTnBytes / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  // The ncg workgroups of a slot read the same B rows: keep them on one XCD (workgroup b runs on XCD
+  // b % 8) so that the tile comes out of that XCD's L2 instead of HBM ncg times.  nslot % 8 == 0.
+  const int xcd = blockIdx.x % kXcds, j = blockIdx.x / kXcds;
+  const int cg = j % ncg, slot = xcd * (nslot / kXcds) + j / ncg;
+  const int64_t ntiles = (M + FTR - 1) / FTR;
+  const int64_t tb0 = (int64_t)slot * tiles_per_slot;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_slot);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  floatx16 tn[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+  // loads only (no stores in the loop): clamped and branch-free, rows past the end are zeroed below.
+  // (Two tiles in flight were tried for split mode: hipcc then waits vmcnt(0) on the newer prefetch
+  // and the kernel gets slower; DEPTH stays 1.)
+  constexpr int DEPTH = 1;
+  float4 pa[DEPTH][8], pb[DEPTH][8];
+  auto prefetch = [&](float4 (&qa)[8], float4 (&qb)[8], int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * FTR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t r = clampi(r0 + MM::row(lrow, it), Mlast);
+      qa[it] = ld4(A + r * lda + cg * FH + lc4);
+      qb[it] = ld4(B + r * FH + lc4);
+    }
+  };
+  auto step = [&](float4 (&qa)[8], float4 (&qb)[8], int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile * FTR;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const bool ok = r0 + MM::row(lrow, it) < M;
+      if (!ok) qa[it] = f4(0.f);
+      const float4 av = qa[it];
+      c0 += (double)av.x; c1 += (double)av.y; c2 += (double)av.z; c3 += (double)av.w;
+      if (!MM::kSplit) {
+        st4(as + MM::row(lrow, it) * FP + lc4, av);
+        st4(bs + MM::row(lrow, it) * FP + lc4, qb[it]);
+      }
+    }
+    if (MM::kSplit) {
+      Split8 sp;
+      split_rows(qa, sp);
+      stage_cols(ta, lrow, lc4, sp);
+      split_rows(qb, sp);
+      stage_cols(tb, lrow, lc4, sp);
+    }
+    __syncthreads();
+    prefetch(qa, qb, tile + DEPTH);
+    if (MM::kSplit) mma_tn64_b3<true>(ta, tb, tn, wn, wc, li, lg);
+    else mma_tn64(as, bs, tn, wn, wc, li, lg);
+  };
+  if (tb0 < tb1) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) prefetch(pa[d], pb[d], tb0 + d);
+    int64_t tile = tb0;
+    for (; tile + DEPTH <= tb1; tile += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) step(pa[d], pb[d], tile + d);
+    }
+    if (DEPTH == 2 && tile < tb1) step(pa[0], pb[0], tile);
+  }
+  float* sl = slab + (size_t)(cg * nslot + slot) * FH * FH;
+  tn_store_slab<MM>(sl, tn, wn, wc, li, lg);
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(raw);
+  red[lrow * FH + lc4 + 0] = c0;
+  red[lrow * FH + lc4 + 1] = c1;
+  red[lrow * FH + lc4 + 2] = c2;
+  red[lrow * FH + lc4 + 3] = c3;
+  __syncthreads();
+  if (tid < FH) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_ += red[k * FH + tid];
+    partials[(size_t)(cg * nslot + slot) * FH + tid] = s_;
+  }
+}
+
+// Split-mode TN with 32-row tiles: 61 KB of LDS and < 256 VGPRs, so two workgroups share a CU and one's
+// split / transposition VALU work runs under the other's MFMAs (with 64-row tiles and one workgroup per
+// CU the matrix pipe was 26 % busy).  A thread owns rows 8*wave .. +7 x columns 2*lane, 2*lane+1 of both
+// operands (float2 loads, 512 B per row and wave); column c = 2*cp + j is kept in slot 64*j + cp, so the
+// two ds_write_b128 per operand and image go to 64 consecutive slots and a fragment read of slots
+// 32*blk .. +31 is conflict-free at pitch 40 (5 sixteen-byte units).  MFMA block blk, index i therefore
+// stands for column 64*(blk & 1) + 2*i + (blk >> 1).
+constexpr int TR3 = 32;                 // rows per tile
+constexpr int TP3 = TR3 + 8;            // bf16 pitch of a slot
+constexpr int TIMG3 = FH * TP3;         // elements per transposed image
+
+__device__ __forceinline__ int colmap32(int blk, int i) { return 64 * (blk & 1) + 2 * i + (blk >> 1); }
+
+__global__ __launch_bounds__(kBlock, 2) void tn_colgroup32_b3_k(
+    int64_t M, const float* __restrict__ A, int64_t lda, int ncg, const float* __restrict__ B,
+    float* __restrict__ slab, double* __restrict__ partials, int nslot, int64_t tiles_per_slot) {
+  __shared__ __attribute__((aligned(16))) __bf16 ta[3 * TIMG3];
+  __shared__ __attribute__((aligned(16))) __bf16 tb[3 * TIMG3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;      // see tn_colgroup_k
+  const int cg = jj % ncg, slot = xcd * (nslot / kXcds) + jj / ncg;
+  const int64_t ntiles = (M + TR3 - 1) / TR3;
+  const int64_t tb0 = (int64_t)slot * tiles_per_slot;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_slot);
+  const int64_t Mlast = M - 1;
+  floatx16 tn[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
+  double c0 = 0.0, c1 = 0.0;            // column sums of A for columns 2*lane, 2*lane + 1
+  float2 pa[8], pb[8];
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * TR3 + 8 * wave;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t r = clampi(r0 + it, Mlast);
+      pa[it] = *reinterpret_cast<const float2*>(A + r * lda + cg * FH + 2 * lane);
+      pb[it] = *reinterpret_cast<const float2*>(B + r * FH + 2 * lane);
+    }
+  };
+  // 8 rows x 2 columns of one operand -> its three transposed images
+  auto stage = [&](__bf16* img, const float2 (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 h, m, l;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const float x = j ? v[it].y : v[it].x;
+        const __bf16 hh = (__bf16)x;
+        const float r1 = x - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[it] = hh;
+        m[it] = mm;
+        l[it] = (__bf16)(r1 - (float)mm);
+      }
+      __bf16* o = img + (64 * j + lane) * TP3 + 8 * wave;
+      *reinterpret_cast<bf16x8*>(o) = h;
+      *reinterpret_cast<bf16x8*>(o + TIMG3) = m;
+      *reinterpret_cast<bf16x8*>(o + 2 * TIMG3) = l;
+    }
+  };
+  if (tb0 < tb1) prefetch(tb0);
+  for (int64_t tile = tb0; tile < tb1; ++tile) {
+    const int64_t r0 = tile * TR3 + 8 * wave;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      if (r0 + it >= M) pa[it] = make_float2(0.f, 0.f);
+      c0 += (double)pa[it].x;
+      c1 += (double)pa[it].y;
+    }
+    stage(ta, pa);
+    stage(tb, pb);
+    __syncthreads();
+    prefetch(tile + 1);
+    const __bf16* qa = ta + ((2 * wn) * 32 + li) * TP3 + 8 * lg;
+    const __bf16* qb = tb + ((2 * wc) * 32 + li) * TP3 + 8 * lg;
+#pragma unroll
+    for (int kc = 0; kc < TR3 / 16; ++kc) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+          a[x][s_] = *reinterpret_cast<const bf16x8*>(qa + s_ * TIMG3 + x * 32 * TP3 + 16 * kc);
+          b[x][s_] = *reinterpret_cast<const bf16x8*>(qb + s_ * TIMG3 + x * 32 * TP3 + 16 * kc);
+        }
+#pragma unroll
+      for (int t_ = 0; t_ < 6; ++t_) {
+        const int sa = t_ == 0 ? 2 : (t_ == 2 || t_ == 3) ? 1 : 0;
+        const int sb = t_ == 1 ? 2 : (t_ == 2 || t_ == 4) ? 1 : 0;
+        mfb(tn[0][0], a[0][sa], b[0][sb]);
+        mfb(tn[0][1], a[0][sa], b[1][sb]);
+        mfb(tn[1][0], a[1][sa], b[0][sb]);
+        mfb(tn[1][1], a[1][sa], b[1][sb]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* sl = slab + (size_t)(cg * nslot + slot) * FH * FH;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = colmap32(2 * wn + a, (e & 3) + 8 * (e >> 2) + 4 * lg);
+        const int c = colmap32(2 * wc + b, li);
+        sl[n * FH + c] = tn[a][b][e];
+      }
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(ta);          // [4 waves][128] doubles
+  red[wave * FH + 2 * lane] = c0;
+  red[wave * FH + 2 * lane + 1] = c1;
+  __syncthreads();
+  if (tid < FH) partials[(size_t)(cg * nslot + slot) * FH + tid] = red[tid] + red[FH + tid] + red[2 * FH + tid] + red[3 * FH + tid];
+}
+
+// out[i] = sum_b slab[b][i], fixed order -> deterministic
+__global__ void slab_reduce_k(const float* __restrict__ slab, int nslab, int total, float* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    // four independent chains (fixed order -> still deterministic): one chain of nslab dependent loads was
+    // the fixed cost that showed on small graphs
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* p = slab + i;
+    int b = 0;
+    for (; b + 3 < nslab; b += 4) {
+      a0 += p[(size_t)b * total];
+      a1 += p[(size_t)(b + 1) * total];
+      a2 += p[(size_t)(b + 2) * total];
+      a3 += p[(size_t)(b + 3) * total];
+    }
+    for (; b < nslab; ++b) a0 += p[(size_t)b * total];
+    out[i] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+// out[m * ldc + n] = sum_b slab[b][m][n] for one 128 x 128 block, fixed order -> deterministic
+__global__ void slab_reduce_ld_k(const float* __restrict__ slab, int nslab, float* __restrict__ out, int64_t ldc) {
+  constexpr int total = FH * FH;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* p = slab + i;
+    int b = 0;
+    for (; b + 3 < nslab; b += 4) {
+      a0 += p[(size_t)b * total];
+      a1 += p[(size_t)(b + 1) * total];
+      a2 += p[(size_t)(b + 2) * total];
+      a3 += p[(size_t)(b + 3) * total];
+    }
+    for (; b < nslab; ++b) a0 += p[(size_t)b * total];
+    out[(int64_t)(i / FH) * ldc + (i % FH)] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+}  // namespace gnm
+
+using namespace gnm;
+
+static inline int64_t cdiv_(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+namespace gnm {   // gnm_tr.hip: the split-mode TN kernel on swizzled row-major images + transpose reads
+int tn_tr_rows_per_tile();
+int tn_tr_occupancy();
+void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, int64_t ldb, int ncgb, float* slab,
+                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st);
+size_t edge_bwd_tr_pack_bytes();
+int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
+                       const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
+                       double* partials, hipStream_t st);
+}
+static int g_tn_variant = 1;     // split mode: 1 = tn_tr_k (transpose reads), 0 = tn_colgroup32_b3_k (round 1)
+static int g_eb_variant = 1;     // split mode: 1 = edge_bwd_tr_k (16-row tiles, two workgroups per CU), 0 = edge_bwd_fused_k<MmB3>
+namespace gnm {
+int eb_variant() { return g_eb_variant; }
+}
+extern "C" int gnm_debug_set_variant(const char* what, int v) {
+  if (what && !strcmp(what, "tn")) { g_tn_variant = v; return 0; }
+  if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
+  ::gnm::set_error("debug_set_variant: unknown switch");
+  return -1;
+}
+
+
+// workspace: packed weights (ncb * 16 * 64 float4)
+extern "C" size_t gnm_rowtile_workspace_bytes(int ncols) { return (size_t)(ncols / 32) * kPackBytesPerBlk; }
+
+extern "C" int gnm_set_matmul_mode(int mode) {
+  GNM_CHECK_ARG(mode == 0 || mode == 1, "set_matmul_mode: mode %d (0 = fp32 MFMA, 1 = bf16x3 split)", mode);
+  g_matmul_mode = mode;
+  return 0;
+}
+extern "C" int gnm_get_matmul_mode(void) { return g_matmul_mode; }
+
+template <class MM>
+static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, const float* b3, const float* P,
+                             const int32_t* isrc, const int32_t* idst, float* t, double* partials, int* nblk_out,
+                             void* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  launch_pack<MM>(W3, FH, FH / 32, 0, ws, st);
+  GNM_LAUNCH_CHECK("pack_w (NT)");
+  if constexpr (MM::kSplit) {
+    const int64_t ntiles = cdiv_(E, ER3);
+    const int grid = persistent_grid(ntiles, 8, occ_blocks<edge_t32_b3_k>());
+    hipLaunchKernelGGL(edge_t32_b3_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                       partials, cdiv_(ntiles, grid));
+    GNM_LAUNCH_CHECK("edge_t_fused_fwd");
+    *nblk_out = grid;
+    return 0;
+  }
+  const int64_t ntiles = cdiv_(E, FTR);
+  const int grid = persistent_grid(ntiles, 4, occ_blocks<rowtile_nt_k<MM, true, 1>>());
+  hipLaunchKernelGGL((rowtile_nt_k<MM, true, 1>), dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t,
+                     (int64_t)FH, P, isrc, idst, partials, cdiv_(ntiles, grid), 1);
+  GNM_LAUNCH_CHECK("edge_t_fused_fwd");
+  *nblk_out = grid;
+  return 0;
+}
+
+extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
+                                    const float* P, const int32_t* isrc, const int32_t* idst, float* t,
+                                    double* partials, int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "edge_t_fused_fwd: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(E > 0 && e_in && W3 && b3 && P && isrc && idst && t && partials && nblk_out, "edge_t_fused_fwd: null/neg argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(FH), "edge_t_fused_fwd: workspace too small");
+  return g_matmul_mode ? edge_t_fused_impl<MmB3>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream)
+                       : edge_t_fused_impl<MmF32>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream);
+}
+
+template <class MM>
+static int node_proj_fwd_impl(int64_t N, int ncols, const float* h, const float* W, const float* b, float* Pout,
+                              void* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  launch_pack<MM>(W, FH, ncols / 32, 0, ws, st);
+  GNM_LAUNCH_CHECK("pack_w (NT, node)");
+  const int64_t ntiles = cdiv_(N, FTR);
+  if constexpr (MM::kSplit) {
+    // HBM-bound in split mode: column groups over workgroups, weights stationary (no reload per tile)
+    const int ncg = ncols / FH;
+    int nslot = (num_cus() * occ_blocks<rowtile_nt_k<MM, false, 1>>()) / ncg / kXcds * kXcds;
+    if (nslot > (int)((ntiles + kXcds - 1) / kXcds * kXcds)) nslot = (int)((ntiles + kXcds - 1) / kXcds * kXcds);
+    if (nslot < kXcds) nslot = kXcds;
+    hipLaunchKernelGGL((rowtile_nt_k<MM, false, 1>), dim3(nslot * ncg), dim3(kBlock), 0, st, N, h, (const void*)ws, b,
+                       Pout, (int64_t)ncols, (const float*)nullptr, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (double*)nullptr, cdiv_(ntiles, nslot), ncg);
+  } else {
+    const int grid = persistent_grid(ntiles, 2, occ_blocks<rowtile_nt_k<MM, false, 5>>());
+    hipLaunchKernelGGL((rowtile_nt_k<MM, false, 5>), dim3(grid), dim3(kBlock), 0, st, N, h, (const void*)ws, b, Pout,
+                       (int64_t)ncols, (const float*)nullptr, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (double*)nullptr, cdiv_(ntiles, grid), 1);
+  }
+  GNM_LAUNCH_CHECK("node_proj_fwd");
+  return 0;
+}
+
+extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, const float* W, const float* b,
+                                 float* Pout, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "node_proj_fwd: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(N > 0 && ncols == 5 * FH && h && W && b && Pout, "node_proj_fwd: bad argument (ncols must be 5*128)");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd: workspace too small");
+  return g_matmul_mode ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
+                       : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
+}
+
+namespace gnm {
+int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st);   // gnm_tr.hip
+}
+extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void);
+
+// The fused edge backward of layer i chained with the by-destination backward pass of layer i-1 (gnm.h).
+extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
+                                  const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
+                                  const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
+                                  const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
+                                  const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
+                                  const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
+                                  int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "edge_bwd_chain: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(g_matmul_mode == 1, "edge_bwd_chain: only built for the bf16x3 matmul mode");
+  GNM_CHECK_ARG(N > 0 && E > 0 && ge && ge_out && t_hi && e_mid && stat_hi && bstat_hi && gamma_hi && W3_hi && gW3_hi &&
+                    gb3_hi && partials_hi && t_lo && stat_lo && P_lo && Q_lo && hf_lo && hb_lo && isrc && idst && in_ptr &&
+                    gP_lo && Ud_lo && Td_lo && partials_lo && nblk_out && partials_hi != partials_lo,
+                "edge_bwd_chain: null / aliased argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "edge_bwd_chain: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  ChainArgs a{};
+  a.E = E; a.N = N;
+  a.ge = ge; a.ge_out = ge_out; a.t_hi = t_hi; a.e_mid = e_mid;
+  a.stat_hi = stat_hi; a.bstat_hi = bstat_hi; a.gamma_hi = gamma_hi;
+  a.slab = slab; a.partials = partials_hi;
+  a.t_lo = t_lo; a.stat_lo = stat_lo; a.P_lo = P_lo; a.Q_lo = Q_lo; a.hf_lo = hf_lo; a.hb_lo = hb_lo;
+  a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
+  a.gP_lo = gP_lo; a.Ud_lo = Ud_lo; a.Td_lo = Td_lo; a.partials_lo = partials_lo;
+  const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st);
+  GNM_LAUNCH_CHECK("edge_bwd_chain");
+  hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3_hi);
+  GNM_LAUNCH_CHECK("edge_bwd_chain slab reduce");
+  *nblk_out = grid;
+  return gnm_reduce_partials(partials_hi, grid, 1, FH, gb3_hi, stream) ? -3 : 0;
+}
+
+extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void) {
+  // packed W3 + one 128x128 slab per possible workgroup
+  return gnm_rowtile_workspace_bytes(FH) + (size_t)kMaxPartialBlocks * FH * FH * sizeof(float);
+}
+
+template <class MM>
+static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in,
+                               const float* stat_e, const float* bstat_e, const float* gamma_e, const float* W3,
+                               float* gW3, float* gb3, double* partials, void* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  int grid;
+  if (MM::kSplit && g_eb_variant >= 1) {
+    grid = edge_bwd_tr_launch(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, ws, slab, partials, st);
+    GNM_LAUNCH_CHECK("edge_bwd_fused (tr)");
+    hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
+    GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
+    return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
+  }
+  launch_pack<MM>(W3, FH, FH / 32, 1, ws, st);
+  GNM_LAUNCH_CHECK("pack_w (NN)");
+  if constexpr (MM::kSplit) {
+    const int64_t ntiles = cdiv_(E, FTR);
+    grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k<MM>>());
+    hipLaunchKernelGGL(edge_bwd_fused_k<MM>, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
+                       gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
+  } else {
+    const int64_t ntiles = cdiv_(E, FTR2);
+    grid = persistent_grid(ntiles, 8, occ_blocks<edge_bwd_fused32_k>());
+    hipLaunchKernelGGL(edge_bwd_fused32_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
+                       gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
+  }
+  GNM_LAUNCH_CHECK("edge_bwd_fused");
+  hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
+  GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
+  return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
+}
+
+extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const float* t, const float* e_in,
+                                  const float* stat_e, const float* bstat_e, const float* gamma_e,
+                                  const float* W3, float* gW3, float* gb3, double* partials, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "edge_bwd_fused: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(E > 0 && ge && ge_out && t && e_in && stat_e && bstat_e && gamma_e && W3 && gW3 && gb3 && partials,
+                "edge_bwd_fused: null/neg argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "edge_bwd_fused: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  return g_matmul_mode ? edge_bwd_fused_impl<MmB3>(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, gW3, gb3, partials, ws, stream)
+                       : edge_bwd_fused_impl<MmF32>(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, gW3, gb3, partials, ws, stream);
+}
+
+static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,
+                        double* partials, float* slab, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const bool tr = g_matmul_mode && g_tn_variant == 1;
+  const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : g_matmul_mode ? TR3 : FTR);
+  const int occ = tr ? tn_tr_occupancy() : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  int nslot = (num_cus() * occ) / ncg;
+  if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
+  if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
+  nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
+  if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
+  if (tr)
+    tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st);
+  else if (g_matmul_mode)
+    hipLaunchKernelGGL(tn_colgroup32_b3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
+                       nslot, cdiv_(ntiles, nslot));
+  else
+    hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
+                       nslot, cdiv_(ntiles, nslot));
+  GNM_LAUNCH_CHECK("tn_colgroup");
+  for (int cg = 0; cg < ncg; ++cg) {
+    hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cg * nslot * FH * FH,
+                       nslot, FH * FH, gW + (size_t)cg * FH * FH);
+    if (gnm_reduce_partials(partials + (size_t)cg * nslot * FH, nslot, 1, FH, gb + cg * FH, stream)) return -3;
+  }
+  GNM_LAUNCH_CHECK("tn_colgroup reduce");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-mode route of gnm_gemm_f32 (gnm_gemm.hip) for the big-M shapes whose other two dimensions are multiples of
+// 128: NT / NN through gemm_rows_b3_k, TN through tn_tr_k with (A group, B group) classes.  Returns 1 = done,
+// 0 = not eligible (the caller runs the fp32-MFMA kernel), < 0 = error.
+// ------------------------------------------------------------------------------------------
+namespace gnm {
+static bool gemm_b3_shape_ok(int mode, int64_t M, int64_t N, int64_t K) {
+  if (!g_matmul_mode) return false;
+  if (mode == GNM_GEMM_TN) return K >= 4096 && M > 0 && N > 0 && M % FH == 0 && N % FH == 0 && (M / FH) * (N / FH) <= 64;
+  return M >= 2048 && N > 0 && K > 0 && N % FH == 0 && K % FH == 0 && (N / FH) * (K / FH) <= 256;
+}
+static int gemm_b3_tn_slots(int64_t rows, int ncls) {
+  const int64_t ntiles = cdiv_(rows, tn_tr_rows_per_tile());
+  int nslot = (num_cus() * tn_tr_occupancy()) / ncls;
+  if (nslot > kMaxPartialBlocks / ncls) nslot = kMaxPartialBlocks / ncls;
+  if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
+  nslot = nslot / kXcds * kXcds;
+  if (nslot < kXcds) nslot = kXcds;
+  return nslot;
+}
+size_t gemm_b3_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
+  if (!gemm_b3_shape_ok(mode, M, N, K)) return 0;
+  if (mode == GNM_GEMM_TN) {
+    const int ncls = (int)((M / FH) * (N / FH));
+    const size_t blocks = (size_t)ncls * gemm_b3_tn_slots(K, ncls);
+    return blocks * FH * FH * sizeof(float) + blocks * FH * sizeof(double);
+  }
+  return (size_t)(N / FH) * (K / FH) * 4 * MmB3::kPackBytes;
+}
+int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                float* C, int64_t ldc, const float* bias, const float* resid, int64_t ldr, int relu, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+  if (!gemm_b3_shape_ok(mode, M, N, K)) return 0;
+  auto al = [](const void* p, int64_t ld) { return (uintptr_t)p % 16 == 0 && ld % 4 == 0; };
+  if (!al(A, lda) || !ws || ws_bytes < gemm_b3_workspace_bytes(mode, M, N, K)) return 0;
+  if (mode == GNM_GEMM_TN) {            // C[M,N] = A[K,M]^T B[K,N]
+    if (bias || resid || relu || !al(B, ldb)) return 0;
+    const int ncga = (int)(M / FH), ncgb = (int)(N / FH), ncls = ncga * ncgb;
+    const int nslot = gemm_b3_tn_slots(K, ncls);
+    const int64_t ntiles = cdiv_(K, tn_tr_rows_per_tile());
+    float* slab = (float*)ws;
+    double* partials = (double*)((char*)ws + (size_t)ncls * nslot * FH * FH * sizeof(float));
+    tn_tr_launch(K, A, lda, ncga, B, ldb, ncgb, slab, partials, nslot, cdiv_(ntiles, nslot), st);
+    for (int cls = 0; cls < ncls; ++cls)
+      hipLaunchKernelGGL(slab_reduce_ld_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cls * nslot * FH * FH,
+                         nslot, C + (int64_t)(cls / ncgb) * FH * ldc + (cls % ncgb) * FH, ldc);
+    return hipGetLastError() == hipSuccess ? 1 : -2;
+  }
+  if (!al(C, ldc) || (resid && !al(resid, ldr)) || (bias && (uintptr_t)bias % 16 != 0)) return 0;
+  const int ncls = (int)(N / FH), ncg = (int)(K / FH);
+  hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, B, ldb, ncls, ncg, mode == GNM_GEMM_NN ? 1 : 0,
+                     (bf16x8*)ws);
+  constexpr int T = 4;
+  const int64_t ngroups = cdiv_(M, NR3 * T);
+  int nchunk = (num_cus() * occ_blocks<gemm_rows_b3_k<T>>()) / ncls;
+  if ((int64_t)nchunk > ngroups) nchunk = (int)ngroups;
+  nchunk = nchunk / kXcds * kXcds;
+  if (nchunk < kXcds) nchunk = kXcds;
+  hipLaunchKernelGGL((gemm_rows_b3_k<T>), dim3(nchunk * ncls), dim3(kBlock), 0, st, M, A, lda, ncg, ncls, (const void*)ws,
+                     bias, resid, ldr, relu, C, ldc, nchunk, cdiv_(ngroups, nchunk));
+  return hipGetLastError() == hipSuccess ? 1 : -2;
+}
+// the same TN product plus the column sums of A (a Linear's bias gradient beside its weight gradient): tn_tr_k keeps them
+// in fp64 per workgroup anyway
+int gemm_b3_tn_colsum_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                          int64_t ldc, float* colsum, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int rc = gemm_b3_try(GNM_GEMM_TN, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, 0, ws, ws_bytes, st);
+  if (rc != 1) return rc;
+  const int ncga = (int)(M / FH), ncgb = (int)(N / FH), ncls = ncga * ncgb;
+  const int nslot = gemm_b3_tn_slots(K, ncls);
+  const double* partials = (const double*)((const char*)ws + (size_t)ncls * nslot * FH * FH * sizeof(float));
+  for (int cga = 0; cga < ncga; ++cga)
+    if (gnm_reduce_partials(partials + (size_t)(cga * ncgb) * nslot * FH, nslot, 1, FH, colsum + (size_t)cga * FH, (void*)st)) return -3;
+  return 1;
+}
+}  // namespace gnm
+
+// gh_in = gh_out + gP W  (W [ncols,128] row-major, ncols % 128 == 0);  gW = gP^T h_in;  gb = sum gP.
+// ws: packed W (ncols/32 fragment blocks) + slabs [ncg][nslot][128][128]; partials double[ncg*nslot][128]
+extern "C" size_t gnm_node_proj_bwd_workspace_bytes(int ncols) {
+  return gnm_rowtile_workspace_bytes(ncols) + (size_t)kMaxPartialBlocks * FH * FH * sizeof(float);
+}
+
+template <class MM>
+static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* W, const float* gh_out, float* gh_in,
+                            void* ws, hipStream_t st) {
+  const int ncg = ncols / FH;
+  for (int cg = 0; cg < ncg; ++cg)   // W rows cg*128.. form the [k=128, c=128] block of group cg
+    launch_pack<MM>(W + (size_t)cg * FH * FH, FH, FH / 32, 1, (char*)ws + (size_t)cg * 4 * MM::kPackBytes, st);
+  GNM_LAUNCH_CHECK("pack_w (NN, node)");
+  if constexpr (MM::kSplit) {
+    constexpr int T = 4;
+    const int64_t ngroups = cdiv_(N, NR3 * T);
+    const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn_group32_b3_k<T>>());
+    hipLaunchKernelGGL((rowtile_nn_group32_b3_k<T>), dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
+                       (const void*)ws, gh_out, gh_in, cdiv_(ngroups, grid));
+  } else {
+    const int64_t ntiles = cdiv_(N, FTR);
+    const int grid = persistent_grid(ntiles, 2, occ_blocks<rowtile_nn_acc_k<MM>>());
+    hipLaunchKernelGGL(rowtile_nn_acc_k<MM>, dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
+                       (const void*)ws, gh_out, gh_in, cdiv_(ntiles, grid));
+  }
+  GNM_LAUNCH_CHECK("node_proj_bwd (NN)");
+  return 0;
+}
+
+// The two halves of gnm_node_proj_bwd as separate entry points (same workspace layout), so that a caller can
+// time / schedule the NN and the TN kernel on their own.
+extern "C" int gnm_node_proj_bwd_nn(int64_t N, int H, int ncols, const float* gP, const float* W, const float* gh_out,
+                                    float* gh_in, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "node_proj_bwd_nn: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && W && gh_out && gh_in, "node_proj_bwd_nn: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_bwd_nn: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  return (g_matmul_mode ? node_proj_bwd_nn<MmB3>(N, ncols, gP, W, gh_out, gh_in, ws, st)
+                        : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st)) ? -2 : 0;
+}
+
+extern "C" int gnm_node_proj_bwd_tn(int64_t N, int H, int ncols, const float* gP, const float* h_in, float* gW, float* gb,
+                                    double* partials, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "node_proj_bwd_tn: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && h_in && gW && gb && partials, "node_proj_bwd_tn: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_node_proj_bwd_workspace_bytes(ncols), "node_proj_bwd_tn: workspace too small");
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(ncols));
+  return tn_colgroups(N, gP, ncols, ncols / FH, h_in, gW, gb, partials, slab, stream);
+}
+
+extern "C" int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
+                                 const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_node_proj_bwd_workspace_bytes(ncols), "node_proj_bwd: workspace too small");
+  const int rc = gnm_node_proj_bwd_nn(N, H, ncols, gP, W, gh_out, gh_in, ws, ws_bytes, stream);
+  return rc ? rc : gnm_node_proj_bwd_tn(N, H, ncols, gP, h_in, gW, gb, partials, ws, ws_bytes, stream);
+}
+
+// out[cg*128 + n][c] = sum_rows A[row][cg*128 + n] * B[row][c];  colsum[cg*128 + n] = sum_rows A[row][cg*128 + n]
+// (A [M, lda >= ncg*128], B [M,128]): the weight-gradient shape of every Linear whose input is 128 wide.
+extern "C" size_t gnm_tn128_workspace_bytes(void) { return (size_t)kMaxPartialBlocks * FH * FH * sizeof(float); }
+
+extern "C" int gnm_tn128(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* out, float* colsum,
+                         double* partials, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(M > 0 && A && B && out && colsum && partials && ncg > 0 && lda >= (int64_t)ncg * FH && ncg <= 16,
+                "tn128: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128: workspace too small");
+  return tn_colgroups(M, A, lda, ncg, B, out, colsum, partials, (float*)ws, stream);
+  return 0;
+}

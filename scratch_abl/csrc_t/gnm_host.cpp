@@ -1,0 +1,260 @@
+// Host-side pieces of libgnm.so: error reporting, device query, graph index build.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "gnm_common.h"
+
+namespace gnm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+  return (int)e;
+}
+
+int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;  // MI355X
+  }
+  return cus;
+}
+
+static int g_occ_cap = 0;
+int occupancy_cap() { return g_occ_cap; }
+
+}  // namespace gnm
+
+extern "C" int gnm_set_occupancy_cap(int blocks_per_cu) {
+  GNM_CHECK_ARG(blocks_per_cu >= 0 && blocks_per_cu <= 8, "set_occupancy_cap: %d outside [0, 8]", blocks_per_cu);
+  gnm::g_occ_cap = blocks_per_cu;
+  return 0;
+}
+extern "C" int gnm_abi_version(void) { return GNM_ABI_VERSION; }
+extern "C" const char* gnm_last_error(void) { return gnm::g_err; }
+extern "C" int gnm_num_cus(void) { return gnm::num_cus(); }
+extern "C" int gnm_max_partial_blocks(void) { return gnm::kMaxPartialBlocks; }
+
+// Stable counting sort of the edge list by destination (internal order) and by source.
+// Replaces DGL's lazy CSR/CSC construction and dgl.reverse (gated_gcn_full.py:115): the
+// reversed graph is the same edge set indexed by source, so one index serves both passes.
+extern "C" int gnm_graph_build_index(const int32_t* src, const int32_t* dst, int64_t N, int64_t E,
+                                     int32_t* perm, int32_t* isrc, int32_t* idst, int32_t* in_ptr,
+                                     int32_t* out_ptr, int32_t* out_pos, int32_t* out_dst) {
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && N < INT32_MAX && E < INT32_MAX, "graph_build_index: N/E out of int32 range");
+  GNM_CHECK_ARG((E == 0 || (src && dst)) && perm && isrc && idst && in_ptr && out_ptr && out_pos && out_dst,
+                "graph_build_index: null argument");
+  for (int64_t k = 0; k < E; ++k) {
+    if (src[k] < 0 || src[k] >= N || dst[k] < 0 || dst[k] >= N) {
+      gnm::set_error("graph_build_index: edge %lld = (%d -> %d) outside [0, %lld)", (long long)k, src[k],
+                     dst[k], (long long)N);
+      return -2;
+    }
+  }
+  // by destination, stable in edge id
+  std::memset(in_ptr, 0, sizeof(int32_t) * (size_t)(N + 1));
+  for (int64_t k = 0; k < E; ++k) in_ptr[dst[k] + 1]++;
+  for (int64_t v = 0; v < N; ++v) in_ptr[v + 1] += in_ptr[v];
+  {
+    std::vector<int32_t> cur(in_ptr, in_ptr + N);
+    for (int64_t k = 0; k < E; ++k) {
+      const int32_t j = cur[dst[k]]++;
+      perm[j] = (int32_t)k;
+      isrc[j] = src[k];
+      idst[j] = dst[k];
+    }
+  }
+  // by source, stable in internal position
+  std::memset(out_ptr, 0, sizeof(int32_t) * (size_t)(N + 1));
+  for (int64_t j = 0; j < E; ++j) out_ptr[isrc[j] + 1]++;
+  for (int64_t v = 0; v < N; ++v) out_ptr[v + 1] += out_ptr[v];
+  {
+    std::vector<int32_t> cur(out_ptr, out_ptr + N);
+    for (int64_t j = 0; j < E; ++j) {
+      const int32_t m = cur[isrc[j]]++;
+      out_pos[m] = (int32_t)j;
+      out_dst[m] = idst[j];
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Greedy decode on the host (inference.py:31-77,182-253): sequential walks over an adjacency in
+// edge-id order.  The reference keeps dict-of-list successors / predecessors and a
+// (src, dst) -> edge id dict (graph_parser.py:13-73); here both directions are CSR arrays whose
+// `eid` column already holds that dict's answer (the LAST edge id of a duplicated pair).
+// ------------------------------------------------------------------------------------------
+namespace {
+
+void csr_by(const int32_t* key, const int32_t* other, int64_t N, int64_t E, int32_t* ptr, int32_t* nbr, int32_t* eid) {
+  std::vector<int32_t> cnt((size_t)N + 1, 0);
+  for (int64_t k = 0; k < E; ++k) ++cnt[(size_t)key[k] + 1];
+  ptr[0] = 0;
+  for (int64_t v = 0; v < N; ++v) ptr[v + 1] = ptr[v] + cnt[(size_t)v + 1];
+  std::vector<int32_t> fill(ptr, ptr + N);
+  for (int64_t k = 0; k < E; ++k) {          // ascending edge id inside a node: the dict-of-list order
+    const int32_t p = fill[(size_t)key[k]]++;
+    nbr[p] = other[k];
+    eid[p] = (int32_t)k;
+  }
+  for (int64_t v = 0; v < N; ++v)            // duplicate (v, nbr) pairs: every copy answers with the last id
+    for (int32_t a = ptr[v]; a < ptr[v + 1]; ++a)
+      for (int32_t b = a + 1; b < ptr[v + 1]; ++b)
+        if (nbr[b] == nbr[a]) eid[a] = eid[b];
+}
+
+// inference.py:31-52 / :55-76.  Marks seen[] (node and node^1), returns the walk in walking order.
+// A forced move (exactly one neighbour) is taken even into consumed territory, as in the reference;
+// a walk longer than `cap` can only be a forced-move cycle (the reference would not terminate).
+bool greedy_walk(int32_t start, const float* scores, const int32_t* ptr, const int32_t* nbr, const int32_t* eid,
+                 int64_t N, const uint8_t* old1, const uint8_t* old2, uint8_t* seen, std::vector<int32_t>& walk,
+                 std::vector<int32_t>& touched, int64_t cap) {
+  int32_t cur = start;
+  for (;;) {
+    if ((int64_t)walk.size() >= cap) return false;
+    walk.push_back(cur);
+    if (!seen[cur]) { seen[cur] = 1; touched.push_back(cur); }
+    const int32_t rc = cur ^ 1;
+    if (rc < N && !seen[rc]) { seen[rc] = 1; touched.push_back(rc); }
+    const int32_t a = ptr[cur], b = ptr[cur + 1];
+    if (a == b) break;
+    if (b - a == 1) { cur = nbr[a]; continue; }
+    int32_t best = -1;
+    float bs = 0.f;
+    for (int32_t p = a; p < b; ++p) {
+      const int32_t v = nbr[p];
+      if (old1[v] || (old2 && old2[v]) || seen[v]) continue;
+      const float s = scores[eid[p]];
+      if (best < 0 || s > bs) { best = v; bs = s; }   // first maximum, as argmax / topk(k=1)
+    }
+    if (best < 0) break;
+    cur = best;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int gnm_decode_build_adjacency(const int32_t* src, const int32_t* dst, int64_t N, int64_t E,
+                                          int32_t* succ_ptr, int32_t* succ_nbr, int32_t* succ_eid,
+                                          int32_t* pred_ptr, int32_t* pred_nbr, int32_t* pred_eid) {
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && N < INT32_MAX && E < INT32_MAX, "decode_build_adjacency: N/E out of int32 range");
+  GNM_CHECK_ARG((E == 0 || (src && dst && succ_nbr && succ_eid && pred_nbr && pred_eid)) && succ_ptr && pred_ptr,
+                "decode_build_adjacency: null argument");
+  for (int64_t k = 0; k < E; ++k)
+    if (src[k] < 0 || src[k] >= N || dst[k] < 0 || dst[k] >= N) {
+      gnm::set_error("decode_build_adjacency: edge %lld = (%d -> %d) outside [0, %lld)", (long long)k, src[k], dst[k],
+                     (long long)N);
+      return -2;
+    }
+  csr_by(src, dst, N, E, succ_ptr, succ_nbr, succ_eid);
+  csr_by(dst, src, N, E, pred_ptr, pred_nbr, pred_eid);
+  return 0;
+}
+
+// One iteration of get_contigs (inference.py:203-250) for nb start edges (start_src[i] -> start_dst[i]):
+// forward walk from the head, backward walk from the tail under visited | seen_forward, the walk of the
+// greatest reconstructed length wins (first one on ties), the nodes it jumped over are added, and --
+// if it has at least len_threshold nodes -- `visited` is updated.  Returns the winning walk's length
+// (its nodes in walk_out[0..len)), the caller stops when that is below len_threshold; < 0 on error.
+extern "C" int64_t gnm_decode_iteration(int64_t N, const float* scores, const int64_t* prefix_length,
+                                        const int64_t* read_length, const int32_t* succ_ptr, const int32_t* succ_nbr,
+                                        const int32_t* succ_eid, const int32_t* pred_ptr, const int32_t* pred_nbr,
+                                        const int32_t* pred_eid, uint8_t* visited, int nb, const int32_t* start_src,
+                                        const int32_t* start_dst, int len_threshold, int32_t* walk_out,
+                                        int64_t walk_cap, int64_t* best_length_out) {
+  if (!(N > 0 && scores && prefix_length && read_length && succ_ptr && succ_nbr && succ_eid && pred_ptr && pred_nbr &&
+        pred_eid && visited && nb > 0 && start_src && start_dst && walk_out && walk_cap > 0)) {
+    gnm::set_error("decode_iteration: bad argument");
+    return -1;
+  }
+  const int64_t cap = 2 * N + 2;
+  std::vector<uint8_t> seen_f((size_t)N, 0), seen_b((size_t)N, 0);
+  std::vector<int32_t> wf, wb, tf, tb, best_walk, best_seen;
+  int64_t best_len = -1;
+  for (int i = 0; i < nb; ++i) {
+    if (start_src[i] < 0 || start_src[i] >= N || start_dst[i] < 0 || start_dst[i] >= N) {
+      gnm::set_error("decode_iteration: start edge %d outside the graph", i);
+      return -2;
+    }
+    wf.clear(); wb.clear(); tf.clear(); tb.clear();
+    const bool ok = greedy_walk(start_dst[i], scores, succ_ptr, succ_nbr, succ_eid, N, visited, nullptr, seen_f.data(),
+                                wf, tf, cap) &&
+                    greedy_walk(start_src[i], scores, pred_ptr, pred_nbr, pred_eid, N, visited, seen_f.data(),
+                                seen_b.data(), wb, tb, cap);
+    if (!ok) {
+      gnm::set_error("decode_iteration: walk %d exceeds 2N nodes (a cycle of forced moves; the reference does not "
+                     "terminate on this input)", i);
+      return -3;
+    }
+    // walk = reversed(backward) + forward; its length in bases (inference.py:20-28)
+    int64_t bases = 0;
+    auto edge_of = [&](int32_t a, int32_t b) -> int32_t {
+      for (int32_t p = succ_ptr[a]; p < succ_ptr[a + 1]; ++p)
+        if (succ_nbr[p] == b) return succ_eid[p];
+      return -1;
+    };
+    bool bad = false;
+    auto add = [&](int32_t a, int32_t b) {
+      const int32_t k = edge_of(a, b);
+      if (k < 0) bad = true; else bases += prefix_length[k];
+    };
+    for (size_t j = wb.size(); j-- > 1;) add(wb[j], wb[j - 1]);
+    if (!wb.empty() && !wf.empty()) add(wb[0], wf[0]);
+    for (size_t j = 0; j + 1 < wf.size(); ++j) add(wf[j], wf[j + 1]);
+    if (bad) {
+      gnm::set_error("decode_iteration: start edge %d (%d -> %d) is not an edge of the graph", i, start_src[i],
+                     start_dst[i]);
+      return -4;
+    }
+    bases += read_length[wf.back()];
+    if (bases > best_len) {                       // max(): the first of equally long walks
+      best_len = bases;
+      best_walk.assign(wb.rbegin(), wb.rend());
+      best_walk.insert(best_walk.end(), wf.begin(), wf.end());
+      best_seen = tf;
+      best_seen.insert(best_seen.end(), tb.begin(), tb.end());
+    }
+    for (int32_t v : tf) seen_f[(size_t)v] = 0;
+    for (int32_t v : tb) seen_b[(size_t)v] = 0;
+  }
+  const int64_t len = (int64_t)best_walk.size();
+  if (len > walk_cap) {
+    gnm::set_error("decode_iteration: walk of %lld nodes does not fit walk_out (%lld)", (long long)len, (long long)walk_cap);
+    return -5;
+  }
+  std::memcpy(walk_out, best_walk.data(), (size_t)len * sizeof(int32_t));
+  if (best_length_out) *best_length_out = best_len;
+  if (len >= len_threshold) {
+    for (int32_t v : best_seen) visited[(size_t)v] = 1;
+    // nodes the walk jumped over: succs[a] & preds[b] for consecutive (a, b), and their complements (:231-239)
+    for (int64_t j = 0; j + 1 < len; ++j) {
+      const int32_t a = best_walk[(size_t)j], b = best_walk[(size_t)j + 1];
+      for (int32_t p = succ_ptr[a]; p < succ_ptr[a + 1]; ++p) {
+        const int32_t t = succ_nbr[p];
+        bool is_pred = false;
+        for (int32_t q = pred_ptr[b]; q < pred_ptr[b + 1] && !is_pred; ++q) is_pred = pred_nbr[q] == t;
+        if (is_pred) {
+          visited[(size_t)t] = 1;
+          if ((t ^ 1) < N) visited[(size_t)(t ^ 1)] = 1;
+        }
+      }
+    }
+  }
+  return len;
+}

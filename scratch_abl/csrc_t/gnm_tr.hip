@@ -423,8 +423,12 @@ constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 4 * E
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
 
 // ABL (timing experiments only, results wrong when non-zero): bit 0 no column walk, bit 1 no gather arithmetic, bit 2 no MFMAs
+__device__ long long g_chain_dbg[256 * 8 * 12];
+#define TS(n) { const long long t_ = clock64(); tacc[n] += t_ - tlast; tlast = t_; }
 template <int ABL>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
+  long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
   __shared__ __attribute__((aligned(16))) unsigned char lds[CH_LDS];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
@@ -481,10 +485,9 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // column walkers: threads 0-95 (waves 0 and 1), one float4 of columns each; role = tid >> 5: 0 sums sigma*Qb
   // (-> gA3h), 1 that (-> Td), 2 gu (-> Ud).  The BatchNorm column sums of layer i-1 (sum gu, sum gu*that, fp64:
   // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
-  const bool walker = tid < 96, bnsum = (tid & 128) != 0;      // BatchNorm sums: waves 2, 3, 6, 7, two rows of a tile each
+  const bool walker = tid < 96, bnsum = tid >= 128 && tid < 256;
   const int role = (tid >> 5) & 3, wc4 = (tid & 31) * 4;
-  const int brow = 2 * (((tid >> 8) << 2) | ((tid >> 5) & 3));   // first of this thread's two rows (0, 2, .. 14)
-  int cur = -1;                             // node whose segment is being summed (wave-uniform)
+  int64_t cur = -1;                         // node whose segment is being summed
   float4 acc0 = f4(0.f);
   double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};
   // Every walker step STORES the running sum to its node's output row (the last store of a segment holds the
@@ -558,6 +561,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     const int64_t r0 = rb + k * ER;
     const int nvalid = re - r0 < ER ? (int)(re - r0) : ER;
     const int* sdk = sd + (int)(k % 3) * 2 * ER;
+    TS(0)
     // ---- phase 0: gt row and e row -> split images; residual ge row -> og; t(i-1) row -> tl; indices -> sd ----
     {
       const float4 mu = ld4(cs + lc4), rs = ld4(cs + SW + lc4), sc = ld4(cs + 2 * SW + lc4),
@@ -577,7 +581,9 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         sdn[ER + row] = fd;
       }
     }
+    TS(1)
     __syncthreads();   // images, residual rows, the next tile's indices ready
+    TS(2)
     // a tile (two for the indices) ahead, in flight under the MFMAs and the gather arithmetic; past the end the
     // last tile is requested again instead of branching around the loads
     prefetch_idx(k + 2 < klast ? k + 2 : klast);
@@ -624,7 +630,9 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) og[(4 * ng + e) * EOP + wave * 16 + ni] += acc[e];
     }
+    TS(3)
     __syncthreads();   // og = ge(i-1) rows complete; every wave is done with the gt images
+    TS(4)
     // ---- by-destination backward of layer i-1 on this thread's row (edge_bwd_dst_k's arithmetic) ----
     {
       const float4 mu = ld4(cl + lc4), rs = ld4(cl + SW + lc4), sc = ld4(cl + 2 * SW + lc4), sh = ld4(cl + 3 * SW + lc4);
@@ -634,19 +642,16 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       if (!(ABL & 2)) sigmoid_grad4(simg_load_f32(ie, EIMG, row, lc4), sg, dsg);
       const float4 gsig = fma4(gqf, ga2, fma4(gqb, ga3, f4(0.f) - gqf * ghf - gqb * ghb));
       const float4 g = fma4(gsig, dsg, ge4);
-      const bool live = row < nvalid;        // rows past the chunk repeat its last row's indices: their terms are zeroed HERE
-      st4_nt(live ? a.ge_out + (r0 + row) * SW + lc4 : dummy_row, g);
-      st4(v1 + row * SW + lc4, live ? sg * gqb : f4(0.f));
-      st4(v2 + row * SW + lc4, live ? gate4(fma4(tt, sc, sh), g) : f4(0.f));
-      st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
+      st4_nt(row < nvalid ? a.ge_out + (r0 + row) * SW + lc4 : dummy_row, g);
+      st4(v1 + row * SW + lc4, sg * gqb);
+      st4(v2 + row * SW + lc4, gate4(fma4(tt, sc, sh), g));
+      st4(v3 + row * SW + lc4, (tt - mu) * rs);
     }
+    TS(5)
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
+    TS(6)
     // ---- column walkers (waves 0 and 1) and BatchNorm sums (waves 2 and 3); the rest go on to the next phase 0 ----
     if (!(ABL & 1) && walker) {
-      // The 16-step chain is the critical path of this phase (the other waves wait for it at the next barrier), so a
-      // step is kept to two packed FMAs and a store: the destination node is wave-uniform (scalar compare, scalar
-      // part of the address), a new segment multiplies the running sum by 0 instead of selecting, and rows past
-      // the chunk were zeroed when they were written.
       const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4;
 #pragma unroll
       for (int r4 = 0; r4 < ER; r4 += 4) {          // four rows' LDS reads up front, then the dependent chain
@@ -654,37 +659,46 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         float4 xs[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          dn[q] = __builtin_amdgcn_readfirstlane(sdk[ER + r4 + q]);
+          dn[q] = sdk[ER + r4 + q];
           xs[q] = ld4(vsrc + (r4 + q) * SW);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float keep = dn[q] == cur ? 1.f : 0.f;
-          acc0 = fma4(acc0, f4(keep), xs[q]);
+          // rows past the chunk repeat its last row's indices and add nothing
+          const float4 x = r4 + q < nvalid ? xs[q] : f4(0.f);
+          acc0 = (dn[q] != cur ? f4(0.f) : acc0) + x;
           cur = dn[q];
-          st4(wout + (int64_t)cur * wpitch, acc0);
+          st4(wout + cur * wpitch, acc0);
         }
       }
     }
-    if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only (rows past the chunk hold zeros)
+    if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only
+      const int rg = 4 * role;                       // rows rg .. rg+3 of the tile
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float4 x = ld4(v2 + (brow + q) * SW + wc4);
-        const float4 th = ld4(v3 + (brow + q) * SW + wc4);
+      for (int q = 0; q < 4; ++q) {
+        float4 x = ld4(v2 + (rg + q) * SW + wc4);
+        float4 th = ld4(v3 + (rg + q) * SW + wc4);
+        if (rg + q >= nvalid) { x = f4(0.f); th = f4(0.f); }     // replaced, never multiplied by zero (0 * NaN)
         s_gu[0] += (double)x.x; s_gu[1] += (double)x.y; s_gu[2] += (double)x.z; s_gu[3] += (double)x.w;
         s_gut[0] += (double)x.x * (double)th.x; s_gut[1] += (double)x.y * (double)th.y;
         s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
       }
     }
+    TS(7)
     {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
     }
+    TS(8)
     // no barrier: a wave reaches the next tile's post-phase-0 barrier only after its own walk, v1 - v3 are rewritten
     // after that barrier, sd is a ring of three; what the next phase 0 writes before it (images, og, tl) was last
     // read by the SAME thread (same row / column mapping) or before this tile's second barrier (gt images)
   }
 
+  if ((tid & 63) == 0 && blockIdx.x < 256) {
+    for (int q = 0; q < 10; ++q) g_chain_dbg[(blockIdx.x * 8 + wave) * 12 + q] = tacc[q];
+    g_chain_dbg[(blockIdx.x * 8 + wave) * 12 + 10] = ntile;
+  }
   float* sl = a.slab + (size_t)chunk * SW * SW;
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -694,23 +708,18 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       sl[m * SW + wc * 32 + li] = tn[x][e];
     }
   __syncthreads();
-  {   // BatchNorm column sums of layer i-1: eight row-pair groups (waves 2, 3, 6, 7) -> one row of partials_lo
-    double* bnr = reinterpret_cast<double*>(lds);      // [8 groups][2][128] doubles = 16 KB (the images are dead)
+  {   // BatchNorm column sums of layer i-1: four row groups (threads 128-255) -> one row of partials_lo each
+    double* bnr = reinterpret_cast<double*>(lds);      // [4 groups][2][128] doubles = 8 KB (the images are dead)
     if (bnsum) {
-      const int grp = brow >> 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        bnr[(grp * 2 + 0) * SW + wc4 + j] = s_gu[j];
-        bnr[(grp * 2 + 1) * SW + wc4 + j] = s_gut[j];
+        bnr[(role * 2 + 0) * SW + wc4 + j] = s_gu[j];
+        bnr[(role * 2 + 1) * SW + wc4 + j] = s_gut[j];
       }
     }
     __syncthreads();
-    if (tid < 2 * SW) {
-      double s_ = 0.0;
-#pragma unroll
-      for (int g8 = 0; g8 < 8; ++g8) s_ += bnr[g8 * 2 * SW + tid];
-      a.partials_lo[(size_t)chunk * 2 * SW + tid] = s_;
-    }
+    if (tid < 2 * SW)
+      a.partials_lo[(size_t)chunk * 2 * SW + tid] = (bnr[tid] + bnr[2 * SW + tid]) + (bnr[4 * SW + tid] + bnr[6 * SW + tid]);
     __syncthreads();
   }
   double* red = reinterpret_cast<double*>(lds);          // 16 row slots x 128 columns = 16 KB (the images are dead)
@@ -784,3 +793,7 @@ void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* 
 }
 
 }  // namespace gnm
+
+extern "C" int gnm_debug_chain_timing(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnm::g_chain_dbg), sizeof(long long) * 256 * 8 * 12);
+}
