@@ -418,6 +418,10 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
 // four row streams AND the six gathered node rows of the NEXT tile are requested a tile ahead, so that no phase
 // waits on memory (the eight waves share every barrier, there is no second workgroup to hide a wait).
 constexpr int CT = 512;                    // threads per workgroup
+#ifndef GNM_WALK_GROUP
+#define GNM_WALK_GROUP 4
+#endif
+constexpr int WG_ = GNM_WALK_GROUP;        // rows per LDS read group of the column walk
 constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 4 * ER * SW * 4 + 3 * 2 * ER * 4;
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
@@ -649,16 +653,16 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       // the chunk were zeroed when they were written.
       const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4;
 #pragma unroll
-      for (int r4 = 0; r4 < ER; r4 += 4) {          // four rows' LDS reads up front, then the dependent chain
-        int dn[4];
-        float4 xs[4];
+      for (int r4 = 0; r4 < ER; r4 += WG_) {        // WG_ rows' LDS reads up front, then the dependent chain
+        int dn[WG_];
+        float4 xs[WG_];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < WG_; ++q) {
           dn[q] = __builtin_amdgcn_readfirstlane(sdk[ER + r4 + q]);
           xs[q] = ld4(vsrc + (r4 + q) * SW);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < WG_; ++q) {
           const float keep = dn[q] == cur ? 1.f : 0.f;
           acc0 = fma4(acc0, f4(keep), xs[q]);
           cur = dn[q];

@@ -485,9 +485,10 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // column walkers: threads 0-95 (waves 0 and 1), one float4 of columns each; role = tid >> 5: 0 sums sigma*Qb
   // (-> gA3h), 1 that (-> Td), 2 gu (-> Ud).  The BatchNorm column sums of layer i-1 (sum gu, sum gu*that, fp64:
   // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
-  const bool walker = tid < 96, bnsum = tid >= 128 && tid < 256;
+  const bool walker = tid < 96, bnsum = (tid & 128) != 0;      // BatchNorm sums: waves 2, 3, 6, 7, two rows of a tile each
   const int role = (tid >> 5) & 3, wc4 = (tid & 31) * 4;
-  int64_t cur = -1;                         // node whose segment is being summed
+  const int brow = 2 * (((tid >> 8) << 2) | ((tid >> 5) & 3));   // first of this thread's two rows (0, 2, .. 14)
+  int cur = -1;                             // node whose segment is being summed (wave-uniform)
   float4 acc0 = f4(0.f);
   double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};
   // Every walker step STORES the running sum to its node's output row (the last store of a segment holds the
@@ -642,16 +643,21 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       if (!(ABL & 2)) sigmoid_grad4(simg_load_f32(ie, EIMG, row, lc4), sg, dsg);
       const float4 gsig = fma4(gqf, ga2, fma4(gqb, ga3, f4(0.f) - gqf * ghf - gqb * ghb));
       const float4 g = fma4(gsig, dsg, ge4);
-      st4_nt(row < nvalid ? a.ge_out + (r0 + row) * SW + lc4 : dummy_row, g);
-      st4(v1 + row * SW + lc4, sg * gqb);
-      st4(v2 + row * SW + lc4, gate4(fma4(tt, sc, sh), g));
-      st4(v3 + row * SW + lc4, (tt - mu) * rs);
+      const bool live = row < nvalid;        // rows past the chunk repeat its last row's indices: their terms are zeroed HERE
+      st4_nt(live ? a.ge_out + (r0 + row) * SW + lc4 : dummy_row, g);
+      st4(v1 + row * SW + lc4, live ? sg * gqb : f4(0.f));
+      st4(v2 + row * SW + lc4, live ? gate4(fma4(tt, sc, sh), g) : f4(0.f));
+      st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
     }
     TS(5)
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
     TS(6)
     // ---- column walkers (waves 0 and 1) and BatchNorm sums (waves 2 and 3); the rest go on to the next phase 0 ----
     if (!(ABL & 1) && walker) {
+      // The 16-step chain is the critical path of this phase (the other waves wait for it at the next barrier), so a
+      // step is kept to two packed FMAs and a store: the destination node is wave-uniform (scalar compare, scalar
+      // part of the address), a new segment multiplies the running sum by 0 instead of selecting, and rows past
+      // the chunk were zeroed when they were written.
       const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4;
 #pragma unroll
       for (int r4 = 0; r4 < ER; r4 += 4) {          // four rows' LDS reads up front, then the dependent chain
@@ -659,26 +665,23 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         float4 xs[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          dn[q] = sdk[ER + r4 + q];
+          dn[q] = __builtin_amdgcn_readfirstlane(sdk[ER + r4 + q]);
           xs[q] = ld4(vsrc + (r4 + q) * SW);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          // rows past the chunk repeat its last row's indices and add nothing
-          const float4 x = r4 + q < nvalid ? xs[q] : f4(0.f);
-          acc0 = (dn[q] != cur ? f4(0.f) : acc0) + x;
+          const float keep = dn[q] == cur ? 1.f : 0.f;
+          acc0 = fma4(acc0, f4(keep), xs[q]);
           cur = dn[q];
-          st4(wout + cur * wpitch, acc0);
+          st4(v1 + ((cur & 15) * SW) + wc4, acc0);   // EXPERIMENT: LDS store instead of the global store
         }
       }
     }
-    if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only
-      const int rg = 4 * role;                       // rows rg .. rg+3 of the tile
+    if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only (rows past the chunk hold zeros)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 x = ld4(v2 + (rg + q) * SW + wc4);
-        float4 th = ld4(v3 + (rg + q) * SW + wc4);
-        if (rg + q >= nvalid) { x = f4(0.f); th = f4(0.f); }     // replaced, never multiplied by zero (0 * NaN)
+      for (int q = 0; q < 2; ++q) {
+        const float4 x = ld4(v2 + (brow + q) * SW + wc4);
+        const float4 th = ld4(v3 + (brow + q) * SW + wc4);
         s_gu[0] += (double)x.x; s_gu[1] += (double)x.y; s_gu[2] += (double)x.z; s_gu[3] += (double)x.w;
         s_gut[0] += (double)x.x * (double)th.x; s_gut[1] += (double)x.y * (double)th.y;
         s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
@@ -708,18 +711,23 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       sl[m * SW + wc * 32 + li] = tn[x][e];
     }
   __syncthreads();
-  {   // BatchNorm column sums of layer i-1: four row groups (threads 128-255) -> one row of partials_lo each
-    double* bnr = reinterpret_cast<double*>(lds);      // [4 groups][2][128] doubles = 8 KB (the images are dead)
+  {   // BatchNorm column sums of layer i-1: eight row-pair groups (waves 2, 3, 6, 7) -> one row of partials_lo
+    double* bnr = reinterpret_cast<double*>(lds);      // [8 groups][2][128] doubles = 16 KB (the images are dead)
     if (bnsum) {
+      const int grp = brow >> 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        bnr[(role * 2 + 0) * SW + wc4 + j] = s_gu[j];
-        bnr[(role * 2 + 1) * SW + wc4 + j] = s_gut[j];
+        bnr[(grp * 2 + 0) * SW + wc4 + j] = s_gu[j];
+        bnr[(grp * 2 + 1) * SW + wc4 + j] = s_gut[j];
       }
     }
     __syncthreads();
-    if (tid < 2 * SW)
-      a.partials_lo[(size_t)chunk * 2 * SW + tid] = (bnr[tid] + bnr[2 * SW + tid]) + (bnr[4 * SW + tid] + bnr[6 * SW + tid]);
+    if (tid < 2 * SW) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) s_ += bnr[g8 * 2 * SW + tid];
+      a.partials_lo[(size_t)chunk * 2 * SW + tid] = s_;
+    }
     __syncthreads();
   }
   double* red = reinterpret_cast<double*>(lds);          // 16 row slots x 128 columns = 16 KB (the images are dead)

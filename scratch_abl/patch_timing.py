@@ -1,0 +1,63 @@
+p='/root/repo/scratch_abl/csrc_t/gnm_tr.hip'; s=open(p).read()
+def rep(old, new, cnt=1):
+    global s
+    assert s.count(old) == cnt, (old, s.count(old))
+    s = s.replace(old, new)
+rep("template <int ABL>\n__global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {",
+"""__device__ long long g_chain_dbg[256 * 8 * 12];
+#define TS(n) { const long long t_ = clock64(); tacc[n] += t_ - tlast; tlast = t_; }
+template <int ABL>
+__global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
+  long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();""")
+rep("""    const int* sdk = sd + (int)(k % 3) * 2 * ER;
+""","""    const int* sdk = sd + (int)(k % 3) * 2 * ER;
+    TS(0)
+""")
+rep("""    __syncthreads();   // images, residual rows, the next tile's indices ready
+""","""    TS(1)
+    __syncthreads();   // images, residual rows, the next tile's indices ready
+    TS(2)
+""")
+rep("""    __syncthreads();   // og = ge(i-1) rows complete; every wave is done with the gt images
+""","""    TS(3)
+    __syncthreads();   // og = ge(i-1) rows complete; every wave is done with the gt images
+    TS(4)
+""")
+rep("""    __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
+""","""    TS(5)
+    __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
+    TS(6)
+""")
+rep("""    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
+      const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
+      gather(sdn[row], sdn[ER + row]);
+    }
+""","""    TS(7)
+    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
+      const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
+      gather(sdn[row], sdn[ER + row]);
+    }
+    TS(8)
+""")
+rep("""  float* sl = a.slab + (size_t)chunk * SW * SW;
+""","""  if ((tid & 63) == 0 && blockIdx.x < 256) {
+    for (int q = 0; q < 10; ++q) g_chain_dbg[(blockIdx.x * 8 + wave) * 12 + q] = tacc[q];
+    g_chain_dbg[(blockIdx.x * 8 + wave) * 12 + 10] = ntile;
+  }
+  float* sl = a.slab + (size_t)chunk * SW * SW;
+""")
+s=s.rstrip('\n')+"""
+
+extern "C" int gnm_debug_chain_timing(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnm::g_chain_dbg), sizeof(long long) * 256 * 8 * 12);
+}
+"""
+open(p,'w').write(s)
+import os
+if os.environ.get("WALK_LDS_STORE"):
+    s=open(p).read()
+    old="          st4(wout + (int64_t)cur * wpitch, acc0);\n"
+    assert s.count(old)==1
+    s=s.replace(old,"          st4(v1 + ((cur & 15) * SW) + wc4, acc0);   // EXPERIMENT: LDS store instead of the global store\n")
+    open(p,'w').write(s)
