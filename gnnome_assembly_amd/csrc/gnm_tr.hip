@@ -422,7 +422,7 @@ constexpr int CT = 512;                    // threads per workgroup
 #define GNM_WALK_GROUP 4
 #endif
 constexpr int WG_ = GNM_WALK_GROUP;        // rows per LDS read group of the column walk
-constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 4 * ER * SW * 4 + 3 * 2 * ER * 4;
+constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 5 * ER * SW * 4 + 3 * 2 * ER * 4;
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
 
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   float* v2 = v1 + ER * SW;                                              // gu
   float* v3 = v2 + ER * SW;                                              // that
   float* tl = v3 + ER * SW;                                              // t(i-1) rows (written and read by the same thread)
-  int* sd = reinterpret_cast<int*>(tl + ER * SW);                        // ring of 3 tiles x [src 16 | dst 16]
+  float* ef = tl + ER * SW;                                              // e_out(i-1) rows in fp32 (same thread writes and reads)
+  int* sd = reinterpret_cast<int*>(ef + ER * SW);                        // ring of 3 tiles x [src 16 | dst 16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -569,6 +570,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
                    cc = ld4(cs + 6 * SW + lc4);
       st4(og + row * EOP + lc4, pg);
       st4(tl + row * SW + lc4, pl);
+      st4(ef + row * SW + lc4, pe_);                  // for the sigmoid of the by-destination pass (cheaper than re-joining the split images)
       const float4 gu = gate4(fma4(pt, sc, sh), pg);
       float4 gt = cc * (gu - m1 - ((pt - mu) * rs) * m2);
       if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       const float4 ge4 = ld4(og + row * EOP + lc4);
       const float4 tt = ld4(tl + row * SW + lc4);
       float4 sg = ge4, dsg = tt;
-      if (!(ABL & 2)) sigmoid_grad4(simg_load_f32(ie, EIMG, row, lc4), sg, dsg);
+      if (!(ABL & 2)) sigmoid_grad4(ld4(ef + row * SW + lc4), sg, dsg);
       const float4 gsig = fma4(gqf, ga2, fma4(gqb, ga3, f4(0.f) - gqf * ghf - gqb * ghb));
       const float4 g = fma4(gsig, dsg, ge4);
       const bool live = row < nvalid;        // rows past the chunk repeat its last row's indices: their terms are zeroed HERE
