@@ -91,7 +91,19 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
   __builtin_nontemporal_store(w, reinterpret_cast<floatx4_*>(p));
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// IEEE division + OCML expf (about 30 VALU instructions): for the once-per-edge uses (loss)
+__device__ __forceinline__ float sigmoid_ieee_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The gate sigmoid is evaluated for every element of every [E,H] pass (five kernels per layer); with IEEE division and
+// OCML's expf that alone was ~0.7 ms of VALU issue per kernel.  Hardware forms instead: ea = 2^(-|x| log2 e) on
+// v_exp_f32 (1 ulp; the product's rounding adds |x| * 4e-8 relative to ea, which only matters where sigma is
+// saturated), r = v_rcp_f32(1 + ea) (1 ulp, argument in [1,2]); sigma = r or ea*r -- no overflow, no 1 - sigma
+// cancellation.  ~7 instructions; forward and backward use the SAME expressions, so sigma' is consistent with sigma.
+__device__ __forceinline__ float gate_exp_(float x) { return __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigmoidf_(float x) {
+  const float ea = gate_exp_(x);
+  const float r = __builtin_amdgcn_rcpf(1.0f + ea);
+  return x >= 0.f ? r : ea * r;
+}
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -108,8 +120,8 @@ __device__ __forceinline__ float4 sigmoid4(float4 a) { return make_float4(sigmoi
 // (for |x| ~ 10 the fp32 difference 1 - sigma keeps only ~3 digits):
 //   ea = exp(-|x|), r = 1/(1+ea):  sigma = x >= 0 ? r : ea*r ;  sigma' = ea*r*r
 __device__ __forceinline__ void sigmoid_grad_(float x, float& sg, float& dsg) {
-  const float ea = expf(-fabsf(x));
-  const float r = 1.0f / (1.0f + ea);
+  const float ea = gate_exp_(x);
+  const float r = __builtin_amdgcn_rcpf(1.0f + ea);
   sg = x >= 0.f ? r : ea * r;
   dsg = ea * r * r;
 }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void bce_fwd_bwd_k(int64_t E, const float* 
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < E; i += (int64_t)gridDim.x * kBlock) {
     const float xi = x[i], yi = y[i];
-    const float p = sigmoidf_(xi);
+    const float p = sigmoid_ieee_(xi);
     acc += (double)(pw * yi * softplusf_(-xi) + (1.f - yi) * softplusf_(xi));
     gscore[i] = (-pw * yi * (1.f - p) + (1.f - yi) * p) * inv_e;
   }
