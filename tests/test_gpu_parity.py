@@ -908,6 +908,43 @@ def test_lean_activation_mode_is_bit_identical_and_smaller():
                                              # them for at most two layers at a time
 
 
+def test_chained_backward_matches_the_layer_by_layer_backward():
+    """engine.CHAIN (default, bf16x3 mode): layer i's fused edge backward and layer i-1's by-destination pass run in
+    one kernel.  Same arithmetic as L x layer_backward up to the order of the fp32 partial sums of the weight
+    gradients: every gradient agrees to 2e-5 (the B_3 weight gradient: other row partition of the same products),
+    the loss and the logits are bit-identical (the forward does not change)."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(30000, 128, 4, 3, dev)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    e, pe, y = (torch.from_numpy(inp[k]).to(dev) for k in ("e", "pe", "y"))
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+
+    def run(chain):
+        old, engine.CHAIN = engine.CHAIN, chain
+        try:
+            model.zero_grad(set_to_none=True)
+            s = model(g, None, e, pe)
+            loss = crit(s.squeeze(-1), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
+        finally:
+            engine.CHAIN = old
+    s0, l0, g0 = run(False)
+    s1, l1, g1 = run(True)
+    assert torch.equal(s0, s1) and l0 == l1
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    bad = []
+    for k in g0:
+        a, b = g1[k].double(), g0[k].double()
+        r = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        if r > 2e-5 and float((a - b).abs().max()) > 1e-6 * gmax:
+            bad.append((k, r))
+    assert not bad, bad
+
+
 @pytest.mark.default_mode_only
 def test_chr1_scale_inference_at_size():
     """BASELINE config 5 at its size (chr1 = 4.03 x chr19 -> R=3 M reads, N=6 M nodes, E~30 M edges,
