@@ -21,6 +21,7 @@ int num_cus();
 // out[i] = sum_b partials[b*row_stride + off + i], i < n (gnm_misc.hip)
 int reduce_partials_strided(const double* partials, int nblk, int row_stride, int off, int n, float* out,
                             void* stream);
+int reduce_partials_batched(const double* partials, int batch, int nblk, int W, float* out, void* stream);
 
 #define GNM_CHECK_ARG(cond, ...)                     \
   do {                                               \

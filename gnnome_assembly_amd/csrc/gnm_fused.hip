@@ -1465,6 +1465,8 @@ __global__ __launch_bounds__(kBlock, 2) void tn_colgroup32_b3_k(
 
 // out[i] = sum_b slab[b][i], fixed order -> deterministic
 __global__ void slab_reduce_k(const float* __restrict__ slab, int nslab, int total, float* __restrict__ out) {
+  slab += (size_t)blockIdx.y * nslab * total;       // blockIdx.y = batch: its own nslab slabs -> its own `total` outputs
+  out += (size_t)blockIdx.y * total;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     // four independent chains (fixed order -> still deterministic): one chain of nslab dependent loads was
     // the fixed cost that showed on small graphs
@@ -1719,11 +1721,9 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
     hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
                        nslot, cdiv_(ntiles, nslot));
   GNM_LAUNCH_CHECK("tn_colgroup");
-  for (int cg = 0; cg < ncg; ++cg) {
-    hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cg * nslot * FH * FH,
-                       nslot, FH * FH, gW + (size_t)cg * FH * FH);
-    if (gnm_reduce_partials(partials + (size_t)cg * nslot * FH, nslot, 1, FH, gb + cg * FH, stream)) return -3;
-  }
+  // one launch each for all column groups (same per-element summation order as one launch per group)
+  hipLaunchKernelGGL(slab_reduce_k, dim3(64, ncg), dim3(256), 0, st, (const float*)slab, nslot, FH * FH, gW);
+  if (reduce_partials_batched(partials, ncg, nslot, FH, gb, stream)) return -3;
   GNM_LAUNCH_CHECK("tn_colgroup reduce");
   return 0;
 }
@@ -1815,8 +1815,13 @@ template <class MM>
 static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* W, const float* gh_out, float* gh_in,
                             void* ws, hipStream_t st) {
   const int ncg = ncols / FH;
-  for (int cg = 0; cg < ncg; ++cg)   // W rows cg*128.. form the [k=128, c=128] block of group cg
-    launch_pack<MM>(W + (size_t)cg * FH * FH, FH, FH / 32, 1, (char*)ws + (size_t)cg * 4 * MM::kPackBytes, st);
+  if constexpr (MM::kSplit) {        // W rows cg*128.. form the [k=128, c=128] block of group cg: ONE launch for all groups
+    // (pack_w3_gen_k with one output class: k runs over the whole stacked weight, block (cg*4 + wv) as pack_w3_k lays it out)
+    hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
+  } else {
+    for (int cg = 0; cg < ncg; ++cg)
+      launch_pack<MM>(W + (size_t)cg * FH * FH, FH, FH / 32, 1, (char*)ws + (size_t)cg * 4 * MM::kPackBytes, st);
+  }
   GNM_LAUNCH_CHECK("pack_w (NN, node)");
   if constexpr (MM::kSplit) {
     constexpr int T = 4;

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256) void reduce_partials_k(const double* __restric
   const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + c;
   if (stride < 0) stride = total;          // dense rows
+  // blockIdx.y = batch (gnm::reduce_partials_batched): batch g reads its own nblk rows and writes its own `total` outputs
+  partials += (size_t)blockIdx.y * nblk * stride;
+  out += (size_t)blockIdx.y * total;
   double acc = 0.0;
   if (col < total)
     for (int b = r; b < nblk; b += 16) acc += partials[(size_t)b * stride + off + col];
@@ -254,6 +257,15 @@ extern "C" int gnm_reduce_partials(const double* partials, int nblk, int rows, i
   hipLaunchKernelGGL(reduce_partials_k, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                      partials, nblk, total, out, (int64_t)-1, 0);
   GNM_LAUNCH_CHECK("reduce_partials");
+  return 0;
+}
+
+// `batch` independent reductions in one launch: out[g][i] = sum_b partials[(g*nblk + b)*W + i], i < W
+int gnm::reduce_partials_batched(const double* partials, int batch, int nblk, int W, float* out, void* stream) {
+  GNM_CHECK_ARG(partials && batch > 0 && nblk > 0 && W > 0 && out, "reduce_partials_batched: bad argument");
+  hipLaunchKernelGGL(reduce_partials_k, dim3((W + 15) / 16, batch), dim3(256), 0, (hipStream_t)stream, partials, nblk, W,
+                     out, (int64_t)-1, 0);
+  GNM_LAUNCH_CHECK("reduce_partials_batched");
   return 0;
 }
 
