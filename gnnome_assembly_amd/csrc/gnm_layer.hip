@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_dst_k(
 
 // by-source backward pass.  See gnm.h for the arithmetic.
 template <int H>
-__global__ __launch_bounds__(kBlock) void edge_bwd_src_k(
+__global__ __launch_bounds__(kBlock, 7) void edge_bwd_src_k(
     int64_t N, const float* __restrict__ e_out, const float* __restrict__ t,
     const float* __restrict__ stat, const float* __restrict__ bstat,
     const float* __restrict__ gamma, const float* __restrict__ ge, const float* __restrict__ Q,
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_src_k(
   const int64_t v1 = min(N, v0 + nodes_per_block);
   const float4 mu = ld4(stat + c4), rs = ld4(stat + H + c4);
   const float4 sc = ld4(stat + 2 * H + c4), sh = ld4(stat + 3 * H + c4);
-  const float4 m1 = ld4(bstat + c4), m2 = ld4(bstat + H + c4);
-  const float4 c = ld4(gamma + c4) * rs;
+  // m1, m2, gamma are only needed once per node: they are re-read there (L1 hits) instead of living in 12 registers
+  // across the gather loop -- the loop's occupancy (loads in flight) is what this latency-bound kernel runs on
   for (int64_t v = v0 + wave; v < v1; v += kWavesPerBlock) {
     const int a = out_ptr[v], b = out_ptr[v + 1];
     float4 a2acc = f4(0.f), us = f4(0.f), ts = f4(0.f);
@@ -325,6 +325,11 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_src_k(
       ts += shfl_xor4(ts, off);
     }
     if (sub == 0) {
+      const float* bs = bstat;
+      const float* gm = gamma;
+      asm volatile("" : "+s"(bs), "+s"(gm));     // opaque to the loop-invariant hoisting that would keep them live
+      const float4 m1 = ld4(bs + c4), m2 = ld4(bs + H + c4);
+      const float4 c = ld4(gm + c4) * rs;
       const float outdeg = (float)(b - a);
       const float indeg = (float)(in_ptr[v + 1] - in_ptr[v]);
       float* g = gP + v * (5 * H) + c4;
