@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void edge_t_stats_fwd_k(int64_t E, float* _
 // e_out = relu(bn(t)) + e_in ; sigma = sigmoid(e_out) ; by-destination gated mean.
 // gated_gcn_full.py:122-130
 template <int H>
-__global__ __launch_bounds__(kBlock) void edge_gate_fwd_k(int64_t N, const float* __restrict__ t,
+__global__ __launch_bounds__(kBlock, 8) void edge_gate_fwd_k(int64_t N, const float* __restrict__ t,
                                                           const float* __restrict__ e_in,
                                                           const float* __restrict__ stat,
                                                           const float* __restrict__ P,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void edge_gate_fwd_k(int64_t N, const float
 // by-source gated mean on the same gate, z = A1h + hf + hb, partial (sum z, sum z^2).
 // gated_gcn_full.py:133-145
 template <int H>
-__global__ __launch_bounds__(kBlock) void node_agg_src_fwd_k(
+__global__ __launch_bounds__(kBlock, 8) void node_agg_src_fwd_k(
     int64_t N, const float* __restrict__ e_out, const float* __restrict__ P,
     const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos,
     const int32_t* __restrict__ out_dst, const float* __restrict__ hf, float* __restrict__ hb,
