@@ -10,6 +10,7 @@
 #include "gnm_common.h"
 
 namespace gnm {
+int enc_bwd_variant();     // gnm_fused.hip (gnm_debug_set_variant)
 
 constexpr int EH = 128;      // hidden width
 constexpr int EQ = 16;       // hidden_edge_features
@@ -174,6 +175,157 @@ __global__ __launch_bounds__(kBlock) void edge_encoder_bwd_k(int64_t E, const fl
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same backward on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate).
+// The VALU kernel above issues ~250 instructions per row and lane (16 hidden units x 8 FMAs + a 16-shuffle
+// reduce-scatter) and runs at 1.8 TB/s; both contractions are small dense products per 16-row tile:
+//   NN  ga1pre[16 rows][16 q]  = ge0[16 rows][128 c] W2[128 c][16 q]     32 MFMAs, contraction over c
+//   TN  gW2[128 c][16 q]      += ge0[16 rows][128 c]^T a1[16 rows][16 q]  32 MFMAs, contraction over rows
+// One wave per 16-row tile; the tile is loaded coalesced (512-byte rows), parked in a wave-private LDS image of
+// pitch 132 floats and read back in the two operand layouts.  The order of a contraction is free, so both are
+// arranged for reads without shuffles: lane (i = l & 15, g = l >> 4)
+//   NN step (j, c): A = tile[i][16 j + 4 g + c] (the c-th word of ONE ds_read_b128), B = W2[16 j + 4 g + c][q = i]
+//   TN step s, column block cb: A = tile[4 g + s][16 cb + i], B = a1[4 g + s][q = i] -- exactly the four rows the
+//   lane holds of the NN result (C layout of the 16 x 16 MFMA: row 4 g + r, column l & 15).
+// relu mask, gW1, gb1 in that C layout; gb2 from the coalesced load registers.  Partials as above.
+// ------------------------------------------------------------------------------------------
+typedef float floatx4m __attribute__((ext_vector_type(4)));
+constexpr int ET = 16;            // rows per wave tile
+constexpr int EPL = EH + 4;       // LDS pitch (floats): conflict-free b128 rows and transposed b32 reads
+constexpr int ENC_LDS = (kWavesPerBlock * ET * EPL > kWavesPerBlock * ENP ? kWavesPerBlock * ET * EPL : kWavesPerBlock * ENP);
+
+__global__ __launch_bounds__(kBlock) void edge_encoder_bwd_mfma_k(int64_t E, const float* __restrict__ ge0,
+                                                                  const float* __restrict__ e_raw,
+                                                                  const int32_t* __restrict__ perm,
+                                                                  const float* __restrict__ W1,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ W2,
+                                                                  double* __restrict__ partials,
+                                                                  int64_t tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) float lds[ENC_LDS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;           // MFMA operand / result coordinates
+  const int cr = lane >> 5, cc4 = (lane & 31) * 4;  // coalesced load coordinates: rows cr, cr + 2, .. ; columns cc4 .. +3
+  float* tile = lds + wave * ET * EPL;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (E + ET - 1) / ET;
+  const int64_t t0 = (int64_t)chunk * tiles_per_block;
+  const int64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+  const int64_t Elast = E - 1;
+  // B operand of the NN product: W2[16 j + 4 g + c][q = i], 32 registers, stationary
+  float w2r[32];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w2r[4 * j + c] = W2[(16 * j + 4 * g + c) * EQ + i];
+  const float w1a = W1[2 * i], w1b = W1[2 * i + 1], bq = b1[i];
+  floatx4m gw2[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) gw2[cb] = (floatx4m){0.f, 0.f, 0.f, 0.f};
+  float4 gb2 = f4(0.f);
+  float gw1_0 = 0.f, gw1_1 = 0.f, gb1_ = 0.f;
+  // software pipeline: perm two tiles ahead, the tile's rows and features one tile ahead; every wave of the workgroup
+  // runs the same number of iterations (tiles past the end are clamped and contribute zeros), so the barriers match
+  const int64_t niter = (tiles_per_block + kWavesPerBlock - 1) / kWavesPerBlock;
+  auto tile_of = [&](int64_t it) __attribute__((always_inline)) { return t0 + wave + it * kWavesPerBlock; };
+  auto clampr = [&](int64_t r) __attribute__((always_inline)) { return r < Elast ? r : Elast; };
+  float4 gn[8];
+  int kn[4];
+  float2 xn[4];
+  auto load_rows = [&](int64_t t) __attribute__((always_inline)) {
+    const int64_t r0 = t * ET;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) gn[it] = ld4_nt(ge0 + clampr(r0 + 2 * it + cr) * EH + cc4);
+  };
+  auto load_perm = [&](int64_t t) __attribute__((always_inline)) {
+    const int64_t r0 = t * ET;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) kn[s_] = perm[clampr(r0 + 4 * g + s_)];
+  };
+  auto load_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) xn[s_] = *reinterpret_cast<const float2*>(e_raw + 2 * (int64_t)kn[s_]);
+  };
+  load_perm(tile_of(0));
+  load_rows(tile_of(0));
+  load_x();
+  load_perm(tile_of(1));
+  for (int64_t it = 0; it < niter; ++it) {
+    const int64_t t = tile_of(it);
+    const int64_t r0 = t * ET;
+    const bool live_tile = t < t1;
+    float2 x[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) x[s_] = xn[s_];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool live = live_tile && r0 + 2 * q + cr < E;
+      const float4 v = live ? gn[q] : f4(0.f);        // rows past the end contribute nothing anywhere below
+      gb2 += v;
+      st4(tile + (2 * q + cr) * EPL + cc4, v);
+    }
+    load_x();                                          // features of the next tile (its perm was requested a tile ago)
+    load_rows(tile_of(it + 1));
+    load_perm(tile_of(it + 2));
+    __syncthreads();
+    // ---- NN: ga1pre = ge0 W2 ----
+    floatx4m cacc = (floatx4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 a4 = ld4(tile + i * EPL + 16 * j + 4 * g);
+      cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w2r[4 * j + 0], cacc, 0, 0, 0);
+      cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w2r[4 * j + 1], cacc, 0, 0, 0);
+      cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w2r[4 * j + 2], cacc, 0, 0, 0);
+      cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w2r[4 * j + 3], cacc, 0, 0, 0);
+    }
+    // ---- relu of linear1_edge for rows 4 g + s, unit q = i; its backward; gW1, gb1 ----
+    float a1[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const float ap = fmaf(w1a, x[s_].x, fmaf(w1b, x[s_].y, bq));
+      a1[s_] = fmaxf(ap, 0.f);
+      const float ga = ap > 0.f ? cacc[s_] : 0.f;
+      gw1_0 = fmaf(ga, x[s_].x, gw1_0);
+      gw1_1 = fmaf(ga, x[s_].y, gw1_1);
+      gb1_ += ga;
+    }
+    // ---- TN: gW2[16 cb + 4 g + r][q] += sum_rows ge0[row][16 cb + ..] a1[row][q] ----
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+        gw2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(tile[(4 * g + s_) * EPL + 16 * cb + i], a1[s_], gw2[cb], 0, 0, 0);
+    }
+    __syncthreads();                                   // the tile image is rewritten by the next iteration
+  }
+  // ---- per-wave results -> red[wave][ENP] (the tile images are dead), then the 4 waves in fp64 ----
+  float* r = lds + wave * ENP;
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[(16 * cb + 4 * g + e) * EQ + i] = gw2[cb][e];
+  gb2 += shfl_xor4(gb2, 32);                           // the two row slots of the coalesced layout
+  if (cr == 0) {
+    r[EH * EQ + cc4 + 0] = gb2.x; r[EH * EQ + cc4 + 1] = gb2.y;
+    r[EH * EQ + cc4 + 2] = gb2.z; r[EH * EQ + cc4 + 3] = gb2.w;
+  }
+  gw1_0 += __shfl_xor(gw1_0, 16, 64); gw1_1 += __shfl_xor(gw1_1, 16, 64); gb1_ += __shfl_xor(gb1_, 16, 64);
+  gw1_0 += __shfl_xor(gw1_0, 32, 64); gw1_1 += __shfl_xor(gw1_1, 32, 64); gb1_ += __shfl_xor(gb1_, 32, 64);
+  if (g == 0) {
+    r[EH * EQ + EH + 2 * i + 0] = gw1_0;
+    r[EH * EQ + EH + 2 * i + 1] = gw1_1;
+    r[EH * EQ + EH + 2 * EQ + i] = gb1_;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ENP; k += kBlock) {
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) acc += (double)lds[w * ENP + k];
+    partials[(size_t)chunk * ENP + k] = acc;
+  }
+}
+
 }  // namespace gnm
 
 using namespace gnm;
@@ -202,12 +354,21 @@ extern "C" int gnm_edge_encoder_bwd(int64_t E, int H, int F, int Q, const float*
                                     void* stream) {
   GNM_CHECK_ARG(H == EH && F == 2 && Q == EQ, "edge_encoder_bwd: built for H=128, edge_features=2, hidden=16 (got %d,%d,%d)", H, F, Q);
   GNM_CHECK_ARG(E >= 0 && ge0 && e_raw && perm && W1 && b1 && W2 && gW1 && gb1 && gW2 && gb2, "edge_encoder_bwd: null/neg argument");
-  const int grid = persistent_grid(E, 256, occ_blocks<edge_encoder_bwd_k>());
-  GNM_CHECK_ARG(ws && ws_bytes >= (size_t)grid * ENP * sizeof(double), "edge_encoder_bwd: workspace too small");
-  const int64_t rpb = (E + grid - 1) / grid;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(edge_encoder_bwd_k, dim3(grid), dim3(kBlock), 0, st, E, ge0, e_raw, perm, W1, b1, W2,
-                     (double*)ws, rpb);
+  int grid;
+  if (enc_bwd_variant() == 0) {        // the VALU kernel (round 1), kept for A/B (gnm_debug_set_variant("enc_bwd", 0))
+    grid = persistent_grid(E, 256, occ_blocks<edge_encoder_bwd_k>());
+    GNM_CHECK_ARG(ws && ws_bytes >= (size_t)grid * ENP * sizeof(double), "edge_encoder_bwd: workspace too small");
+    const int64_t rpb = (E + grid - 1) / grid;
+    hipLaunchKernelGGL(edge_encoder_bwd_k, dim3(grid), dim3(kBlock), 0, st, E, ge0, e_raw, perm, W1, b1, W2,
+                       (double*)ws, rpb);
+  } else {
+    const int64_t ntiles = (E + ET - 1) / ET;
+    grid = persistent_grid(ntiles, 16, occ_blocks<edge_encoder_bwd_mfma_k>());
+    GNM_CHECK_ARG(ws && ws_bytes >= (size_t)grid * ENP * sizeof(double), "edge_encoder_bwd: workspace too small");
+    hipLaunchKernelGGL(edge_encoder_bwd_mfma_k, dim3(grid), dim3(kBlock), 0, st, E, ge0, e_raw, perm, W1, b1, W2,
+                       (double*)ws, (ntiles + grid - 1) / grid);
+  }
   GNM_LAUNCH_CHECK("edge_encoder_bwd");
   // gW2 | gb2 | gW1 | gb1 are contiguous in the partial rows; reduce each piece into its tensor
   const double* p = (const double*)ws;

@@ -1522,10 +1522,13 @@ static int g_tn_variant = 1;     // split mode: 1 = tn_tr_k (transpose reads), 0
 static int g_eb_variant = 1;     // split mode: 1 = edge_bwd_tr_k (16-row tiles, two workgroups per CU), 0 = edge_bwd_fused_k<MmB3>
 namespace gnm {
 int eb_variant() { return g_eb_variant; }
+static int g_enc_bwd = 1;        // edge encoder backward: 1 = fp32-MFMA kernel, 0 = VALU kernel (round 1)
+int enc_bwd_variant() { return g_enc_bwd; }
 }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "tn")) { g_tn_variant = v; return 0; }
   if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
+  if (what && !strcmp(what, "enc_bwd")) { g_enc_bwd = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }
