@@ -221,6 +221,150 @@ static void plan_split(int mode, int64_t M, int64_t N, int64_t K, int* splits, i
   *splits = (int)((ktiles + tiles_per - 1) / tiles_per);
 }
 
+// ------------------------------------------------------------------------------------------
+// Skinny weight gradient on the fp32 matrix cores:  C[128, N] = X[K, 128]^T Y[K, N]  (N <= 32, K rows huge) and the
+// column sums of X -- e.g. linear_pe (full_graph.py:23): gW = gh^T pe with pe 18 wide, gb = sum gh.  The 128 x 128
+// tiled kernel above spends 7/8 of its MFMAs on padding there.  Structure of gnm_encoder.hip's MFMA backward: one wave
+// per 16-row tile of X (coalesced load, wave-private LDS image of pitch 132), v_mfma_f32_16x16x4_f32 with
+//   A = X[row 4 g + s][16 cb + i]  (transposed read of the image),   B = Y[row 4 g + s][16 qb + i]  (read from global),
+// lane (i = l & 15, g = l >> 4), step s = 0..3 -- the contraction order over the tile's rows is free.
+// partials[chunk][128 x 32 | 128] in fp64, reduced in a fixed order by tn_skinny_finish_k.
+// ------------------------------------------------------------------------------------------
+typedef float floatx4s __attribute__((ext_vector_type(4)));
+constexpr int SKT = 16, SKW = 128, SKP = SKW + 4, SKQ = 32;
+constexpr int SKN = SKW * SKQ + SKW;                  // partial sums per workgroup
+constexpr int SK_LDS = kWavesPerBlock * SKN;          // floats (>= the four tile images)
+constexpr int kSkinnyMaxBlocks = 1024;
+
+template <int NB>
+__global__ __launch_bounds__(kBlock) void tn_skinny128_k(int64_t K, const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ Y, int64_t ldy, int N,
+                                                         double* __restrict__ partials, int64_t tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) float lds[SK_LDS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int cr = lane >> 5, cc4 = (lane & 31) * 4;
+  float* tile = lds + wave * SKT * SKP;
+  const int64_t ntiles = (K + SKT - 1) / SKT;
+  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
+  const int64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+  const int64_t Klast = K - 1;
+  floatx4s acc[NB][8];
+#pragma unroll
+  for (int qb = 0; qb < NB; ++qb)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) acc[qb][cb] = (floatx4s){0.f, 0.f, 0.f, 0.f};
+  float4 cs = f4(0.f);
+  const int64_t niter = (tiles_per_block + kWavesPerBlock - 1) / kWavesPerBlock;
+  auto tile_of = [&](int64_t it) __attribute__((always_inline)) { return t0 + wave + it * kWavesPerBlock; };
+  auto clampr = [&](int64_t r) __attribute__((always_inline)) { return r < Klast ? r : Klast; };
+  float4 xn[8];
+  float yn[NB][4];
+  auto load_tile = [&](int64_t t) __attribute__((always_inline)) {
+    const int64_t r0 = t * SKT;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xn[q] = ld4_nt(X + clampr(r0 + 2 * q + cr) * ldx + cc4);
+#pragma unroll
+    for (int qb = 0; qb < NB; ++qb)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int col = 16 * qb + i;
+        yn[qb][s_] = Y[clampr(r0 + 4 * g + s_) * ldy + (col < N ? col : 0)];
+      }
+  };
+  load_tile(tile_of(0));
+  for (int64_t it = 0; it < niter; ++it) {
+    const int64_t t = tile_of(it);
+    const int64_t r0 = t * SKT;
+    const bool live_tile = t < t1;
+    float y[NB][4];
+#pragma unroll
+    for (int qb = 0; qb < NB; ++qb)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) y[qb][s_] = (16 * qb + i < N) ? yn[qb][s_] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool live = live_tile && r0 + 2 * q + cr < K;
+      const float4 v = live ? xn[q] : f4(0.f);        // rows past the end contribute nothing
+      cs += v;
+      st4(tile + (2 * q + cr) * SKP + cc4, v);
+    }
+    load_tile(tile_of(it + 1));
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const float a = tile[(4 * g + s_) * SKP + 16 * cb + i];
+#pragma unroll
+        for (int qb = 0; qb < NB; ++qb) acc[qb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, y[qb][s_], acc[qb][cb], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+  // C / D of the 16 x 16 MFMA: row 4 g + e (= X column 16 cb + 4 g + e), column l & 15 (= Y column 16 qb + i)
+  float* r = lds + wave * SKN;
+  for (int k = lane; k < SKN; k += 64) r[k] = 0.f;     // the unused 16-column block when NB == 1
+#pragma unroll
+  for (int qb = 0; qb < NB; ++qb)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[(16 * cb + 4 * g + e) * SKQ + 16 * qb + i] = acc[qb][cb][e];
+  cs += shfl_xor4(cs, 32);
+  if (cr == 0) {
+    r[SKW * SKQ + cc4 + 0] = cs.x; r[SKW * SKQ + cc4 + 1] = cs.y;
+    r[SKW * SKQ + cc4 + 2] = cs.z; r[SKW * SKQ + cc4 + 3] = cs.w;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SKN; k += kBlock) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) a += (double)lds[w * SKN + k];
+    partials[(size_t)blockIdx.x * SKN + k] = a;
+  }
+}
+
+// C[m * ldc + n] = sum_b partials[b][m * 32 + n] (n < N), colsum[m] = sum_b partials[b][128 * 32 + m]; fixed order
+__global__ void tn_skinny_finish_k(const double* __restrict__ partials, int nblk, int N, float* __restrict__ C, int64_t ldc,
+                                   float* __restrict__ colsum) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= SKN) return;
+  const int m = k < SKW * SKQ ? k / SKQ : k - SKW * SKQ, n = k < SKW * SKQ ? k % SKQ : -1;
+  if (n >= N || (n < 0 && !colsum)) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    a0 += partials[(size_t)b * SKN + k];
+    a1 += partials[(size_t)(b + 1) * SKN + k];
+    a2 += partials[(size_t)(b + 2) * SKN + k];
+    a3 += partials[(size_t)(b + 3) * SKN + k];
+  }
+  for (; b < nblk; ++b) a0 += partials[(size_t)b * SKN + k];
+  const float v = (float)((a0 + a1) + (a2 + a3));
+  if (n >= 0) C[(int64_t)m * ldc + n] = v;
+  else colsum[m] = v;
+}
+
+static bool tn_skinny_shape_ok(int64_t M, int64_t N, int64_t K) { return M == SKW && N >= 1 && N <= SKQ && K >= 4096; }
+static size_t tn_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return tn_skinny_shape_ok(M, N, K) ? (size_t)kSkinnyMaxBlocks * SKN * sizeof(double) : 0;
+}
+// 1 = done, 0 = not eligible
+static int tn_skinny_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                         int64_t ldc, float* colsum, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!tn_skinny_shape_ok(M, N, K) || (uintptr_t)A % 16 != 0 || lda % 4 != 0 || !ws || ws_bytes < tn_skinny_workspace_bytes(M, N, K))
+    return 0;
+  const int64_t ntiles = (K + SKT - 1) / SKT;
+  int grid = persistent_grid(ntiles, 16, N > 16 ? occ_blocks<tn_skinny128_k<2>>() : occ_blocks<tn_skinny128_k<1>>());
+  if (grid > kSkinnyMaxBlocks) grid = kSkinnyMaxBlocks;
+  const int64_t tpb = (ntiles + grid - 1) / grid;
+  if (N > 16) hipLaunchKernelGGL(tn_skinny128_k<2>, dim3(grid), dim3(kBlock), 0, st, K, A, lda, B, ldb, (int)N, (double*)ws, tpb);
+  else hipLaunchKernelGGL(tn_skinny128_k<1>, dim3(grid), dim3(kBlock), 0, st, K, A, lda, B, ldb, (int)N, (double*)ws, tpb);
+  hipLaunchKernelGGL(tn_skinny_finish_k, dim3((SKN + 255) / 256), dim3(256), 0, st, (const double*)ws, grid, (int)N, C, ldc, colsum);
+  return 1;
+}
+
 }  // namespace gnm
 
 using namespace gnm;
@@ -239,7 +383,9 @@ extern "C" size_t gnm_gemm_f32_workspace_bytes(int mode, int64_t M, int64_t N, i
   plan_split(mode, M, N, K, &splits, &kps);
   const size_t f32 = splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
   const size_t b3 = gemm_b3_workspace_bytes(mode, M, N, K);
-  return f32 > b3 ? f32 : b3;
+  const size_t sk = mode == GNM_GEMM_TN ? tn_skinny_workspace_bytes(M, N, K) : 0;
+  const size_t m2 = f32 > b3 ? f32 : b3;
+  return m2 > sk ? m2 : sk;
 }
 
 extern "C" int gnm_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -249,6 +395,11 @@ extern "C" int gnm_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const flo
   GNM_CHECK_ARG(mode >= 0 && mode <= 2, "gemm_f32: mode %d", mode);
   GNM_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && A && B && C, "gemm_f32: null/neg argument");
   if (M == 0 || N == 0) return 0;
+  if (mode == GNM_GEMM_TN && !bias && !resid && !relu &&
+      tn_skinny_try(M, N, K, A, lda, B, ldb, C, ldc, nullptr, ws, ws_bytes, (hipStream_t)stream)) {
+    GNM_LAUNCH_CHECK("gemm_f32 (skinny TN)");
+    return 0;
+  }
   {
     const int rc = gemm_b3_try(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, resid, ldr, relu, ws, ws_bytes, (hipStream_t)stream);
     if (rc < 0) { GNM_LAUNCH_CHECK("gemm_f32 (split route)"); return rc; }
@@ -298,6 +449,10 @@ extern "C" int gnm_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const float* 
   GNM_CHECK_ARG(M > 0 && N > 0 && K >= 0 && A && B && C && colsum, "gemm_tn_colsum: null/neg argument");
   GNM_CHECK_ARG(ws_bytes >= gnm_gemm_tn_colsum_workspace_bytes(M, N, K) && (ws || ws_bytes == 0),
                 "gemm_tn_colsum: workspace too small");
+  if (tn_skinny_try(M, N, K, A, lda, B, ldb, C, ldc, colsum, ws, ws_bytes, (hipStream_t)stream)) {
+    GNM_LAUNCH_CHECK("gemm_tn_colsum (skinny)");
+    return 0;
+  }
   const int rc = gemm_b3_tn_colsum_try(M, N, K, A, lda, B, ldb, C, ldc, colsum, ws, ws_bytes, (hipStream_t)stream);
   if (rc < 0) { GNM_LAUNCH_CHECK("gemm_tn_colsum (split route)"); return rc; }
   if (rc > 0) return 0;

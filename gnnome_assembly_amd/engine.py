@@ -814,8 +814,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     # encoders backward
     lib = _lib.load()
     G["linear_pe.weight"] = tgt("linear_pe.weight", P["linear_pe.weight"])
-    gemm(TN, gh, ms.pe, G["linear_pe.weight"])
-    G["linear_pe.bias"] = colsum(gh, out["linear_pe.bias"] if out else None)
+    G["linear_pe.bias"] = gemm_tn_colsum(gh, ms.pe, G["linear_pe.weight"], out["linear_pe.bias"] if out else None)
     G["linear2_edge.weight"] = tgt("linear2_edge.weight", P["linear2_edge.weight"])
     G["linear1_edge.weight"] = tgt("linear1_edge.weight", P["linear1_edge.weight"])
     if ms.a1 is None:      # fused encoder: every encoder gradient from one pass over ge

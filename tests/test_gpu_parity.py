@@ -97,7 +97,7 @@ def test_library_loaded_and_device():
     # big-M shapes with 128-multiple other dimensions: the split-mode route (gemm_rows_b3_k / tn_tr_k classes) under
     # bf16x3, the fp32-MFMA kernel under f32 -- the shapes of a hidden-256 model (the reference's default width)
     (0, 5000, 256, 256), (0, 3001, 1280, 256), (0, 2048, 128, 128), (1, 4100, 256, 256), (1, 2500, 256, 1280),
-    (2, 256, 256, 9000), (2, 1280, 256, 5003), (2, 256, 128, 4096),
+    (2, 256, 256, 9000), (2, 1280, 256, 5003), (2, 256, 128, 4096), (2, 128, 18, 9001),
 ])
 def test_gemm_f32(mode, M, N, K):
     from gnnome_assembly_amd import engine
@@ -126,7 +126,8 @@ def test_gemm_f32(mode, M, N, K):
     assert float(big[:, :4].abs().max()) == 0.0 and float(big[:, 4 + N:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 9000), (1280, 256, 5003), (128, 128, 4096), (64, 128, 3001), (128, 18, 1000)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 9000), (1280, 256, 5003), (128, 128, 4096), (64, 128, 3001), (128, 18, 1000),
+                                   (128, 18, 100003), (128, 32, 4500), (128, 7, 5003), (128, 16, 4096)])   # skinny fp32-MFMA route
 def test_gemm_tn_colsum(M, N, K):
     """gnm_gemm_tn_colsum: a Linear's weight and bias gradient in one call (split route where it applies, gemm + colsum
     otherwise) against fp64."""
