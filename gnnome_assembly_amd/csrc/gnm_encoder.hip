@@ -11,6 +11,7 @@
 
 namespace gnm {
 int enc_bwd_variant();     // gnm_fused.hip (gnm_debug_set_variant)
+int enc_fwd_variant();
 
 constexpr int EH = 128;      // hidden width
 constexpr int EQ = 16;       // hidden_edge_features
@@ -326,6 +327,76 @@ __global__ __launch_bounds__(kBlock) void edge_encoder_bwd_mfma_k(int64_t E, con
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward on the fp32 matrix cores, same recipe: per 16-row tile  e0[16][128] = a1[16][16] W2^T + b2  is 32
+// v_mfma_f32_16x16x4_f32 (contraction over the 16 hidden units, 4 per instruction); lane (i = l & 15, g = l >> 4):
+//   A = a1[row i][4 s + g] -- computed in place from the row's two features (same fmaf nesting as the VALU kernel, so
+//       the relu decisions are bit-identical),   B = W2[16 cb + i][4 s + g] (32 stationary registers),
+//   C = e0[row 4 g + r][16 cb + i] -> wave-private LDS image -> coalesced 512-byte rows (+ b2) to HBM.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void edge_encoder_fwd_mfma_k(int64_t E, const float* __restrict__ e_raw,
+                                                                  const int32_t* __restrict__ perm,
+                                                                  const float* __restrict__ W1,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ W2,
+                                                                  const float* __restrict__ b2,
+                                                                  float* __restrict__ e0, int64_t tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * ET * EPL];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int cr = lane >> 5, cc4 = (lane & 31) * 4;
+  float* tile = lds + wave * ET * EPL;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (E + ET - 1) / ET;
+  const int64_t t0 = (int64_t)chunk * tiles_per_block;
+  const int64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+  const int64_t Elast = E - 1;
+  float w2r[32];                               // W2[16 cb + i][4 s + g]
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) w2r[4 * cb + s_] = W2[(16 * cb + i) * EQ + 4 * s_ + g];
+  float w1a[4], w1b[4], bq[4];                 // hidden units 4 s + g
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) { w1a[s_] = W1[2 * (4 * s_ + g)]; w1b[s_] = W1[2 * (4 * s_ + g) + 1]; bq[s_] = b1[4 * s_ + g]; }
+  const float4 bb = ld4(b2 + cc4);
+  const int64_t niter = (tiles_per_block + kWavesPerBlock - 1) / kWavesPerBlock;
+  auto tile_of = [&](int64_t it) __attribute__((always_inline)) { return t0 + wave + it * kWavesPerBlock; };
+  auto clampr = [&](int64_t r) __attribute__((always_inline)) { return r < Elast ? r : Elast; };
+  // perm two tiles ahead, the row's features one tile ahead (a dependent pair of loads per row)
+  int kn = perm[clampr(tile_of(0) * ET + i)];
+  float2 xn = *reinterpret_cast<const float2*>(e_raw + 2 * (int64_t)kn);
+  kn = perm[clampr(tile_of(1) * ET + i)];
+  for (int64_t it = 0; it < niter; ++it) {
+    const int64_t t = tile_of(it);
+    const int64_t r0 = t * ET;
+    const float x0 = xn.x, x1 = xn.y;
+    xn = *reinterpret_cast<const float2*>(e_raw + 2 * (int64_t)kn);
+    kn = perm[clampr(tile_of(it + 2) * ET + i)];
+    float a1[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) a1[s_] = fmaxf(fmaf(w1a[s_], x0, fmaf(w1b[s_], x1, bq[s_])), 0.f);
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      floatx4m c = (floatx4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s_], w2r[4 * cb + s_], c, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[(4 * g + e) * EPL + 16 * cb + i] = c[e];
+    }
+    __syncthreads();
+    if (t < t1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int64_t row = r0 + 2 * q + cr;
+        if (row < E) st4_nt(e0 + row * EH + cc4, ld4(tile + (2 * q + cr) * EPL + cc4) + bb);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace gnm
 
 using namespace gnm;
@@ -335,7 +406,15 @@ extern "C" int gnm_edge_encoder_fwd(int64_t E, int H, int F, int Q, const float*
                                     float* e0, void* stream) {
   GNM_CHECK_ARG(H == EH && F == 2 && Q == EQ, "edge_encoder_fwd: built for H=128, edge_features=2, hidden=16 (got %d,%d,%d)", H, F, Q);
   GNM_CHECK_ARG(E >= 0 && e_raw && perm && W1 && b1 && W2 && b2 && e0, "edge_encoder_fwd: null/neg argument");
-  int64_t g = (E + 7) / 8;
+  if (enc_fwd_variant() != 0 && E > 0) {
+    const int64_t ntiles = (E + ET - 1) / ET;
+    const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_encoder_fwd_mfma_k>());
+    hipLaunchKernelGGL(edge_encoder_fwd_mfma_k, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, E, e_raw, perm, W1, b1,
+                       W2, b2, e0, (ntiles + grid - 1) / grid);
+    GNM_LAUNCH_CHECK("edge_encoder_fwd");
+    return 0;
+  }
+  int64_t g = (E + 7) / 8;             // the VALU kernel (gnm_debug_set_variant("enc_fwd", 0))
   const int64_t cap = (int64_t)num_cus() * 8;
   if (g > cap) g = cap;
   if (g < 1) g = 1;

@@ -1524,11 +1524,14 @@ namespace gnm {
 int eb_variant() { return g_eb_variant; }
 static int g_enc_bwd = 1;        // edge encoder backward: 1 = fp32-MFMA kernel, 0 = VALU kernel (round 1)
 int enc_bwd_variant() { return g_enc_bwd; }
+static int g_enc_fwd = 1;        // edge encoder forward: 1 = fp32-MFMA kernel, 0 = VALU kernel
+int enc_fwd_variant() { return g_enc_fwd; }
 }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "tn")) { g_tn_variant = v; return 0; }
   if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
   if (what && !strcmp(what, "enc_bwd")) { g_enc_bwd = v; return 0; }
+  if (what && !strcmp(what, "enc_fwd")) { g_enc_fwd = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }
