@@ -825,13 +825,19 @@ def test_train_loop_matches_the_reference_loop(tmp_path, golden_dir):
         assert np.allclose(g_, ref, rtol=1e-4, atol=0), (name, g_, ref)
     assert hist.lr == z["lr64"].tolist() and hist.final_lr == float(z["final_lr64"])       # ReduceLROnPlateau
     assert hist.best_epoch == int(z["best_epoch64"])
-    # TP/TN/FP/FN: predictions within round-off of 0.5 may fall either way (the reference's fp32 and fp64 runs
-    # differ by a few edges themselves); allow that band, exact where the two reference runs agree
+    # TP/TN/FP/FN: threshold statistics of the logits after k Adam steps at lr = 2e-2.  A prediction within the
+    # accumulated round-off of 0.5 falls either way, and that band widens with every step (Adam normalises each gradient
+    # entry, so fp32-level differences between two correct evaluations are re-amplified each step: the per-step losses
+    # above stay within 1e-4, the last epoch's logits differ by ~1e-3).  The first epoch must match the reference's
+    # fp64 run to the band its own fp32 run shows (+2 edges); later epochs additionally get 0.1 % of the edges counted
+    # (which of two equally valid fp32 backward kernels is used moves epoch 4 by 3-8 edges of 10,794).
     for name, g_, r64, r32 in (("train", hist.tfpn_train, z["tfpn_train64"], z["tfpn_train32"]),
                                ("valid", hist.tfpn_valid, z["tfpn_valid64"], z["tfpn_valid32"])):
         g_ = np.array(g_)
         assert g_.shape == r64.shape and np.array_equal(g_.sum(1), r64.sum(1))
-        assert np.all(np.abs(g_ - r64) <= 3 * np.abs(r32 - r64) + 2), (name, g_.tolist(), r64.tolist())
+        slack = np.full(g_.shape, 2.0)
+        slack[1:] = np.maximum(2.0, np.ceil(1e-3 * r64.sum(1, keepdims=True)[1:]))
+        assert np.all(np.abs(g_ - r64) <= 3 * np.abs(r32 - r64) + slack), (name, g_.tolist(), r64.tolist())
     # final weights after 8 Adam steps (strided sample) vs the fp64 run.  Adam normalises every gradient entry by
     # its own running magnitude, so an entry that is round-off-sized in one step moves by up to lr in either
     # direction: single elements differ by O(lr) between ANY two fp32 evaluations; the tensors as a whole agree
