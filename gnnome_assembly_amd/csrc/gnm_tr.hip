@@ -418,10 +418,7 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
 // four row streams AND the six gathered node rows of the NEXT tile are requested a tile ahead, so that no phase
 // waits on memory (the eight waves share every barrier, there is no second workgroup to hide a wait).
 constexpr int CT = 512;                    // threads per workgroup
-#ifndef GNM_WALK_GROUP
-#define GNM_WALK_GROUP 4
-#endif
-constexpr int WG_ = GNM_WALK_GROUP;        // rows per LDS read group of the column walk
+constexpr int WG_ = 4;                     // rows per LDS read group of the column walk (8 and 16 measured the same)
 constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 5 * ER * SW * 4 + 3 * 2 * ER * 4;
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
