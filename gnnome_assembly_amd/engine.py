@@ -462,6 +462,14 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
 # ONE kernel with the by-destination pass of layer i-1 (gnm_edge_bwd_chain: 5 [E,H] streams instead of 4 + 4, the
 # matrix-core work under the gather arithmetic).  GNM_CHAIN=0 / engine.CHAIN = False goes back to layer_backward.
 CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
+# Inside the chained schedule: layer i's node-projection weight gradient (gW5 = gP^T h_in, matrix-core bound, no consumer
+# before the optimizer step) is launched one workgroup per CU on a side stream BESIDE layer i-1's by-source pass (HBM
+# bound, capped at four workgroups per CU so that both fit a CU's registers: 168 + 4 x 80 of 512 per SIMD lane).
+# Measured on one box: 187.9 -> 183.8 ms/step; with five by-source workgroups the two kernels no longer co-reside and
+# nothing is gained.  GNM_TN_SIDE=0 keeps everything on one stream (the per-op timing mode always does).
+TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
+TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "1"))
+SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
@@ -522,21 +530,42 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
           _ptr(sc.partials), C.byref(nblk), st)
     if ACTIVATIONS == "lean":
         s.P = None              # as below: only the by-destination pass reads the rebuilt P
+    side = _side_stream(dev) if (TN_SIDE and _prof is None) else None
+    main = torch.cuda.current_stream()
+    pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
     while True:
         prm, s = prms[i], saved[i]
         o = outs[i] or {}
         g = grads[i]
         bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, o.get("gamma_e"), o.get("beta_e"))
+        if pending is not None:
+            # the matrix-bound weight gradient of the layer above, one workgroup per CU on the side stream, beside this
+            # layer's HBM-bound by-source pass (see TN_SIDE)
+            pgP, ph, pW, pb = pending
+            side.wait_stream(main)
+            sc3 = scratch(dev, "tn")
+            ws3 = sc3.ws(need_p)
+            lib.gnm_set_occupancy_cap(TN_SIDE_CAP)
+            _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(pgP), _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials),
+                                                _ptr(ws3), need_p, C.c_void_p(side.cuda_stream)), "gnm_node_proj_bwd_tn")
+            pgP.record_stream(side)
+            ph.record_stream(side)
+            pending = None
+            lib.gnm_set_occupancy_cap(SRC_SIDE_CAP)
         _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
               _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), st)
+        lib.gnm_set_occupancy_cap(0)
         del Ud, Td, Q
         g["W5"], g["b5"] = tgt(i, "W5", 5 * H, H), tgt(i, "b5", 5 * H)
         gh_in = torch.empty(N, H, **f32)
         ws = sc.ws(max(need_p, need_f))
         _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
-        _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
-              _ptr(sc.partials), _ptr(ws), need_p, st)
+        if side is not None and i > 0:
+            pending = (gP, s.h_in, g["W5"], g["b5"])
+        else:
+            _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
+                  _ptr(sc.partials), _ptr(ws), need_p, st)
         del gP
         gh = gh_in
         g["W3"], g["b3"] = tgt(i, "W3", H, H), tgt(i, "b3", H)
@@ -544,6 +573,8 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need_f, st)
             saved[0] = None
+            if side is not None:
+                main.wait_stream(side)
             break
         j = i - 1
         prm_j, s_j = ensure(j)
