@@ -530,9 +530,11 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
           _ptr(sc.partials), C.byref(nblk), st)
     if ACTIVATIONS == "lean":
         s.P = None              # as below: only the by-destination pass reads the rebuilt P
-    side = _side_stream(dev) if (TN_SIDE and _prof is None) else None
+    # not in the lean mode: the deferred kernel keeps its gP (one [E,H]-sized tensor) alive one layer longer
+    side = _side_stream(dev) if (TN_SIDE and _prof is None and ACTIVATIONS != "lean") else None
     main = torch.cuda.current_stream()
     pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
+    held: List[torch.Tensor] = []   # what the side stream is reading; dropped only after the main stream has waited for it
     while True:
         prm, s = prms[i], saved[i]
         o = outs[i] or {}
@@ -542,14 +544,15 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             # the matrix-bound weight gradient of the layer above, one workgroup per CU on the side stream, beside this
             # layer's HBM-bound by-source pass (see TN_SIDE)
             pgP, ph, pW, pb = pending
-            side.wait_stream(main)
+            main.wait_stream(side)      # the previous deferred kernel ended a layer ago: free, and makes `held` safe to drop
+            held.clear()                # (no record_stream: blocks parked on a side-stream event made the allocator
+            side.wait_stream(main)      #  fall back to hipMalloc / hipFree in the lean mode: 3x the step time)
             sc3 = scratch(dev, "tn")
             ws3 = sc3.ws(need_p)
             lib.gnm_set_occupancy_cap(TN_SIDE_CAP)
             _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(pgP), _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials),
                                                 _ptr(ws3), need_p, C.c_void_p(side.cuda_stream)), "gnm_node_proj_bwd_tn")
-            pgP.record_stream(side)
-            ph.record_stream(side)
+            held.extend((pgP, ph))
             pending = None
             lib.gnm_set_occupancy_cap(SRC_SIDE_CAP)
         _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
@@ -575,6 +578,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             saved[0] = None
             if side is not None:
                 main.wait_stream(side)
+                held.clear()
             break
         j = i - 1
         prm_j, s_j = ensure(j)
