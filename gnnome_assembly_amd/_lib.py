@@ -24,6 +24,8 @@ SIGNATURES = {
     "gnm_num_cus": (_i32, []),
     "gnm_max_partial_blocks": (_i32, []),
     "gnm_graph_build_index": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_graph_edge_locality": (_i32, [_p, _p, _i64, _i64, _i64, C.POINTER(C.c_double)]),
+    "gnm_graph_locality_order": (_i32, [_p, _p, _i64, _i64, _p, _p, C.POINTER(C.c_double)]),
     "gnm_gemm_f32_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64]),
     "gnm_gemm_f32": (_i32, [_i32, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
     "gnm_gemm_tn_colsum_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -98,7 +98,14 @@ def induced_subgraph(graph: AssemblyGraph, node_mask: torch.Tensor) -> AssemblyG
     eid = torch.nonzero(keep, as_tuple=False).squeeze(1)
     s_sub = new_id[src[eid].long()]
     d_sub = new_id[dst[eid].long()]
-    sub = AssemblyGraph.from_tensors(s_sub, d_sub, int(nid.numel()))        # edges and index stay on the device
+    # the parent's internal node order (graph.py "Node numbering"), restricted to the sub-graph: ranks of the kept nodes
+    # compressed to 0 .. n_sub-1 -- so a mini-batch of a graph with scattered node ids is as local as the parent
+    nrank = None
+    pr = graph.index(dev).get("nrank")      # (builds the parent's index once; cached on the graph)
+    if pr is not None:
+        nrank = torch.empty(nid.numel(), dtype=torch.int64, device=dev)
+        nrank[torch.argsort(pr[nid].long())] = torch.arange(nid.numel(), device=dev)
+    sub = AssemblyGraph.from_tensors(s_sub, d_sub, int(nid.numel()), nrank)  # edges and index stay on the device
     sub.ndata = {k: v[nid] for k, v in graph.ndata.items()}
     sub.edata = {k: v[eid] for k, v in graph.edata.items()}
     sub.ndata[NID] = nid

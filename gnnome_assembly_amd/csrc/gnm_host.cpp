@@ -94,6 +94,120 @@ extern "C" int gnm_graph_build_index(const int32_t* src, const int32_t* dst, int
 }
 
 // ------------------------------------------------------------------------------------------
+// Locality order of the nodes.  The gather kernels live on the 4 MB per-XCD L2 holding the node rows of the edges
+// in flight, i.e. on node ids that follow the genome: the reference never gives that (pipeline.py:46-61,160-169
+// keep the simulator's read order, graph_parser.py:297-304 numbers nodes by read id), so the engine renumbers the
+// nodes internally, once per graph, and nothing node-shaped leaves it in that numbering.
+//
+// Order = breadth-first (Cuthill-McKee without the degree sort) over the symmetrised graph, every component
+// started from a pseudo-peripheral node (the last node of a first sweep).  True overlaps are transitive -- reads
+// that overlap share neighbours -- while repeat-induced edges join reads with disjoint neighbourhoods and act as
+// shortcuts that fold a breadth-first order (every shortcut seeds a new front: the levels become unions of
+// thousands of short runs).  So the sweep runs on the triangle-supported edges only, as long as those are at least
+// half of the edges; the rest still count as edges of the graph, just not of the ordering.
+// ------------------------------------------------------------------------------------------
+extern "C" int gnm_graph_edge_locality(const int32_t* src, const int32_t* dst, int64_t N, int64_t E, int64_t window,
+                                       double* frac_out) {
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && window >= 0 && (E == 0 || (src && dst)) && frac_out,
+                "graph_edge_locality: bad argument");
+  int64_t local = 0;
+  for (int64_t k = 0; k < E; ++k) {
+    const int64_t d = (int64_t)src[k] - (int64_t)dst[k];
+    local += (d < 0 ? -d : d) <= window;
+  }
+  *frac_out = E ? (double)local / (double)E : 1.0;
+  return 0;
+}
+
+extern "C" int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, int64_t N, int64_t E,
+                                        int32_t* order, int32_t* rank, double* core_frac_out) {
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && N < INT32_MAX && 2 * E < INT32_MAX, "graph_locality_order: N/E out of int32 range");
+  GNM_CHECK_ARG((E == 0 || (src && dst)) && (N == 0 || (order && rank)), "graph_locality_order: null argument");
+  for (int64_t k = 0; k < E; ++k)
+    if (src[k] < 0 || src[k] >= N || dst[k] < 0 || dst[k] >= N) {
+      gnm::set_error("graph_locality_order: edge %lld = (%d -> %d) outside [0, %lld)", (long long)k, src[k], dst[k],
+                     (long long)N);
+      return -2;
+    }
+  // symmetrised adjacency without self loops, every list sorted by neighbour id (duplicates stay: harmless)
+  std::vector<int32_t> ptr((size_t)N + 1, 0);
+  for (int64_t k = 0; k < E; ++k)
+    if (src[k] != dst[k]) { ++ptr[(size_t)src[k] + 1]; ++ptr[(size_t)dst[k] + 1]; }
+  for (int64_t v = 0; v < N; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
+  std::vector<int32_t> adj((size_t)ptr[(size_t)N]);
+  {
+    std::vector<int32_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t k = 0; k < E; ++k)
+      if (src[k] != dst[k]) {
+        adj[(size_t)cur[(size_t)src[k]]++] = dst[k];
+        adj[(size_t)cur[(size_t)dst[k]]++] = src[k];
+      }
+  }
+  for (int64_t v = 0; v < N; ++v) {           // short lists: insertion sort
+    int32_t* a = adj.data() + ptr[(size_t)v];
+    const int32_t n = ptr[(size_t)v + 1] - ptr[(size_t)v];
+    for (int32_t i = 1; i < n; ++i) {
+      const int32_t x = a[i];
+      int32_t j = i;
+      for (; j > 0 && a[j - 1] > x; --j) a[j] = a[j - 1];
+      a[j] = x;
+    }
+  }
+  // core[p] = the edge (v, adj[p]) closes a triangle: v and adj[p] have a common neighbour
+  std::vector<uint8_t> core(adj.size(), 0);
+  int64_t ncore = 0;
+  for (int64_t v = 0; v < N; ++v)
+    for (int32_t p = ptr[(size_t)v]; p < ptr[(size_t)v + 1]; ++p) {
+      const int32_t u = adj[(size_t)p];
+      if (u < v) continue;                    // decided from the smaller end, mirrored below
+      int32_t i = ptr[(size_t)v], ie = ptr[(size_t)v + 1], j = ptr[(size_t)u], je = ptr[(size_t)u + 1];
+      bool tri = false;
+      while (i < ie && j < je) {
+        const int32_t x = adj[(size_t)i], y = adj[(size_t)j];
+        if (x == y) { if (x != u && x != v) { tri = true; break; } ++i; ++j; }
+        else if (x < y) ++i;
+        else ++j;
+      }
+      if (tri) { core[(size_t)p] = 1; ++ncore; }
+    }
+  for (int64_t v = 0; v < N; ++v)             // mirror onto the larger end's entries (binary search in the sorted list)
+    for (int32_t p = ptr[(size_t)v]; p < ptr[(size_t)v + 1]; ++p) {
+      const int32_t u = adj[(size_t)p];
+      if (u >= v) continue;
+      int32_t lo = ptr[(size_t)u], hi = ptr[(size_t)u + 1];
+      while (lo < hi) { const int32_t m = (lo + hi) >> 1; if (adj[(size_t)m] < (int32_t)v) lo = m + 1; else hi = m; }
+      core[(size_t)p] = core[(size_t)lo];     // the first copy of (u, v): duplicates share the flag
+    }
+  const int64_t nund = (int64_t)adj.size() / 2;
+  const bool use_core = nund > 0 && 2 * ncore >= nund;
+  if (core_frac_out) *core_frac_out = nund ? (double)ncore / (double)nund : 0.0;
+  auto sweep = [&](int32_t start, std::vector<uint8_t>& mark, std::vector<int32_t>& q) {
+    q.clear();
+    q.push_back(start);
+    mark[(size_t)start] = 1;
+    for (size_t h = 0; h < q.size(); ++h) {
+      const int32_t v = q[h];
+      for (int32_t p = ptr[(size_t)v]; p < ptr[(size_t)v + 1]; ++p) {
+        if (use_core && !core[(size_t)p]) continue;
+        const int32_t u = adj[(size_t)p];
+        if (!mark[(size_t)u]) { mark[(size_t)u] = 1; q.push_back(u); }
+      }
+    }
+  };
+  std::vector<uint8_t> seen1((size_t)N, 0), seen2((size_t)N, 0);
+  std::vector<int32_t> q1, q2;
+  int64_t pos = 0;
+  for (int64_t s = 0; s < N; ++s) {
+    if (seen1[(size_t)s]) continue;
+    sweep((int32_t)s, seen1, q1);             // first sweep: its last node is (pseudo-)peripheral
+    sweep(q1.back(), seen2, q2);              // second sweep from there = the order of this component
+    for (int32_t v : q2) order[pos++] = v;
+  }
+  for (int64_t i = 0; i < N; ++i) rank[(size_t)order[i]] = (int32_t)i;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Greedy decode on the host (inference.py:31-77,182-253): sequential walks over an adjacency in
 // edge-id order.  The reference keeps dict-of-list successors / predecessors and a
 // (src, dst) -> edge id dict (graph_parser.py:13-73); here both directions are CSR arrays whose

@@ -248,6 +248,27 @@ def bn_bwd_finalize(partials, nblk, count, H, device, gg=None, gb=None):
     return bstat, gg, gb
 
 
+def node_rows_in(idx, x: torch.Tensor) -> torch.Tensor:
+    """[N,W] rows in the caller's node numbering -> the graph's internal numbering (a gather through idx['nperm'];
+    the tensor itself when the index keeps the caller's numbering)."""
+    nperm = idx.get("nperm")
+    if nperm is None:
+        return x
+    out = torch.empty_like(x)
+    _call("gnm_gather_rows_f32", x.shape[0], x.shape[1], _ptr(x), _ptr(nperm), _ptr(out), _stream())
+    return out
+
+
+def node_rows_out(idx, x: torch.Tensor) -> torch.Tensor:
+    """The inverse of node_rows_in: internal numbering -> the caller's."""
+    nrank = idx.get("nrank")
+    if nrank is None:
+        return x
+    out = torch.empty_like(x)
+    _call("gnm_gather_rows_f32", x.shape[0], x.shape[1], _ptr(x), _ptr(nrank), _ptr(out), _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------
 # one GatedGCN layer
 # ---------------------------------------------------------------------------------------
@@ -756,7 +777,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     N, E = graph.num_nodes(), graph.num_edges()
     H = P["linear_pe.weight"].shape[0]
     f32 = dict(dtype=torch.float32, device=dev)
-    pe = _f32c(pe)
+    pe = node_rows_in(idx, _f32c(pe))         # caller's node numbering -> internal (graph.py "Node numbering")
     e_raw = _f32c(e_raw)
     # encoders                                                            (full_graph.py:23-26)
     h = torch.empty(N, H, **f32)

@@ -27,7 +27,8 @@ def positional_encoding(graph, pe_dim: int = 16, alpha: float = 0.95) -> torch.T
     ws = scratch(dev).ws(need)
     _call("gnm_pagerank_pe", N, E, _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]), pe_dim,
           C.c_double(alpha), _ptr(pe), _ptr(ws), need, _stream())
-    return pe
+    from .engine import node_rows_out
+    return node_rows_out(idx, pe)      # the index may use an internal node numbering (graph.py); features leave in the caller's
 
 
 @on_device_of(lambda overlap_length, overlap_similarity: overlap_similarity)

@@ -7,11 +7,22 @@ caller's edge-id order (graph_parser.py:297 fixes it; inference.py:46-49,454 rel
 Internally the engine keeps all [E,H] tensors sorted by destination; the index
 (gnm_graph_build_index, replaces DGL's lazy CSR/CSC build and dgl.reverse,
 gated_gcn_full.py:115) is built once per graph on the host and cached on the device.
+
+Node numbering.  The gather kernels are fast when node ids follow the genome (the node rows of the edges
+in flight then sit in the 4 MB per-XCD L2).  The reference's graphs do NOT come that way: reads keep the
+simulator's / sequencer's order (pipeline.py:46-61,160-169) and graph_parser.py:297-304 numbers nodes by read
+id.  So the index is built over an INTERNAL node numbering (gnm_graph_locality_order: breadth-first over the
+triangle-supported overlaps) whenever the caller's numbering is not already local; index()['nperm'] (internal
+-> caller id) / ['nrank'] (caller -> internal) exist exactly then.  Nothing node-shaped leaves the engine in
+the internal numbering: the model gathers `pe` rows in, the stand-alone layers permute h in and out.
+`node_order`: 'auto' (default; GNM_NODE_ORDER overrides), 'keep' (trust the caller), 'bfs' (always renumber).
 """
 from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
+import time
 
 import numpy as np
 import torch
@@ -22,13 +33,31 @@ __all__ = ["AssemblyGraph", "from_dgl"]
 
 _INDEX_KEYS = ("perm", "isrc", "idst", "in_ptr", "out_ptr", "out_pos", "out_dst")
 
+NODE_ORDER = os.environ.get("GNM_NODE_ORDER", "auto").strip().lower()
+# 'auto' keeps the caller's numbering when at least LOCAL_FRAC of the edges join nodes whose ids differ by at most
+# LOCAL_WINDOW (2048 rows x 512 B = 1 MB of every gathered [N,128] tensor: inside one XCD's L2 with room to spare)
+LOCAL_WINDOW = 2048
+LOCAL_FRAC = 0.9
 
-def tensor_index(src: torch.Tensor, dst: torch.Tensor, n: int):
+
+def set_node_order(mode: str) -> None:
+    """Default node-order policy of graphs built from now on: 'auto' | 'keep' | 'bfs'."""
+    global NODE_ORDER
+    if mode not in ("auto", "keep", "bfs"):
+        raise ValueError(f"node order {mode!r}: expected 'auto', 'keep' or 'bfs'")
+    NODE_ORDER = mode
+
+
+def tensor_index(src: torch.Tensor, dst: torch.Tensor, n: int, nrank: torch.Tensor = None):
     """The same seven index arrays as gnm_graph_build_index, built with tensor ops on the device the edge
     list lives on (two stable sorts, two bincounts): for graphs that are born on the GPU, e.g. the induced
     sub-graphs of the mini-batch mode, so that no edge list crosses PCIe.  Bit-identical to the host
-    builder (tests/test_host_cpu.py::test_tensor_index_equals_host_index)."""
+    builder (tests/test_host_cpu.py::test_tensor_index_equals_host_index).  With `nrank` (caller node id ->
+    internal node id) the index is built over the internal numbering and carries nperm / nrank."""
     s64, d64 = src.long(), dst.long()
+    if nrank is not None:
+        r64 = nrank.long()
+        s64, d64 = r64[s64], r64[d64]
     perm = torch.sort(d64, stable=True).indices                       # stable by destination
     isrc, idst = s64[perm], d64[perm]
     zero = torch.zeros(1, dtype=torch.int64, device=src.device)
@@ -36,15 +65,21 @@ def tensor_index(src: torch.Tensor, dst: torch.Tensor, n: int):
     out_pos = torch.sort(isrc, stable=True).indices                   # by source, ascending internal position
     out_ptr = torch.cat((zero, torch.cumsum(torch.bincount(s64, minlength=n), 0)))
     i32 = lambda t: t.to(torch.int32).contiguous()  # noqa: E731
-    return {"perm": i32(perm), "isrc": i32(isrc), "idst": i32(idst), "in_ptr": i32(in_ptr), "out_ptr": i32(out_ptr),
-            "out_pos": i32(out_pos), "out_dst": i32(idst[out_pos])}
+    idx = {"perm": i32(perm), "isrc": i32(isrc), "idst": i32(idst), "in_ptr": i32(in_ptr), "out_ptr": i32(out_ptr),
+           "out_pos": i32(out_pos), "out_dst": i32(idst[out_pos])}
+    if nrank is not None:
+        idx["nrank"] = i32(nrank)
+        idx["nperm"] = i32(torch.argsort(nrank.long()))
+    return idx
 
 
 class AssemblyGraph:
     @classmethod
-    def from_tensors(cls, src: torch.Tensor, dst: torch.Tensor, num_nodes: int) -> "AssemblyGraph":
+    def from_tensors(cls, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, nrank: torch.Tensor = None) -> "AssemblyGraph":
         """A graph whose edge list already lives on a device: edges and index stay there (tensor_index);
-        the host copy is only made if something asks for it."""
+        the host copy is only made if something asks for it.  `nrank` (optional, [num_nodes] on the same device):
+        the internal node numbering to use (caller id -> internal id), e.g. the parent graph's order restricted
+        to a sub-graph; without it the caller's numbering is kept (no host round trip for a breadth-first sweep)."""
         if src.shape != dst.shape or src.dim() != 1:
             raise ValueError("src and dst must be 1-D tensors of equal length")
         g = cls.__new__(cls)
@@ -57,6 +92,9 @@ class AssemblyGraph:
         g.device = src.device
         g.ndata = {}
         g.edata = {}
+        g._node_order = "keep"
+        g._nrank_t = nrank
+        g.relabel_info = {"mode": "given" if nrank is not None else "keep", "relabelled": nrank is not None}
         return g
 
     @property
@@ -71,7 +109,9 @@ class AssemblyGraph:
             self._dst_np = np.ascontiguousarray(self._dst_t.cpu().numpy(), dtype=np.int32)
         return self._dst_np
 
-    def __init__(self, src, dst, num_nodes=None):
+    def __init__(self, src, dst, num_nodes=None, node_order=None):
+        if node_order not in (None, "auto", "keep", "bfs"):
+            raise ValueError(f"node_order {node_order!r}: expected None, 'auto', 'keep' or 'bfs'")
         src = np.ascontiguousarray(_to_numpy(src), dtype=np.int32)
         dst = np.ascontiguousarray(_to_numpy(dst), dtype=np.int32)
         if src.shape != dst.shape or src.ndim != 1:
@@ -88,6 +128,9 @@ class AssemblyGraph:
         self.device = torch.device("cpu")
         self.ndata = {}
         self.edata = {}
+        self._node_order = node_order      # None: the module default at the time the index is built
+        self._nrank_t = None
+        self.relabel_info = {}             # filled by host_index(): what was decided, on what evidence, how long it took
 
     # ---- DGLGraph surface ------------------------------------------------------------
     def num_nodes(self):
@@ -140,15 +183,41 @@ class AssemblyGraph:
         if self._host_index is None:
             lib = _lib.load()
             n, e = self._n, self.num_edges()
+            ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            src, dst = self._src, self._dst
+            mode = self._node_order or NODE_ORDER
+            info = {"mode": mode, "relabelled": False}
+            order = rank = None
+            if mode == "auto":
+                frac = C.c_double(1.0)
+                _lib.check(lib.gnm_graph_edge_locality(ptr(src), ptr(dst), n, e, LOCAL_WINDOW, C.byref(frac)),
+                           "gnm_graph_edge_locality")
+                info["local_edge_fraction"] = frac.value
+                relabel = n > LOCAL_WINDOW and frac.value < LOCAL_FRAC
+            else:
+                relabel = mode == "bfs"
+            if relabel:
+                t0 = time.perf_counter()
+                order, rank = np.empty(n, np.int32), np.empty(n, np.int32)
+                core = C.c_double(0.0)
+                _lib.check(lib.gnm_graph_locality_order(ptr(src), ptr(dst), n, e, ptr(order), ptr(rank), C.byref(core)),
+                           "gnm_graph_locality_order")
+                src, dst = np.ascontiguousarray(rank[src]), np.ascontiguousarray(rank[dst])
+                frac = C.c_double(1.0)
+                lib.gnm_graph_edge_locality(ptr(src), ptr(dst), n, e, LOCAL_WINDOW, C.byref(frac))
+                info.update(relabelled=True, seconds=time.perf_counter() - t0, triangle_edge_fraction=core.value,
+                            local_edge_fraction_after=frac.value)
+            self.relabel_info.clear()          # in place: the .to(device) copies share this dict
+            self.relabel_info.update(info)
             idx = {
                 "perm": np.empty(e, np.int32), "isrc": np.empty(e, np.int32), "idst": np.empty(e, np.int32),
                 "in_ptr": np.empty(n + 1, np.int32), "out_ptr": np.empty(n + 1, np.int32),
                 "out_pos": np.empty(e, np.int32), "out_dst": np.empty(e, np.int32),
             }
-            ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-            _lib.check(lib.gnm_graph_build_index(ptr(self._src), ptr(self._dst), n, e,
-                                                 *[ptr(idx[k]) for k in _INDEX_KEYS]),
+            _lib.check(lib.gnm_graph_build_index(ptr(src), ptr(dst), n, e, *[ptr(idx[k]) for k in _INDEX_KEYS]),
                        "gnm_graph_build_index")
+            if order is not None:
+                idx["nperm"], idx["nrank"] = order, rank
             self._host_index = idx
         return self._host_index
 
@@ -157,7 +226,7 @@ class AssemblyGraph:
         device = torch.device(device) if device is not None else self.device
         if device not in self._dev_index:
             if self._src_t is not None and self._host_index is None:       # born on a device: build it there
-                idx = tensor_index(self._src_t, self._dst_t, self._n)
+                idx = tensor_index(self._src_t, self._dst_t, self._n, self._nrank_t)
                 self._dev_index[self._src_t.device] = idx
                 if device != self._src_t.device:
                     self._dev_index[device] = {k: v.to(device) for k, v in idx.items()}

@@ -28,11 +28,12 @@ class _LayerFn(torch.autograd.Function):
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
         prm = engine.layer_params(P, 0)
-        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h.detach().contiguous(), e_int, need, batch_norm)
+        h_int = engine.node_rows_in(idx, engine._f32c(h.detach()))       # caller's node numbering -> internal (graph.py)
+        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h_int, e_int, need, batch_norm)
         ctx.graph, ctx.saved, ctx.P, ctx.dims, ctx.bn = graph, saved, P, (N, E, H), batch_norm
         out_e = torch.empty_like(e_out)
         out_e.index_copy_(0, perm, e_out)
-        return h_out, out_e
+        return engine.node_rows_out(idx, h_out), out_e
 
     @staticmethod
     def backward(ctx, gh_out, ge_out):
@@ -43,7 +44,9 @@ class _LayerFn(torch.autograd.Function):
         perm = idx["perm"].long()
         prm = engine.layer_params(ctx.P, 0)
         ge = ge_out.index_select(0, perm).contiguous()        # fresh buffer, overwritten below
-        gh_in, ge_in, g = engine.layer_backward(idx, N, E, H, prm, ctx.saved, gh_out.contiguous(), ge, ctx.bn)
+        gh_in, ge_in, g = engine.layer_backward(idx, N, E, H, prm, ctx.saved,
+                                                engine.node_rows_in(idx, engine._f32c(gh_out)), ge, ctx.bn)
+        gh_in = engine.node_rows_out(idx, gh_in)
         ctx.saved = None
         ge_user = torch.empty_like(ge_in)
         ge_user.index_copy_(0, perm, ge_in)
@@ -128,7 +131,7 @@ class _PredFn(torch.autograd.Function):
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
         scores, saved = engine.predictor_forward(idx, N, E, H, W1.detach(), b1.detach(), W2.detach(), b2.detach(),
-                                                 x.detach().contiguous(), e_int, need)
+                                                 engine.node_rows_in(idx, engine._f32c(x.detach())), e_int, need)
         ctx.graph, ctx.saved, ctx.dims = graph, saved, (N, E, H)
         ctx.W1, ctx.W2 = W1.detach(), W2.detach()
         return scores
@@ -141,6 +144,7 @@ class _PredFn(torch.autograd.Function):
         idx = ctx.graph.index(gscores.device)
         perm = idx["perm"].long()
         gx, ge, g = engine.predictor_backward(idx, N, E, H, ctx.W1, ctx.W2, ctx.saved, gscores)
+        gx = engine.node_rows_out(idx, gx)
         ctx.saved = None
         ge_user = torch.empty_like(ge)
         ge_user.index_copy_(0, perm, ge)

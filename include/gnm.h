@@ -59,6 +59,21 @@ int gnm_graph_build_index(const int32_t* src, const int32_t* dst, int64_t N, int
                           int32_t* perm, int32_t* isrc, int32_t* idst, int32_t* in_ptr,
                           int32_t* out_ptr, int32_t* out_pos, int32_t* out_dst);
 
+/* ---- locality order of the nodes (HOST pointers).  The reference never sorts reads by position
+ *      (pipeline.py:46-61,160-169 keep the simulator's read order; graph_parser.py:297-304 numbers nodes by
+ *      read id), while the gather kernels rely on node ids that follow the genome (the node rows of the edges in
+ *      flight must fit the 4 MB per-XCD L2).  The host renumbers the nodes INTERNALLY, once per graph:
+ * edge_locality:  *frac_out = fraction of the edges with |src - dst| <= window in the caller's numbering
+ *                 (decides whether a renumbering is needed at all);
+ * locality_order: order[new] = old, rank[old] = new: breadth-first over the symmetrised graph restricted to the
+ *                 triangle-supported edges (true overlaps are transitive; repeat-induced shortcuts would fold
+ *                 the order) when those are at least half of the edges, every component started from a
+ *                 pseudo-peripheral node; *core_frac_out (optional) = fraction of triangle-supported edges.   */
+int gnm_graph_edge_locality(const int32_t* src, const int32_t* dst, int64_t N, int64_t E, int64_t window,
+                            double* frac_out);
+int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, int64_t N, int64_t E, int32_t* order,
+                             int32_t* rank, double* core_frac_out);
+
 /* ---- greedy decode (HOST pointers, sequential CPU work; inference.py:31-77,182-253) ----------
  * build_adjacency: successors / predecessors of every node in edge-id order, as the reference's
  *   succ / pred dicts (graph_parser.py:13-73); *_eid[p] = edges[(node, nbr)] of its edges dict, i.e. the
