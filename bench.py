@@ -60,6 +60,13 @@ def parse():
                     help="fused-kernel matmul mode (default: GNM_MATMUL or the library default bf16x3); see include/gnm.h")
     ap.add_argument("--no-alt-matmul", action="store_true", help="skip the extra measurement in the other matmul mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores)")
+    ap.add_argument("--shuffle-nodes", action="store_true",
+                    help="give the SAME graph randomly shuffled node ids (what the reference's pipeline produces: reads are "
+                         "never sorted by position) for the main measurement; edge ids as usual")
+    ap.add_argument("--node-order", default=None, choices=["auto", "keep", "bfs"],
+                    help="internal node numbering policy of the graph index (default: the package default, 'auto')")
+    ap.add_argument("--permute-edge-ids", action="store_true", help="seeded random edge-id permutation (SURVEY 8d second variant)")
+    ap.add_argument("--no-alt-orders", action="store_true", help="skip the alt_node_order / alt_edge_ids measurements")
     return ap.parse_args()
 
 
@@ -154,7 +161,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(reads, H, L, budget_s=25.0, threads=0, full_reads=750_000):
+def cpu_baseline(reads, H, L, budget_s=60.0, threads=0, full_reads=750_000):
     """fwd+bwd edges/s of the CPU oracle on this host (all cores torch gives us), on a bounded
     sample: the graph is shrunk until one step fits the time budget (edges/s is size-normalised)."""
     from gnnome_assembly_amd import synth
@@ -179,9 +186,11 @@ def cpu_baseline(reads, H, L, budget_s=25.0, threads=0, full_reads=750_000):
             return loss.item()
         return step, int(src.size), n
 
-    # grow the sample geometrically while a step stays cheap (host throughput is strongly
-    # size-dependent once the working set leaves the caches); keep the largest size measured
-    r = min(reads, 2000)
+    # the same graph, or a 1/10-size one (R = 75 k) when a step exceeds 60 s, 1 warm-up + 3 timed steps.
+    # The sample grows geometrically while warm-up + 3 timed steps still fit the budget (host throughput is strongly
+    # size-dependent once the working set leaves the caches, so the next size is priced by the last one measured); the
+    # largest size measured is kept, and the default bench run still ends within minutes.
+    r = min(reads, 4000)
     while True:
         step, E, n = make(r)
         step()                                   # warm-up at this size
@@ -197,14 +206,16 @@ def cpu_baseline(reads, H, L, budget_s=25.0, threads=0, full_reads=750_000):
         step()
         times.append(time.time() - t0)
     med = float(np.median(times))
+    tenth = full_reads // 10
+    note = (f"the 1/10-size sample of SURVEY 8(d) (R={tenth}) would take ~{med * tenth / r:.0f} s/step x 4 steps on this host: "
+            f"over the {budget_s:.0f} s CPU budget of the default run" if r < tenth else "the 1/10-size sample of SURVEY 8(d)")
     return {"value": E / med, "unit": "edges/s", "cores": threads, "kind": "port",
             "sample": f"R={r} (N={n}, E={E}) = 1/{full_reads / r:.0f} of the GPU workload's R={full_reads} (edges/s is "
-                      f"size-normalised; the small graph is cache-friendlier, which favours the CPU; SURVEY 8(d) asked "
-                      f"for 1/10 and 3 steps, the time budget of the default run allows this), H={H} L={L} fwd+bwd, "
-                      f"torch-CPU oracle fp32, median of {len(times)} steps after warm-up ({med:.2f} s/step)"}
+                      f"size-normalised; a smaller graph is cache-friendlier, which favours the CPU; {note}), H={H} L={L} "
+                      f"fwd+bwd, torch-CPU oracle fp32, median of {len(times)} steps after warm-up ({med:.2f} s/step)"}
 
 
-def cpu_baseline_subprocess(args, timeout_s=120):
+def cpu_baseline_subprocess(args, timeout_s=240):
     """Run the CPU leg in its own process with a hard wall-clock bound: the bench line must
     come out within minutes whatever the host does."""
     import subprocess
@@ -251,35 +262,59 @@ def main():
     from gnnome_assembly_amd import synth, engine, dp
     if args.matmul:
         G._lib.set_matmul_mode(args.matmul)
+    backend_name = None
     if world > 1:
         dp.init_process_group(os.environ.get("GNM_BENCH_BACKEND", "nccl"))
+        backend_name = {"nccl": "RCCL"}.get(dist.get_backend(), dist.get_backend())     # what actually carries the all-reduce
         dbg("process group up")
 
     H, L, R = args.hidden, args.layers, args.reads
-    src, dst, n = synth.make_graph(R, seed=rank)
-    inp = synth.make_inputs(src, dst, n, seed=rank)
-    E = int(src.size)
-    graph = G.AssemblyGraph(src, dst, n).to(dev)
-    graph.index()                                   # index resident in HBM before timing
+
+    def workload(shuffle_nodes, permute_edges, node_order):
+        """The rank's synthetic graph + inputs resident in HBM.  shuffle_nodes: the same graph under a seeded random
+        renumbering of its nodes (pe rows follow their nodes); permute_edges: a seeded random edge-id permutation."""
+        src, dst, n = synth.make_graph(R, seed=rank, permute_edge_ids=permute_edges)
+        inp = synth.make_inputs(src, dst, n, seed=rank)
+        pe_np = inp["pe"]
+        if shuffle_nodes:
+            p = np.random.default_rng(rank + 4242).permutation(n).astype(np.int32)
+            src, dst = p[src], p[dst]
+            pe_np = np.empty_like(inp["pe"])
+            pe_np[p] = inp["pe"]
+        t0 = time.perf_counter()
+        g = G.AssemblyGraph(src, dst, n, node_order=node_order).to(dev)
+        g.index()                                   # index resident in HBM before timing
+        t_index = time.perf_counter() - t0
+        return {"graph": g, "n": n, "E": int(src.size), "e": torch.from_numpy(inp["e"]).to(dev),
+                "pe": torch.from_numpy(pe_np).to(dev), "y": torch.from_numpy(inp["y"]).to(dev),
+                "crit": G.BCEWithLogitsLoss(float(inp["pos_weight"])), "index_seconds": t_index,
+                "relabel": dict(g.relabel_info)}
+
+    W = workload(args.shuffle_nodes, args.permute_edge_ids, args.node_order)
+    n, E = W["n"], W["E"]
     model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(H, L, 0, randomize_norm=False).items()})
     model.to(dev)
-    e = torch.from_numpy(inp["e"]).to(dev)
-    pe = torch.from_numpy(inp["pe"]).to(dev)
-    y = torch.from_numpy(inp["y"]).to(dev)
-    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
     model.flatten_parameters()                      # one parameter buffer in the engine's layout; the gradients follow it
-    flat = dp.FlatGradients(model.parameters())
+    flat = dp.FlatGradients(model.parameters(), direct_write=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    own = []        # world > 1: (event before the step, event before the gradient exchange) = this rank's OWN compute
 
     def step():
         if args.inference:
             with torch.no_grad():
-                return model(graph, None, e, pe)
+                return model(W["graph"], None, W["e"], W["pe"])
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         flat.zero_()
-        scores = model(graph, None, e, pe)
-        loss = crit(scores.squeeze(-1), y)
+        scores = model(W["graph"], None, W["e"], W["pe"])
+        loss = W["crit"](scores.squeeze(-1), W["y"])
         loss.backward()
+        if world > 1:
+            e1.record()
+            own.append((e0, e1))
         flat.all_reduce_mean()
         opt.step()
         return loss
@@ -289,11 +324,15 @@ def main():
         step()
     torch.cuda.synchronize()
     dbg("warmup done")
+    per_rank = None
+
     def timed_run(nsteps):
         """EXACTLY nsteps steps between barrier + synchronize on both sides; max over ranks."""
+        nonlocal per_rank
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        own.clear()
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step()
@@ -308,10 +347,20 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             esum = tt[1:2].clone()
             dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+            # per-rank edges, own compute time per step (HIP events: forward + backward up to the gradient
+            # exchange) and the fraction of the step the rank spends waiting for the slowest one / in the collective
+            mine = sum(a.elapsed_time(b) for a, b in own) / max(len(own), 1)
+            rows = torch.zeros(world, 3, dtype=torch.float64, device=dev)
+            rows[rank] = torch.tensor([float(E), mine, dt_ / nsteps * 1e3], dtype=torch.float64)
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+            step_ms = float(tmax.item()) / nsteps * 1e3
+            per_rank = [{"rank": r, "edges": int(rows[r, 0].item()), "own_compute_ms_per_step": round(rows[r, 1].item(), 3),
+                         "idle_fraction": round(max(0.0, 1.0 - rows[r, 1].item() / step_ms), 4)} for r in range(world)]
             return float(tmax.item()), float(esum.item())
         return dt_, float(E)
 
     dt, total_edges = timed_run(args.steps)
+    per_rank_main = per_rank
     dbg(f"timed region done {dt:.3f}s")
     ms = dt / args.steps * 1e3
     value = total_edges * args.steps / dt
@@ -353,6 +402,27 @@ def main():
                    "note": "P [N,5H] and t [E,H] are rebuilt in the backward by the kernels that made them instead of being "
                            "kept; bit-identical results (tests/test_gpu_parity.py::test_lean_activation_mode...)"}
         engine.set_activation_mode("saved")
+    # The same graph under other numberings (never `value`): SURVEY 8(d) asks for a seeded random edge-id permutation
+    # beside the src-major ids; VERDICT r2 for randomly shuffled NODE ids -- what the reference's pipeline produces (reads
+    # are never sorted by position: pipeline.py:46-61,160-169, graph_parser.py:297-304) -- with the index's internal
+    # renumbering ('auto') and without it ('keep' = what every gather kernel sees when node ids are taken as they come).
+    alt_orders = {}
+    if world == 1 and not args.inference and not args.no_alt_orders and not args.shuffle_nodes and args.matmul is None:
+        main_W = dict(W)
+        nalt = max(2, args.steps // 2)
+        for key, (shuf, perm_e, order) in {"shuffled_node_ids": (True, False, None),
+                                           "shuffled_node_ids_kept": (True, False, "keep"),
+                                           "alt_edge_ids": (False, True, None)}.items():
+            W.clear()
+            torch.cuda.empty_cache()
+            W.update(workload(shuf, perm_e, order))
+            step()
+            adt, aedges = timed_run(nalt)
+            alt_orders[key] = {"ms_per_step": adt / nalt * 1e3, "value": aedges * nalt / adt, "unit": "edges/s",
+                               "steps": nalt, "index_seconds": round(W["index_seconds"], 3), "node_order": W["relabel"]}
+        W.clear()
+        W.update(main_W)
+        dbg("alt order runs done")
     res = None
     if rank == 0:
         tot = sum(t for _, t in ops.values())
@@ -395,10 +465,13 @@ def main():
             "dtype": "f32 (bf16x3 split products, f32 accumulate)" if mode == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"synthetic chr19-scale assembly graph per GPU: R={R} reads, N={n} nodes, "
                                    f"E={E} edges, hidden={H}, layers={L}, BCE fwd+bwd + Adam"
-                                   + (", RCCL grad all-reduce" if world > 1 else ""),
+                                   + (f", {backend_name} grad all-reduce" if world > 1 else ""),
                        "reads": R, "nodes": n, "edges": E, "edges_total": int(total_edges), "hidden": H, "layers": L,
                        "parallelism": f"dp{world}", "edge_layers_per_s": value * L, "matmul": mode,
-                       "activations": engine.ACTIVATIONS},
+                       "activations": engine.ACTIVATIONS,
+                       "node_ids": "randomly shuffled" if args.shuffle_nodes else "position-sorted (SURVEY 8d generator)",
+                       "edge_ids": "seeded random permutation" if args.permute_edge_ids else "src-major",
+                       "node_order": W["relabel"], "index_seconds": round(W["index_seconds"], 3)},
             "roofline": roof,
             "op_ms": {k: round(v[1], 3) for k, v in ranked},
             "op_total_ms": round(tot, 3),
@@ -408,6 +481,11 @@ def main():
             res["alt_matmul"] = alt
         if alt_act:
             res["alt_activations"] = alt_act
+        if alt_orders:
+            res["alt_node_order"] = {k: v for k, v in alt_orders.items() if k != "alt_edge_ids"}
+            res["alt_edge_ids"] = alt_orders.get("alt_edge_ids")
+        if per_rank_main:
+            res["per_rank"] = per_rank_main
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(res), flush=True)

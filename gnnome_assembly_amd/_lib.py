@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNM_LIBRARY") or os.path.join(_HERE, "libgnm.so")   # GNM_LIBRARY: A/B against another build (tools)
 
 _lib = None
+ABI_VERSION = 2     # GNM_ABI_VERSION of include/gnm.h
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -43,7 +44,7 @@ SIGNATURES = {
     "gnm_node_bwd_stats": (_i32, [_i64, _i32, _p, _p, _p, _p, _pi, _p]),
     "gnm_node_bwd_apply": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
-    "gnm_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gnm_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "gnm_edge_bwd_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_ln_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_ln_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
@@ -60,7 +61,7 @@ SIGNATURES = {
     "gnm_node_proj_bwd_workspace_bytes": (_sz, [_i32]),
     "gnm_node_proj_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_nn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
-    "gnm_node_proj_bwd_tn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_node_proj_bwd_tn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _i32, _p]),
     "gnm_edge_bwd_chain": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_pi, _p, _sz, _p]),
     "gnm_edge_bwd_fused_workspace_bytes": (_sz, []),
     "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -107,8 +108,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     v = lib.gnm_abi_version()
-    if v != 1:
-        raise GnmError(f"libgnm.so ABI version {v}, expected 1")
+    if v != ABI_VERSION:
+        raise GnmError(f"libgnm.so ABI version {v}, expected {ABI_VERSION} (rebuild: python __graft_entry__.py)")
     _lib = lib
     mode = os.environ.get("GNM_MATMUL", "").strip().lower()
     if mode:                                     # matmul mode of the fused kernels (gnm.h); library default: bf16x3

@@ -39,9 +39,11 @@ int reduce_partials_batched(const double* partials, int batch, int nblk, int W, 
 
 // Grid for the persistent row/segment kernels: a multiple of 8 (one slice per XCD),
 // at most kMaxPartialBlocks, at least enough to give every block `min_items` items.
-int occupancy_cap();   // 0 = none; see gnm_set_occupancy_cap
-inline int persistent_grid(int64_t items, int64_t min_items_per_block, int blocks_per_cu) {
-  const int cap_ = occupancy_cap();
+// `call_cap` > 0: the caller's per-call cap on workgroups per CU (entry points that take max_blocks_per_cu);
+// otherwise the process-wide knob of gnm_set_occupancy_cap (tools only; 0 = none).
+int occupancy_cap();
+inline int persistent_grid(int64_t items, int64_t min_items_per_block, int blocks_per_cu, int call_cap = 0) {
+  const int cap_ = call_cap > 0 ? call_cap : occupancy_cap();
   if (cap_ > 0 && blocks_per_cu > cap_) blocks_per_cu = cap_;
   int64_t want = (items + min_items_per_block - 1) / min_items_per_block;
   int64_t cap = (int64_t)num_cus() * blocks_per_cu;

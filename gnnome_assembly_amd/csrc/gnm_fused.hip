@@ -1708,11 +1708,12 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
 }
 
 static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,
-                        double* partials, float* slab, void* stream) {
+                        double* partials, float* slab, void* stream, int max_blocks_per_cu = 0) {
   hipStream_t st = (hipStream_t)stream;
   const bool tr = g_matmul_mode && g_tn_variant == 1;
   const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : g_matmul_mode ? TR3 : FTR);
-  const int occ = tr ? tn_tr_occupancy() : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  int occ = tr ? tn_tr_occupancy() : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  if (max_blocks_per_cu > 0 && occ > max_blocks_per_cu) occ = max_blocks_per_cu;    // the caller shares the CUs with another stream
   int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
@@ -1858,12 +1859,13 @@ extern "C" int gnm_node_proj_bwd_nn(int64_t N, int H, int ncols, const float* gP
 }
 
 extern "C" int gnm_node_proj_bwd_tn(int64_t N, int H, int ncols, const float* gP, const float* h_in, float* gW, float* gb,
-                                    double* partials, void* ws, size_t ws_bytes, void* stream) {
+                                    double* partials, void* ws, size_t ws_bytes, int max_blocks_per_cu, void* stream) {
   GNM_CHECK_ARG(H == FH, "node_proj_bwd_tn: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && h_in && gW && gb && partials, "node_proj_bwd_tn: bad argument");
+  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && h_in && gW && gb && partials && max_blocks_per_cu >= 0,
+                "node_proj_bwd_tn: bad argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_node_proj_bwd_workspace_bytes(ncols), "node_proj_bwd_tn: workspace too small");
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(ncols));
-  return tn_colgroups(N, gP, ncols, ncols / FH, h_in, gW, gb, partials, slab, stream);
+  return tn_colgroups(N, gP, ncols, ncols / FH, h_in, gW, gb, partials, slab, stream, max_blocks_per_cu);
 }
 
 extern "C" int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
@@ -1871,7 +1873,7 @@ extern "C" int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, c
                                  void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_node_proj_bwd_workspace_bytes(ncols), "node_proj_bwd: workspace too small");
   const int rc = gnm_node_proj_bwd_nn(N, H, ncols, gP, W, gh_out, gh_in, ws, ws_bytes, stream);
-  return rc ? rc : gnm_node_proj_bwd_tn(N, H, ncols, gP, h_in, gW, gb, partials, ws, ws_bytes, stream);
+  return rc ? rc : gnm_node_proj_bwd_tn(N, H, ncols, gP, h_in, gW, gb, partials, ws, ws_bytes, 0, stream);
 }
 
 // out[cg*128 + n][c] = sum_rows A[row][cg*128 + n] * B[row][c];  colsum[cg*128 + n] = sum_rows A[row][cg*128 + n]

@@ -552,11 +552,11 @@ extern "C" int gnm_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out,
                                 const float* stat_e, const float* bstat_e, const float* gamma_e,
                                 const float* ge, const float* Q, const int32_t* in_ptr,
                                 const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
-                                const float* Ud, const float* Td, float* gP, void* stream) {
+                                const float* Ud, const float* Td, float* gP, int max_blocks_per_cu, void* stream) {
   GNM_CHECK_ARG(N >= 0 && E >= 0 && e_out && t && stat_e && bstat_e && gamma_e && ge && Q && in_ptr && out_ptr &&
-                    out_pos && out_dst && Ud && Td && gP, "edge_bwd_src: null/neg argument");
+                    out_pos && out_dst && Ud && Td && gP && max_blocks_per_cu >= 0, "edge_bwd_src: null/neg argument");
   GNM_DISPATCH_H(H, {
-    const int grid = persistent_grid(N, 64, occ_blocks<edge_bwd_src_k<HH>>());
+    const int grid = persistent_grid(N, 64, occ_blocks<edge_bwd_src_k<HH>>(), max_blocks_per_cu);
     const int64_t npb = ceil_div64(N, grid);
     hipLaunchKernelGGL(edge_bwd_src_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, e_out, t, stat_e, bstat_e, gamma_e, ge, Q, in_ptr, out_ptr, out_pos, out_dst, Ud, Td, gP, npb);
   });

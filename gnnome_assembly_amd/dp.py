@@ -21,12 +21,16 @@ _live = weakref.WeakSet()      # the FlatGradients objects alive in this process
 
 
 def fresh_flat_gradients(params) -> "Optional[FlatGradients]":
-    """The FlatGradients whose buffer holds the .grad of EVERY tensor in `params`, if it has been zeroed since its
-    last use (so that writing a gradient into it equals accumulating it); None otherwise."""
+    """The FlatGradients(direct_write=True) whose buffer holds the .grad of EVERY tensor in `params`, if it has been
+    zeroed since its last use (so that writing a gradient into it equals accumulating it) and no parameter carries
+    a gradient hook (hooks only see gradients that travel through autograd); None otherwise."""
     if not params:
         return None
     for fg in _live:
-        if fg.fresh and fg.owns(params):
+        if fg.direct_write and fg.fresh and fg.owns(params):
+            if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in params):
+                fg.fresh = False        # autograd is about to accumulate into the buffer
+                return None
             return fg
     return None
 
@@ -55,9 +59,18 @@ class FlatGradients:
 
     `flat` carries one extra trailing element: the number of graphs this rank contributed to the step
     (1, or 0 for a padding step of a rank whose shard is shorter).  It rides in the same collective, and the
-    summed gradient is divided by the summed count -- the mean over the graphs that actually took part."""
+    summed gradient is divided by the summed count -- the mean over the graphs that actually took part.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    `direct_write=True` (what train.train and bench.py pass) is an OPT-IN to the engine's fast path: after zero_(), the
+    whole-model backward writes every gradient straight into these views and tells autograd "no gradient" (writing
+    into zeros == accumulating; ~140 accumulation kernels per step disappear).  The price, hence opt-in: while the
+    buffer is fresh, torch.autograd.grad(loss, params) returns None for the parameters (and still fills .grad), and
+    parameter hooks would not fire (the fast path stands down when a parameter has hooks).  Anything that writes a
+    gradient other than the model's backward -- all_reduce_mean, a manual p.grad.add_ -- must leave `fresh` False;
+    all_reduce_mean does.  With the default direct_write=False every gradient takes the ordinary autograd route."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], direct_write: bool = False):
+        self.direct_write = bool(direct_write)
         self.params = [p for p in params if p.requires_grad]
         if all(hasattr(p, "_gnm_slot") for p in self.params):
             # a model flattened by models.flatten_parameters: follow its layout, so that the five stacked projection
@@ -88,16 +101,18 @@ class FlatGradients:
                 raise RuntimeError("FlatGradients: a parameter's .grad was re-allocated; use "
                                    "optimizer.zero_grad(set_to_none=False) or FlatGradients.zero_()")
 
-    def all_reduce_mean(self, contributed: bool = True):
+    def all_reduce_mean(self, contributed: bool = True, async_op: bool = False):
         """Average the gradient over the ranks that contributed a graph to this step: ONE all-reduce (sum) of
         the flat buffer on the current stream, then a device-side division by the summed count (no host
         sync).  Every rank must call it the same number of times; a rank without a graph for this step
-        calls zero_() and all_reduce_mean(contributed=False)."""
+        calls zero_() and all_reduce_mean(contributed=False).  `async_op` is accepted for callers of the round-1
+        signature and ignored: the collective is stream-ordered, there is nothing to wait for on the host."""
+        self.fresh = False          # the buffer now holds a gradient: the next backward must accumulate, not overwrite
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return None
         self.flat[-1] = 1.0 if contributed else 0.0
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.grads.div_(self.flat[-1])
+        self.grads.div_(self.flat[-1].clamp(min=1.0))    # a step no rank contributed to leaves a zero gradient, not 0/0
         return None
 
 

@@ -145,12 +145,6 @@ def scratch(device, key: str = "main") -> _Scratch:
     return _scratch[(device, key)]
 
 
-# Two-stream backward (CORUN, opt-in: GNM_CORUN=1): the MFMA-bound fused edge backward runs on a side
-# stream, capped at one workgroup per CU, while the HBM-bound by-source pass runs beside it on the main
-# stream.  Measured: the pair takes 7.3 ms together instead of 4.9 + 3.2 ms (both slow down: the
-# by-source kernel is latency-bound at the 2 workgroups per CU that still fit), i.e. -0.6 ms per layer
-# (2 %) for one more [E,H] buffer -- inside the box-to-box spread, so it is not the default.
-CORUN = os.environ.get("GNM_CORUN", "0") == "1"
 _side_streams: Dict[torch.device, "torch.cuda.Stream"] = {}
 
 
@@ -424,33 +418,13 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
               _ptr(sc.partials), C.byref(nblk), st)
         bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
-        corun = CORUN and H == 128 and FUSED and _prof is None
-        if corun:
-            # fused edge backward (MFMA-bound) on the side stream, one workgroup per CU, writing a fresh ge ...
-            main, side = torch.cuda.current_stream(), _side_stream(dev)
-            sc2 = scratch(dev, "side")
-            g["b3"] = new("b3", H)
-            ge_new = torch.empty_like(ge)
-            need = lib.gnm_edge_bwd_fused_workspace_bytes()
-            ws2 = sc2.ws(need)
-            side.wait_stream(main)
-            lib.gnm_set_occupancy_cap(1)
-            _lib.check(lib.gnm_edge_bwd_fused(E, H, _ptr(ge), _ptr(ge_new), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e),
-                                              _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]),
-                                              _ptr(sc2.partials), _ptr(ws2), need, C.c_void_p(side.cuda_stream)),
-                       "gnm_edge_bwd_fused")
-            lib.gnm_set_occupancy_cap(2)       # ... while the by-source pass (HBM-bound) shares the CUs
         # by-source pass: gA2h, gB1h, gB2h
         _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
               _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
-              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), st)
+              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), 0, st)
         del Ud, Td, Q
-        if corun:
-            lib.gnm_set_occupancy_cap(0)
-            main.wait_stream(side)
-            ge = ge_new
         # gt, B_3 gradients, ge_in = ge_tot + gt W3
-        elif H == 128 and FUSED:
+        if H == 128 and FUSED:
             g["b3"] = new("b3", H)
             need = lib.gnm_edge_bwd_fused_workspace_bytes()
             ws = sc.ws(need)
@@ -472,7 +446,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         ws = sc.ws(need)
         _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh_out), _ptr(gh_in), _ptr(ws), need, st)
         _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
-              _ptr(sc.partials), _ptr(ws), need, st)
+              _ptr(sc.partials), _ptr(ws), need, 0, st)
     else:
         g["b5"] = gemm_tn_colsum(gP, s.h_in, g["W5"], out.get("b5"))
         gemm(NN, gP, prm.W5, gh_in, resid=gh_out)
@@ -484,17 +458,20 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
 # matrix-core work under the gather arithmetic).  GNM_CHAIN=0 / engine.CHAIN = False goes back to layer_backward.
 CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
 # Inside the chained schedule: layer i's node-projection weight gradient (gW5 = gP^T h_in, matrix-core bound, no consumer
-# before the optimizer step) is launched one workgroup per CU on a side stream BESIDE layer i-1's by-source pass (HBM
-# bound, capped at four workgroups per CU so that both fit a CU's registers: 168 + 4 x 80 of 512 per SIMD lane).
-# Measured on one box: 187.9 -> 183.8 ms/step; with five by-source workgroups the two kernels no longer co-reside and
-# nothing is gained.  GNM_TN_SIDE=0 keeps everything on one stream (the per-op timing mode always does).
+# before the optimizer step) is launched on a side stream BESIDE layer i-1's by-source pass (HBM bound), which is capped
+# at four workgroups per CU (4 x 80 registers per SIMD lane) so that the weight-gradient workgroups (168 registers) find
+# room on every CU.  Measured on one box: 187.9 -> 183.8 ms/step; with five by-source workgroups the two kernels no
+# longer co-reside and nothing is gained.  The caps travel as ARGUMENTS of the two launches (max_blocks_per_cu; 0 = none):
+# no process-wide state is touched (round 2 flipped gnm_set_occupancy_cap between the launches, and the weight-gradient
+# kernel never honoured it: TN_SIDE_CAP = 0 is what was measured).  GNM_TN_SIDE=0 keeps everything on one stream (the
+# per-op timing mode always does).
 TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
-TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "1"))
+TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
 SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
-    return CHAIN and FUSED and H == 128 and batch_norm and not CORUN and _lib.get_matmul_mode() == "bf16x3"
+    return CHAIN and FUSED and H == 128 and batch_norm and _lib.get_matmul_mode() == "bf16x3"
 
 
 def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tensor], L: int, saved: List[LayerSaved],
@@ -561,25 +538,25 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
         o = outs[i] or {}
         g = grads[i]
         bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, o.get("gamma_e"), o.get("beta_e"))
+        src_cap = 0
         if pending is not None:
-            # the matrix-bound weight gradient of the layer above, one workgroup per CU on the side stream, beside this
-            # layer's HBM-bound by-source pass (see TN_SIDE)
+            # the matrix-bound weight gradient of the layer above on the side stream, beside this layer's HBM-bound
+            # by-source pass (see TN_SIDE)
             pgP, ph, pW, pb = pending
             main.wait_stream(side)      # the previous deferred kernel ended a layer ago: free, and makes `held` safe to drop
             held.clear()                # (no record_stream: blocks parked on a side-stream event made the allocator
             side.wait_stream(main)      #  fall back to hipMalloc / hipFree in the lean mode: 3x the step time)
             sc3 = scratch(dev, "tn")
             ws3 = sc3.ws(need_p)
-            lib.gnm_set_occupancy_cap(TN_SIDE_CAP)
             _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(pgP), _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials),
-                                                _ptr(ws3), need_p, C.c_void_p(side.cuda_stream)), "gnm_node_proj_bwd_tn")
+                                                _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
+                       "gnm_node_proj_bwd_tn")
             held.extend((pgP, ph))
             pending = None
-            lib.gnm_set_occupancy_cap(SRC_SIDE_CAP)
+            src_cap = SRC_SIDE_CAP
         _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
               _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
-              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), st)
-        lib.gnm_set_occupancy_cap(0)
+              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), src_cap, st)
         del Ud, Td, Q
         g["W5"], g["b5"] = tgt(i, "W5", 5 * H, H), tgt(i, "b5", 5 * H)
         gh_in = torch.empty(N, H, **f32)
@@ -589,7 +566,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             pending = (gP, s.h_in, g["W5"], g["b5"])
         else:
             _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
-                  _ptr(sc.partials), _ptr(ws), need_p, st)
+                  _ptr(sc.partials), _ptr(ws), need_p, 0, st)
         del gP
         gh = gh_in
         g["W3"], g["b3"] = tgt(i, "W3", H, H), tgt(i, "b3", H)

@@ -92,7 +92,7 @@ class AssemblyGraph:
         g.device = src.device
         g.ndata = {}
         g.edata = {}
-        g._node_order = "keep"
+        g._node_order_mode = "keep"
         g._nrank_t = nrank
         g.relabel_info = {"mode": "given" if nrank is not None else "keep", "relabelled": nrank is not None}
         return g
@@ -128,7 +128,7 @@ class AssemblyGraph:
         self.device = torch.device("cpu")
         self.ndata = {}
         self.edata = {}
-        self._node_order = node_order      # None: the module default at the time the index is built
+        self._node_order_mode = node_order      # None: the module default at the time the index is built
         self._nrank_t = None
         self.relabel_info = {}             # filled by host_index(): what was decided, on what evidence, how long it took
 
@@ -185,7 +185,7 @@ class AssemblyGraph:
             n, e = self._n, self.num_edges()
             ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
             src, dst = self._src, self._dst
-            mode = self._node_order or NODE_ORDER
+            mode = self._node_order_mode or NODE_ORDER
             info = {"mode": mode, "relabelled": False}
             order = rank = None
             if mode == "auto":

@@ -35,7 +35,10 @@ def save_graph(path: str, graph: AssemblyGraph) -> None:
 
 
 def load_graph(path: str, device="cpu") -> AssemblyGraph:
-    with np.load(_npz_path(path)) as z:
+    import os
+    path = str(path)
+    # the path as given if it names a file (saved through a file object, or under another extension); else save_graph's name
+    with np.load(path if os.path.isfile(path) else _npz_path(path)) as z:
         src, dst, num_nodes = z["src"], z["dst"], int(z["num_nodes"])
         for name, a in (("src", src), ("dst", dst)):
             if a.ndim != 1 or not np.issubdtype(a.dtype, np.integer):

@@ -111,9 +111,15 @@ class History:
 
 
 def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSample], out: str = "model",
-          hyperparameters: Optional[Dict] = None, workdir: str = ".", verbose: bool = True):
+          hyperparameters: Optional[Dict] = None, workdir: str = ".", verbose: bool = True,
+          hooks: Optional[Dict] = None):
     """Full-graph training loop (train.py:232-281,379-529).  Returns (model, best_state_dict, History).
-    Under torch.distributed every rank passes ITS shard of the training graphs (dp.shard_graphs)."""
+    Under torch.distributed every rank passes ITS shard of the training AND of the validation graphs
+    (dp.shard_graphs; a shard may be empty for validation): the W graphs of a step contribute the mean of their
+    gradients, epoch / validation losses and TP..FN counts are summed over the ranks, rank 0 writes the files.
+    `hooks` (observers for tests and logging, never needed for training): "after_exchange"(epoch, it, flat) right
+    after the gradient exchange of a full-graph step, "after_epoch"(epoch, model) at the end of every epoch."""
+    hooks = hooks or {}
     hp = dict(get_hyperparameters())
     hp.update(hyperparameters or {})
     seed = hp["seed"]
@@ -135,7 +141,7 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
             dist.broadcast(p.data, 0)
     best_state = copy.deepcopy(model.state_dict())                                              # train.py:203
     model.flatten_parameters()
-    flat = dp.FlatGradients(model.parameters())
+    flat = dp.FlatGradients(model.parameters(), direct_write=True)       # the loop below zero_()s before every backward
     optimizer = torch.optim.Adam(model.parameters(), lr=hp["lr"])                               # train.py:209
     criterion = models.BCEWithLogitsLoss(pos_weight=1.0 / ratio)                                # train.py:210-211
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=hp["decay"],
@@ -161,6 +167,8 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
                     loss = criterion(pred, s.y)
                     loss.backward()
                 flat.all_reduce_mean(contributed=s is not None)
+                if "after_exchange" in hooks:
+                    hooks["after_exchange"](epoch, it, flat)
                 optimizer.step()                                                                # train.py:256-258
                 if s is not None:
                     loss_sum += loss.detach().double()
@@ -237,6 +245,8 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
             save_checkpoint(epoch, model, optimizer, train_loss, val_loss, out, os.path.join(workdir, "checkpoints"))
         scheduler.step(val_loss)                                                                # train.py:529
         hist.final_lr = optimizer.param_groups[0]["lr"]
+        if "after_epoch" in hooks:
+            hooks["after_epoch"](epoch, model)
         if verbose and rank == 0:
             print(f"epoch {epoch}: train loss {train_loss:.4f}  valid loss {val_loss:.4f}  lr {hist.lr[-1]:.2e}")
     return model, best_state, hist

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 1
+#define GNM_ABI_VERSION 2   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -44,9 +44,13 @@ const char* gnm_last_error(void);
 int gnm_num_cus(void);
 /* upper bound on the number of per-block partial rows any kernel writes (see *_partials) */
 int gnm_max_partial_blocks(void);
-/* Cap on the workgroups per CU the persistent kernels size their grids for (0 = none, the default:
- * one full resident wave of workgroups).  A host that runs two kernels on two streams at once sets
- * it around each launch so that both fit on every CU (process-wide, not thread-safe).          */
+/* Process-wide configuration knobs (NOT per-call state; set them before the first launch, never while another
+ * thread is inside the library).  Everything a launch needs beyond them travels in its arguments, so the entry
+ * points themselves are re-entrant: two host threads, or one host on two streams, may call concurrently.
+ *   gnm_set_matmul_mode     (below) which matrix-core arithmetic the fused kernels use;
+ *   gnm_set_occupancy_cap   tools/ only: a default cap on workgroups per CU for every persistent kernel
+ *                           (0 = none).  A host that co-schedules two kernels on two streams does NOT use it: the
+ *                           entry points it needs take the cap per call (max_blocks_per_cu; 0 = none).       */
 int gnm_set_occupancy_cap(int blocks_per_cu);
 
 /* ---- graph index (HOST pointers; replaces DGL's lazy CSR/CSC build + dgl.reverse,
@@ -185,7 +189,7 @@ int gnm_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const floa
                      const float* stat_e, const float* bstat_e, const float* gamma_e,
                      const float* ge, const float* Q, const int32_t* in_ptr,
                      const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
-                     const float* Ud, const float* Td, float* gP, void* stream);
+                     const float* Ud, const float* Td, float* gP, int max_blocks_per_cu, void* stream);
 /* edge_bwd_gt: gt = gamma*rstd*(gu - m1 - that*m2), gu = ge*[t*scale+shift > 0]          */
 int gnm_edge_bwd_gt(int64_t E, int H, const float* ge, const float* t, const float* stat_e,
                     const float* bstat_e, const float* gamma_e, float* gt, void* stream);
@@ -265,7 +269,7 @@ int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float*
 int gnm_node_proj_bwd_nn(int64_t N, int H, int ncols, const float* gP, const float* W, const float* gh_out,
                          float* gh_in, void* ws, size_t ws_bytes, void* stream);
 int gnm_node_proj_bwd_tn(int64_t N, int H, int ncols, const float* gP, const float* h_in, float* gW, float* gb,
-                         double* partials, void* ws, size_t ws_bytes, void* stream);
+                         double* partials, void* ws, size_t ws_bytes, int max_blocks_per_cu, void* stream);
 size_t gnm_edge_bwd_fused_workspace_bytes(void);
 int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const float* t, const float* e_in,
                        const float* stat_e, const float* bstat_e, const float* gamma_e,

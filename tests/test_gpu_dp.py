@@ -121,3 +121,78 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert r["steps"] == 2 and r["warmup"] == 1
     # whole-job aggregate: the edges of BOTH ranks per max-over-ranks step time
     assert abs(r["value"] - r["config"]["edges_total"] / (r["ms_per_step"] / 1e3)) <= 1e-6 * r["value"]
+
+
+def test_train_loop_under_two_ranks_mixed_chromosomes(tmp_path):
+    """BASELINE.json configs[3] in miniature, EXECUTED: gnnome_assembly_amd.train.train (the counterpart of the
+    reference's loop, train.py:232-281,379-529) under world = 2 on the HIP path, three training graphs at
+    chr19 : chr20 : chr21 relative sizes (evaluate.py:28-30) sharded 2 + 1 (one padded step per epoch), one
+    validation graph on rank 0 only, two epochs, patience 0.  Checks: broadcast initial weights + matched collectives
+    (replicas bit-equal after every epoch), the first exchanged gradient == mean of the oracle gradients of the two
+    graphs of that step, identical validation losses / LR schedule / best epoch on both ranks, files from rank 0 only,
+    no hang."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import train_dp_worker as W
+    world, H, L, R, epochs = 2, 128, 3, 1200, 2
+    port = _free_port()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+                GNM_BENCH_DEVICE="0", GNM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "tests", "train_dp_worker.py"), str(tmp_path), str(H), str(L), str(R), str(epochs)]
+    procs, outs = _run_group([cmd] * world, [dict(base, RANK=str(r), LOCAL_RANK=str(r)) for r in range(world)], 300)
+    _log("dp2_train_config4.log", "\n".join(outs))
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+    j = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    # shards: size-sorted round robin of (chr19, chr20, chr21) = sizes (1, 1.073, 0.731): rank 0 [chr20, chr21], rank 1 [chr19]
+    assert j[0]["shard"] == [1, 2] and j[1]["shard"] == [0] and j[0]["valid_shard"] == [0] and j[1]["valid_shard"] == []
+    assert len(j[0]["step_graph"]) == 2 * epochs and len(j[1]["step_graph"]) == epochs      # rank 1 pads one step per epoch
+    # replicas bit-equal after every epoch and at the end
+    assert len(j[0]["epoch_hashes"]) == epochs and j[0]["epoch_hashes"] == j[1]["epoch_hashes"]
+    assert np.array_equal(z[0]["final"], z[1]["final"]) and list(z[0]["order"]) == list(z[1]["order"])
+    # the reduced scalars are the same everywhere
+    for k in ("loss_train", "loss_valid", "lr", "final_lr", "best_epoch", "tfpn_train", "tfpn_valid"):
+        assert j[0][k] == j[1][k], (k, j[0][k], j[1][k])
+    assert all(np.isfinite(j[0]["loss_valid"])) and len(j[0]["loss_valid"]) == epochs
+    assert sum(j[0]["tfpn_valid"][0]) > 0                                   # the validation graph was scored (by rank 0 only)
+    # only rank 0 wrote files
+    assert "checkpoints/cfg4.pt" in j[0]["files"] and j[1]["files"] == []
+    assert ("pretrained/model_cfg4.pt" in j[0]["files"]) == (j[0]["best_epoch"] >= 0)
+    # first exchanged gradient == mean of the ORACLE gradients of the two graphs of step 0 (bars of the test above)
+    assert np.array_equal(z[0]["grad0"], z[1]["grad0"])
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    from oracle import gatedgcn_oracle as orc
+    train_set, _ = W.dataset(R)
+    first = [train_set[j[r]["shard"][j[r]["step_graph"][0]]] for r in range(world)]     # (reads, seed) of each rank's step-0 graph
+    torch.manual_seed(0)                                                     # train.train: utils.set_seed, then the model
+    sd0 = {k: v.detach().numpy() for k, v in G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16).state_dict().items()}
+    ratios = []
+    for reads, seed in train_set:                                            # train.py:181: dataset mean of #pos / #neg
+        src, dst, n = synth.make_graph(reads, seed=seed, permute_edge_ids=True)
+        y = synth.make_inputs(src, dst, n, seed=seed)["y"]
+        ratios.append(np.float32((y == 1).sum()) / np.float32((y == 0).sum()))
+    pw = 1.0 / float(np.mean(ratios))
+
+    def oracle(dtype):
+        tot = None
+        for reads, seed in first:
+            src, dst, n = synth.make_graph(reads, seed=seed, permute_edge_ids=True)
+            inp = synth.make_inputs(src, dst, n, seed=seed)
+            p = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in sd0.items()}
+            s = orc.model_forward(p, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(inp["e"]).to(dtype),
+                                  torch.from_numpy(inp["pe"]).to(dtype))
+            orc.bce_loss(s, torch.from_numpy(inp["y"]).to(dtype), pw).backward()
+            g = {k: v.grad.double().numpy() / world for k, v in p.items()}
+            tot = g if tot is None else {k: tot[k] + g[k] for k in g}
+        return tot
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    o, bad = 0, []
+    gmax = max(float(np.linalg.norm(v)) for v in g64.values())
+    for k in [str(s) for s in z[0]["order"]]:
+        want = g64[k].reshape(-1)
+        got = z[0]["grad0"][o:o + want.size].astype(np.float64)
+        o += want.size
+        r, r32, mx = rel_l2(got, want), rel_l2(g32[k].reshape(-1), want), float(np.abs(got - want).max())
+        if not (r <= 2e-4 or r <= 3.0 * r32 + 1e-6 or mx <= max(2e-7, 1e-6 * gmax)):
+            bad.append((k, r, r32, mx))
+    assert o == z[0]["grad0"].size and not bad, bad

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import golden_files
-from helpers import load_case, sd_to_torch, rel_l2, assert_parity, RTOL, ATOL
+from helpers import load_case, sd_to_torch, rel_l2, assert_parity, tally_clause, RTOL, ATOL
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,13 @@ NOISE_X = 3.0
 
 
 def _grad_ok(r_ours, r_ref32, max_abs, floor):
-    return r_ours <= GRAD_L2 or r_ours <= NOISE_X * r_ref32 + 1e-6 or max_abs <= floor
+    """Which clause lets this tensor pass is tallied per test (helpers.GRAD_CLAUSES -> gpurun_out/grad_clauses.json,
+    committed as profiles/r03_grad_clauses.txt); tests/test_zz_grad_clause_budget.py fails the suite when a test
+    takes more escapes (anything but the plain rel-L2 bar) than the committed baseline."""
+    clause = ("l2" if r_ours <= GRAD_L2 else "noise" if r_ours <= NOISE_X * r_ref32 + 1e-6 else
+              "floor" if max_abs <= floor else "miss")
+    tally_clause(clause)
+    return clause != "miss"
 
 
 def _oracle_grads(z, sd, dtype, batch_norm=True):
@@ -84,7 +90,7 @@ def _cmp(name, got, want, rows):
 def test_library_loaded_and_device():
     from gnnome_assembly_amd import _lib
     lib = _lib.load()
-    assert lib.gnm_abi_version() == 1
+    assert lib.gnm_abi_version() == 2
     assert lib.gnm_num_cus() >= 64
     print("CUs:", lib.gnm_num_cus(), torch.cuda.get_device_name(0))
 
@@ -278,7 +284,9 @@ def test_model_matches_golden(fname):
         brows, bgmax = _branch_exact_rows(z["src"], z["dst"], int(z["n"]), z["e_raw"], z["pe"], z["y"],
                                           float(z["pos_weight"]), sd, L, dev)
         exact = {r[0]: r for r in brows}
+        nmiss = len(bad)
         bad = [b for b in bad if exact[b[0]][1] > BRANCH_L2 and exact[b[0]][2] > max(GRAD_ABS_FLOOR, 1e-6 * bgmax)]
+        tally_clause("branch_exact", nmiss - len(bad), forgiven=True)
     assert not bad, f"gradient mismatches (name, rel_l2, max_abs, ref_norm, reference-fp32 rel_l2): {bad}"
     # eval mode == train mode (BatchNorm has no running stats: gated_gcn_full.py:55-56)
     model.eval()
@@ -680,54 +688,13 @@ def test_other_widths_and_norms_vs_oracle(H, L, bn):
     if bad and bn:      # BatchNorm: only relu-kink flips may explain a miss (see test_model_matches_golden)
         brows, bgmax = _branch_exact_rows(src, dst, n, inp["e"], inp["pe"], inp["y"], float(inp["pos_weight"]), sd, L, dev)
         exact = {r[0]: r for r in brows}
+        nmiss = len(bad)
         bad = [b for b in bad if exact[b[0]][1] > BRANCH_L2 and exact[b[0]][2] > max(GRAD_ABS_FLOOR, 1e-6 * bgmax)]
+        tally_clause("branch_exact", nmiss - len(bad), forgiven=True)
     assert not bad, bad
 
 
-def _device_masks(ms, sd, e_raw_np, perm):
-    """The relu branch decisions the device kernels took, reproduced exactly: every kernel tests the
-    sign of a single fmaf (or of a stored pre-activation), and the sign of round(a*b+c) equals the
-    sign of a*b+c evaluated in fp64 (a*b is exact there)."""
-    inv = torch.empty_like(perm)
-    inv[perm] = torch.arange(perm.numel())
-    u, w = [], []
-    for s in ms.layers:
-        uu = s.t.double() * s.stat_e[2].double() + s.stat_e[3].double()
-        u.append((uu > 0).cpu()[inv])                 # internal order -> edge-id order
-        ww = s.z.double() * s.stat_h[2].double() + s.stat_h[3].double()
-        w.append((ww > 0).cpu())
-    hid = (ms.pred.hid > 0).cpu()[inv]
-    # encoder: ap = fmaf(w1a, x0, fmaf(w1b, x1, b))  (gnm_encoder.hip) -- inner fma rounded to fp32
-    W1, b1 = sd["linear1_edge.weight"].astype(np.float64), sd["linear1_edge.bias"].astype(np.float64)
-    x = e_raw_np.astype(np.float64)
-    inner = (x[:, 1:2] * W1[None, :, 1] + b1[None, :]).astype(np.float32).astype(np.float64)
-    a1 = torch.from_numpy((x[:, 0:1] * W1[None, :, 0] + inner) > 0)
-    return {"u": u, "w": w, "hid": hid, "a1": a1}
-
-
-def _branch_exact_rows(src, dst, n, e_raw, pe, y, pw, sd, L, dev):
-    """rows (name, rel_l2, max_abs, ref_norm) of the HIP gradients against the fp64 oracle backward evaluated
-    on the SAME relu branches the device took, and the largest reference gradient norm."""
-    from gnnome_assembly_amd import AssemblyGraph, engine
-    from oracle import gatedgcn_oracle as orc
-    g = AssemblyGraph(src, dst, n).to(dev)
-    perm = g.index()["perm"].long().cpu()
-    P = {k: v.to(dev) for k, v in sd_to_torch(sd).items()}
-    scores, ms = engine.model_forward(g, torch.from_numpy(e_raw).to(dev), torch.from_numpy(pe).to(dev), P, L, True)
-    masks = _device_masks(ms, sd, e_raw, perm)
-    loss, gs = engine.bce_with_logits(scores, torch.from_numpy(y).to(dev), pw)
-    Gd = engine.model_backward(g, P, L, ms, gs)
-    torch.cuda.synchronize()
-    with torch.no_grad():
-        _, l64, g64 = orc.manual_forward_backward(sd_to_torch(sd, torch.float64), torch.from_numpy(src), torch.from_numpy(dst),
-                                                  n, torch.from_numpy(e_raw).double(), torch.from_numpy(pe).double(),
-                                                  torch.from_numpy(y).double(), pw, masks=masks)
-    assert abs(loss.item() - l64.item()) < 1e-5
-    rows = []
-    gmax = max(float(v.norm()) for v in g64.values())
-    for k in g64:
-        _cmp(k, Gd[k], g64[k], rows)
-    return rows, gmax
+from helpers import branch_exact_rows as _branch_exact_rows  # noqa: E402  (shared with __graft_entry__.smoke)
 
 
 BRANCH_L2 = 5e-5
@@ -780,7 +747,6 @@ def test_full_size_forward_is_edge_id_order_equivariant():
     assert r <= 2e-5 and float((s1 - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
 
 
-@pytest.mark.mode_independent
 def test_train_loop_matches_the_reference_loop(tmp_path, golden_dir):
     """gnnome_assembly_amd.train.train (the build's own LOOP, not a hand-rolled one) against the reference's
     full-graph training loop run on the reference's own model (tests/golden/make_golden_train.py: train.py:181,
@@ -863,7 +829,7 @@ def test_flat_gradient_fast_path_equals_autograd_accumulation():
     crit(model(g, None, e, pe).squeeze(-1), y).backward()                 # ordinary autograd accumulation
     ref = {k: p.grad.clone() for k, p in model.named_parameters()}
     model.flatten_parameters()
-    flat = dp.FlatGradients(model.parameters())
+    flat = dp.FlatGradients(model.parameters(), direct_write=True)          # the fast path is an opt-in
     named = dict(model.named_parameters())
     a = [named[f"gnn.convs.1.{k}.weight"].grad for k in ("A_1", "A_2", "A_3", "B_1", "B_2")]
     assert all(x.data_ptr() + x.numel() * 4 == y_.data_ptr() for x, y_ in zip(a[:-1], a[1:]))   # one [5H,H] block
@@ -875,6 +841,23 @@ def test_flat_gradient_fast_path_equals_autograd_accumulation():
     crit(model(g, None, e, pe).squeeze(-1), y).backward()                 # not zeroed: accumulates (autograd route)
     assert all(torch.equal(p.grad, 2 * ref[k]) for k, p in named.items())
     assert all(flat.flat.data_ptr() <= p.grad.data_ptr() < flat.flat.data_ptr() + flat.flat.numel() * 4 for p in named.values())
+    # a gradient written by anything else than the model's backward leaves the buffer "not fresh": the next backward
+    # accumulates instead of overwriting (all_reduce_mean on a padding step did not clear the flag)
+    flat.zero_()
+    flat.all_reduce_mean(contributed=False)
+    assert not flat.fresh
+    # a parameter hook switches the fast path off (hooks only see gradients that travel through autograd) ...
+    flat.zero_()
+    seen = []
+    hnd = named["predictor.W2.bias"].register_hook(lambda gr: seen.append(float(gr.sum())))
+    crit(model(g, None, e, pe).squeeze(-1), y).backward()
+    hnd.remove()
+    assert seen and not flat.fresh and all(torch.equal(p.grad, ref[k]) for k, p in named.items())
+    # ... and without the opt-in every gradient takes the autograd route: autograd.grad returns them
+    plain = dp.FlatGradients(model.parameters())
+    plain.zero_()
+    gs = torch.autograd.grad(crit(model(g, None, e, pe).squeeze(-1), y), list(named.values()))
+    assert all(torch.equal(a_, ref[k]) for a_, k in zip(gs, named))
 
 
 def test_lean_activation_mode_is_bit_identical_and_smaller():
@@ -1038,9 +1021,11 @@ def test_bench_line_contract(tmp_path):
     assert "1/" in cb["sample"]                      # the sample states its ratio to the GPU workload
 
 
-def test_two_stream_backward_option_changes_nothing_but_rounding():
-    """engine.CORUN (GNM_CORUN=1): fused edge backward on a side stream beside the by-source pass.  Same
-    kernels, only the number of per-workgroup gW3 slabs differs -> gradients equal to fp32 round-off."""
+def test_side_stream_schedule_and_per_call_caps_change_nothing_but_rounding():
+    """The chained backward launches the node weight-gradient kernel on a side stream beside the by-source pass
+    (engine.TN_SIDE); the workgroups-per-CU caps of the two kernels are ARGUMENTS of their launches (gnm.h
+    max_blocks_per_cu), no process-wide state.  Same kernels: another cap only changes the number of per-workgroup
+    partial slabs, i.e. the summation order -> gradients equal to fp32 round-off, and every setting is deterministic."""
     from gnnome_assembly_amd import engine
     dev = _dev()
 
@@ -1054,16 +1039,17 @@ def test_two_stream_backward_option_changes_nothing_but_rounding():
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in model.named_parameters()}
     base = run()
-    engine.CORUN = True
+    keep = (engine.TN_SIDE, engine.TN_SIDE_CAP, engine.SRC_SIDE_CAP)
     try:
-        co = run()
-        co2 = run()
+        for setting in ((False, 0, 0), (True, 1, 2), (True, 2, 8)):
+            engine.TN_SIDE, engine.TN_SIDE_CAP, engine.SRC_SIDE_CAP = setting
+            co, co2 = run(), run()
+            for k in base:
+                assert torch.equal(co[k], co2[k]), (setting, k)                    # still deterministic
+                d = float((co[k] - base[k]).abs().max())
+                assert d <= 1e-5 * float(base[k].abs().max()) + 1e-9, (setting, k, d)
     finally:
-        engine.CORUN = False
-    for k in base:
-        assert torch.equal(co[k], co2[k]), k                                   # still deterministic
-        d = float((co[k] - base[k]).abs().max())
-        assert d <= 1e-5 * float(base[k].abs().max()) + 1e-9, (k, d)
+        engine.TN_SIDE, engine.TN_SIDE_CAP, engine.SRC_SIDE_CAP = keep
 
 
 @pytest.mark.mode_independent
@@ -1114,3 +1100,36 @@ def test_degenerate_constant_features_stay_finite_and_match_the_oracle():
     d = float((got.cpu().double() - want).abs().max())
     print(f"constant-feature graph: max |logit - oracle| = {d:.2e}, |logit| up to {float(want.abs().max()):.3f}")
     assert d <= 2e-3 * max(1.0, float(want.abs().max()))
+
+
+def test_non_finite_inputs_stay_confined_and_the_split_mode_divergence_is_as_documented():
+    """An inf operand of a split-mode (bf16x3) product gives NaN where the reference's fp32 arithmetic gives +-inf:
+    x = hi + mid + lo with hi = inf leaves mid = inf - inf = NaN, and even a clean split would meet inf * w_hi +
+    inf * w_mid with opposite signs.  The fp32-MFMA mode propagates inf like torch.  Either way the damage is
+    CONFINED to the rows that hold the non-finite value (no kernel mixes rows of a [M,K] operand in the forward
+    product), NaN stays NaN in both modes, and all other rows are bit-identical to the run without it.
+    INTEGRATION.md ("Numerics") tells callers which mode to pick if they rely on inf semantics."""
+    from gnnome_assembly_amd import _lib, engine
+    dev = _dev()
+    mode = _lib.get_matmul_mode()
+    rng = np.random.default_rng(5)
+    M, N, K = 4096, 128, 128                                  # the shape class of every H = 128 layer product
+    X = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev)
+    Wt = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32) + 0.01).to(dev)
+    clean = engine.gemm(engine.NT, X, Wt, torch.empty(M, N, device=dev))
+    Xi = X.clone()
+    Xi[7, 3] = float("inf")
+    Xi[100, 5] = float("nan")
+    out = engine.gemm(engine.NT, Xi, Wt, torch.empty(M, N, device=dev))
+    torch.cuda.synchronize()
+    rows = torch.ones(M, dtype=torch.bool, device=dev)
+    rows[7] = rows[100] = False
+    assert torch.equal(out[rows], clean[rows])                # confined to the two rows
+    assert bool(torch.isnan(out[100]).all())                  # NaN in -> NaN out, both modes
+    assert not bool(torch.isfinite(out[7]).any())             # the inf row is non-finite everywhere ...
+    ref = Xi[7:8].cpu() @ Wt.cpu().t()                        # ... torch fp32: +-inf by the sign of W[:, 3]
+    assert bool(torch.isinf(ref).all())
+    if mode == "f32":
+        assert torch.equal(out[7:8].cpu(), ref)               # the fp32-MFMA mode keeps the reference's inf semantics
+    else:
+        assert bool(torch.isnan(out[7]).any())                # bf16x3: the documented divergence
