@@ -418,7 +418,6 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
 // four row streams AND the six gathered node rows of the NEXT tile are requested a tile ahead, so that no phase
 // waits on memory (the eight waves share every barrier, there is no second workgroup to hide a wait).
 constexpr int CT = 512;                    // threads per workgroup
-constexpr int WG_ = 4;                     // rows per LDS read group of the column walk (8 and 16 measured the same)
 constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 5 * ER * SW * 4 + 3 * 2 * ER * 4;
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
@@ -478,26 +477,30 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   const int trq0 = simg_tr_base(lane, 0), trq1 = simg_tr_base(lane, 1);   // transpose-read bases (gnm_tr.h)
   const int ni = lane & 15, ng = lane >> 4;
   const int nnb = ni * SPITCH + ((((ni & 3) << 2) | (ng ^ (swz(ni) & 3))) << 4);
-  // column walkers: column wcol; role 0 sums sigma*Qb (-> gA3h), 1 that (-> Td), 2 gu (-> Ud), 3 the BatchNorm column
-  // sums of layer i-1 (sum gu, sum gu*that, fp64)
-  // column walkers: threads 0-95 (waves 0 and 1), one float4 of columns each; role = tid >> 5: 0 sums sigma*Qb
-  // (-> gA3h), 1 that (-> Td), 2 gu (-> Ud).  The BatchNorm column sums of layer i-1 (sum gu, sum gu*that, fp64:
-  // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
-  const bool walker = tid < 96, bnsum = (tid & 128) != 0;      // BatchNorm sums: waves 2, 3, 6, 7, two rows of a tile each
-  const int role = (tid >> 5) & 3, wc4 = (tid & 31) * 4;
-  const int brow = 2 * (((tid >> 8) << 2) | ((tid >> 5) & 3));   // first of this thread's two rows (0, 2, .. 14)
-  int cur = -1;                             // node whose segment is being summed (wave-uniform)
-  float4 acc0 = f4(0.f);
+  // Column walk (per-destination sums gA3h / Td / Ud of layer i-1), waves 0-5: role = wave >> 1 (0 sums sigma*Qb -> gA3h,
+  // 1 that -> Td, 2 gu -> Ud); a wave covers 64 columns (wave & 1) x the tile's FOUR ROW GROUPS (grp = lane >> 4: rows
+  // 4 grp .. 4 grp + 3, one float4 of columns per lane).  Round 2 walked the 16 rows as ONE dependent chain on 96
+  // threads (2100 cycles of a 7650-cycle tile, every other wave waiting at the next barrier); now a lane chains over 4
+  // rows, and the carry from the groups before it (and from the tile before: `carry` / `cur`) arrives through three
+  // wave-local shuffle rounds -- no barrier, no LDS round trip.  A segment is stored ONCE, by the lane that owns its last
+  // row (destination-sorted rows: the next row's node differs; the next tile's first node is already in the index ring),
+  // through an address select against a per-thread dummy line: still no data-dependent branch around a memory operation.
+  // The BatchNorm column sums of layer i-1 (sum gu, sum gu*that) are taken beside the walk by waves 6 and 7: four rows per
+  // thread summed in fp32, then added to the thread's fp64 accumulators (one conversion per tile instead of per row).
+  const bool walker = wave < 6, bnsum = wave >= 6;
+  const int role = wave >> 1;
+  const int wgrp = lane >> 4;
+  const int wc4 = walker ? ((((wave & 1) << 4) | (lane & 15)) * 4) : (tid & 31) * 4;
+  const int brow = 4 * ((tid >> 5) & 3);    // BatchNorm sums: rows brow .. brow + 3 of a tile
+  int cur = -1;                             // destination node of the previous tile's last row
+  float4 carry = f4(0.f);                   // running sum of that node's segment at the end of the previous tile
   double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};
-  // Every walker step STORES the running sum to its node's output row (the last store of a segment holds the
-  // whole sum; a node's ~5 stores meet in L2): no data-dependent branch around a memory operation, so hipcc keeps
-  // COUNTED vmcnt waits for the prefetched rows (a store under such a branch costs vmcnt(0) = a full drain of the
-  // software pipeline on every tile).  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
   float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
   const int64_t wpitch = role == 0 ? 5 * SW : SW;
   // target of the throw-away stores (rows past the chunk, scoreboard equalisation): a slab of its own BEHIND the
   // gridDim.x slabs that carry results -- a late throw-away store must never meet this workgroup's final slab store
   float* const dummy_row = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + lc4;
+  float* const dummy_w = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + (size_t)(32 + (tid >> 5)) * SW + (tid & 31) * 4;   // walkers' own line
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
@@ -547,12 +550,12 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     prefetch_rows(0);
     // hipcc merges the vector-memory scoreboard of the loop entry with the back edge's and keeps the weaker
     // guarantee.  Throw-away stores (into this workgroup's slab, rewritten at the end) give the entry the queue a
-    // steady-state iteration leaves behind -- row loads | 1 store | 16 walker stores (threads 0-95) | 6 gathers -- so that phase 0
+    // steady-state iteration leaves behind -- row loads | 1 store | 4 walker stores (waves 0-5) | 6 gathers -- so that phase 0
     // waits with a COUNTED vmcnt for the row loads only and the gathers / stores stay in flight.
     st4(dummy_row, f4(0.f));
     if (walker) {
 #pragma unroll
-      for (int r = 0; r < ER; ++r) st4(dummy_row + SW * (1 + r), f4(0.f));
+      for (int r = 0; r < 4; ++r) st4(dummy_w, f4(0.f));
     }
     gather(s0, d0);
   }
@@ -644,40 +647,57 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
     }
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
-    // ---- column walkers (waves 0 and 1) and BatchNorm sums (waves 2 and 3); the rest go on to the next phase 0 ----
+    // ---- column walk (waves 0-5) and BatchNorm sums (waves 6, 7) ----
     if (!(ABL & 1) && walker) {
-      // The 16-step chain is the critical path of this phase (the other waves wait for it at the next barrier), so a
-      // step is kept to two packed FMAs and a store: the destination node is wave-uniform (scalar compare, scalar
-      // part of the address), a new segment multiplies the running sum by 0 instead of selecting, and rows past
-      // the chunk were zeroed when they were written.
-      const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4;
+      const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4 + (4 * wgrp) * SW;
+      const int* dk = sdk + ER + 4 * wgrp;
+      const int d0 = dk[0], d1 = dk[1], d2 = dk[2], d3 = dk[3];
+      // node of the row AFTER this group: the next group's first row, or (last group) the next tile's first row, which
+      // phase 0 put into the ring before this tile's first barrier; the chunk's last tile closes every segment
+      const int dnx = sd[(int)((k + 1) % 3) * 2 * ER + ER];
+      const int d4 = wgrp == 3 ? (k == klast ? -1 : dnx) : sdk[ER + (4 * wgrp + 4 < ER ? 4 * wgrp + 4 : ER - 1)];
+      const float4 x0 = ld4(vsrc), x1 = ld4(vsrc + SW), x2 = ld4(vsrc + 2 * SW), x3 = ld4(vsrc + 3 * SW);
+      // running sums inside the group (a new segment multiplies the running sum by 0; rows past the chunk hold zeros
+      // and repeat the last row's node: they extend its segment by nothing)
+      const float4 s1 = fma4(x0, f4(d1 == d0 ? 1.f : 0.f), x1);
+      const float4 s2 = fma4(s1, f4(d2 == d1 ? 1.f : 0.f), x2);
+      const float4 s3 = fma4(s2, f4(d3 == d2 ? 1.f : 0.f), x3);
+      // carry into the group's first segment: I(g) = s3(g) + [group g is one segment] * cin(g),
+      // cin(g) = [d0(g) == d3(g-1)] * I(g-1), I(-1) = the previous tile's I(3).  Round r makes group r final (a group
+      // recomputed in a later round sees the same, final, neighbour).
+      const int dlp_ = __shfl_up(d3, 16, 64);
+      const float link = d0 == (wgrp == 0 ? cur : dlp_) ? 1.f : 0.f;
+      const float4 open = f4(d0 == d3 ? 1.f : 0.f);
+      float4 cin = carry * link;
+      float4 I = fma4(cin, open, s3);
 #pragma unroll
-      for (int r4 = 0; r4 < ER; r4 += WG_) {        // WG_ rows' LDS reads up front, then the dependent chain
-        int dn[WG_];
-        float4 xs[WG_];
-#pragma unroll
-        for (int q = 0; q < WG_; ++q) {
-          dn[q] = __builtin_amdgcn_readfirstlane(sdk[ER + r4 + q]);
-          xs[q] = ld4(vsrc + (r4 + q) * SW);
-        }
-#pragma unroll
-        for (int q = 0; q < WG_; ++q) {
-          const float keep = dn[q] == cur ? 1.f : 0.f;
-          acc0 = fma4(acc0, f4(keep), xs[q]);
-          cur = dn[q];
-          st4(wout + (int64_t)cur * wpitch, acc0);
-        }
+      for (int r = 1; r < 4; ++r) {
+        const float4 Ip = make_float4(__shfl_up(I.x, 16, 64), __shfl_up(I.y, 16, 64), __shfl_up(I.z, 16, 64), __shfl_up(I.w, 16, 64));
+        if (wgrp != 0) cin = Ip * link;           // (a select: group 0 keeps the tile carry)
+        I = fma4(cin, open, s3);
       }
+      // every segment is stored once, from its last row
+      float* const o0 = wout + (int64_t)d0 * wpitch;
+      st4(d1 != d0 ? o0 : dummy_w, x0 + cin);
+      st4(d2 != d1 ? wout + (int64_t)d1 * wpitch : dummy_w, fma4(cin, f4(d1 == d0 ? 1.f : 0.f), s1));
+      st4(d3 != d2 ? wout + (int64_t)d2 * wpitch : dummy_w, fma4(cin, f4(d2 == d0 ? 1.f : 0.f), s2));
+      st4(d4 != d3 ? wout + (int64_t)d3 * wpitch : dummy_w, I);
+      // the tile's last row -> the next tile's group 0
+      const int sl_ = 48 + (lane & 15);
+      carry = make_float4(__shfl(I.x, sl_, 64), __shfl(I.y, sl_, 64), __shfl(I.z, sl_, 64), __shfl(I.w, sl_, 64));
+      cur = sdk[ER + ER - 1];
     }
-    if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only (rows past the chunk hold zeros)
+    if (!(ABL & 1) && bnsum) {                       // LDS reads, fp32 over four rows, then fp64 (rows past the chunk hold zeros)
+      float4 ga_ = f4(0.f), gb_ = f4(0.f);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < 4; ++q) {
         const float4 x = ld4(v2 + (brow + q) * SW + wc4);
         const float4 th = ld4(v3 + (brow + q) * SW + wc4);
-        s_gu[0] += (double)x.x; s_gu[1] += (double)x.y; s_gu[2] += (double)x.z; s_gu[3] += (double)x.w;
-        s_gut[0] += (double)x.x * (double)th.x; s_gut[1] += (double)x.y * (double)th.y;
-        s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
+        ga_ += x;
+        gb_ = fma4(x, th, gb_);
       }
+      s_gu[0] += (double)ga_.x; s_gu[1] += (double)ga_.y; s_gu[2] += (double)ga_.z; s_gu[3] += (double)ga_.w;
+      s_gut[0] += (double)gb_.x; s_gut[1] += (double)gb_.y; s_gut[2] += (double)gb_.z; s_gut[3] += (double)gb_.w;
     }
     {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
@@ -697,10 +717,10 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       sl[m * SW + wc * 32 + li] = tn[x][e];
     }
   __syncthreads();
-  {   // BatchNorm column sums of layer i-1: eight row-pair groups (waves 2, 3, 6, 7) -> one row of partials_lo
-    double* bnr = reinterpret_cast<double*>(lds);      // [8 groups][2][128] doubles = 16 KB (the images are dead)
+  {   // BatchNorm column sums of layer i-1: four row groups (waves 6, 7) -> one row of partials_lo
+    double* bnr = reinterpret_cast<double*>(lds);      // [4 groups][2][128] doubles = 8 KB (the images are dead)
     if (bnsum) {
-      const int grp = brow >> 1;
+      const int grp = brow >> 2;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bnr[(grp * 2 + 0) * SW + wc4 + j] = s_gu[j];
@@ -711,7 +731,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     if (tid < 2 * SW) {
       double s_ = 0.0;
 #pragma unroll
-      for (int g8 = 0; g8 < 8; ++g8) s_ += bnr[g8 * 2 * SW + tid];
+      for (int g8 = 0; g8 < 4; ++g8) s_ += bnr[g8 * 2 * SW + tid];
       a.partials_lo[(size_t)chunk * 2 * SW + tid] = s_;
     }
     __syncthreads();
