@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kBlock) void edge_t_stats_fwd_k(int64_t E, float* _
 
 // e_out = relu(bn(t)) + e_in ; sigma = sigmoid(e_out) ; by-destination gated mean.
 // gated_gcn_full.py:122-130
-template <int H>
+// RES = false: no residual (GatedGCN_1d(residual=False) or in_channels != out_channels, gated_gcn_full.py:41-42,124-125)
+template <int H, bool RES = true>
 __global__ __launch_bounds__(kBlock, 8) void edge_gate_fwd_k(int64_t N, const float* __restrict__ t,
                                                           const float* __restrict__ e_in,
                                                           const float* __restrict__ stat,
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(kBlock, 8) void edge_gate_fwd_k(int64_t N, const fl
     for (int64_t j = a + sub; j < b; j += RPW) {
       const int64_t s = isrc[j];
       const float4 tt = ld4_nt(t + j * H + c4);
-      const float4 ee = ld4_nt(e_in + j * H + c4);
+      float4 ee = f4(0.f);
+      if constexpr (RES) ee = ld4_nt(e_in + j * H + c4);
       const float4 a2 = ld4(P + s * (5 * H) + H + c4);
       const float4 eo = relu4(fma4(tt, sc, sh)) + ee;
       st4_nt(e_out + j * H + c4, eo);
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kBlock, 8) void node_agg_src_fwd_k(
 }
 
 // h_out = relu(bn(z)) + h_in.   gated_gcn_full.py:147-152
-template <int H>
+template <int H, bool RES = true>
 __global__ __launch_bounds__(kBlock) void node_update_fwd_k(int64_t N, const float* __restrict__ z,
                                                             const float* __restrict__ stat,
                                                             const float* __restrict__ h_in,
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(kBlock) void node_update_fwd_k(int64_t N, const flo
     const int c4 = (int)(i % G) * 4;
     const int64_t o = (i / G) * H + c4;
     const float4 sc = ld4(stat + 2 * H + c4), sh = ld4(stat + 3 * H + c4);
-    st4(h_out + o, relu4(fma4(ld4(z + o), sc, sh)) + ld4(h_in + o));
+    float4 hr = f4(0.f);
+    if constexpr (RES) hr = ld4(h_in + o);
+    st4(h_out + o, relu4(fma4(ld4(z + o), sc, sh)) + hr);
   }
 }
 
@@ -470,12 +474,15 @@ extern "C" int gnm_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, co
                                  const float* stat_e, const float* P, const int32_t* isrc,
                                  const int32_t* in_ptr, float* e_out, float* hf, float* inv_f,
                                  void* stream) {
-  GNM_CHECK_ARG(N >= 0 && E >= 0 && t && e_in && stat_e && P && isrc && in_ptr && e_out && hf && inv_f,
-                "edge_gate_fwd: null/neg argument");
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && t && stat_e && P && isrc && in_ptr && e_out && hf && inv_f,
+                "edge_gate_fwd: null/neg argument");      // e_in == NULL: no residual (residual=False / in != out)
   GNM_DISPATCH_H(H, {
     const int grid = persistent_grid(N, 64, occ_blocks<edge_gate_fwd_k<HH>>());
     const int64_t npb = ceil_div64(N, grid);
-    hipLaunchKernelGGL(edge_gate_fwd_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, stat_e, P, isrc, in_ptr, e_out, hf, inv_f, npb);
+    if (e_in)
+      hipLaunchKernelGGL((edge_gate_fwd_k<HH, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, stat_e, P, isrc, in_ptr, e_out, hf, inv_f, npb);
+    else
+      hipLaunchKernelGGL((edge_gate_fwd_k<HH, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, stat_e, P, isrc, in_ptr, e_out, hf, inv_f, npb);
   });
   GNM_LAUNCH_CHECK("edge_gate_fwd");
   return 0;
@@ -499,9 +506,13 @@ extern "C" int gnm_node_agg_src_fwd(int64_t N, int64_t E, int H, const float* e_
 
 extern "C" int gnm_node_update_fwd(int64_t N, int H, const float* z, const float* stat_h,
                                    const float* h_in, float* h_out, void* stream) {
-  GNM_CHECK_ARG(N >= 0 && z && stat_h && h_in && h_out, "node_update_fwd: null/neg argument");
-  GNM_DISPATCH_H(H, hipLaunchKernelGGL(node_update_fwd_k<HH>, dim3(ew_grid(N * (HH / 4))), dim3(kBlock),
-                                       0, (hipStream_t)stream, N, z, stat_h, h_in, h_out));
+  GNM_CHECK_ARG(N >= 0 && z && stat_h && h_out, "node_update_fwd: null/neg argument");   // h_in == NULL: no residual
+  GNM_DISPATCH_H(H, {
+    if (h_in)
+      hipLaunchKernelGGL((node_update_fwd_k<HH, true>), dim3(ew_grid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, stat_h, h_in, h_out);
+    else
+      hipLaunchKernelGGL((node_update_fwd_k<HH, false>), dim3(ew_grid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, stat_h, h_in, h_out);
+  });
   GNM_LAUNCH_CHECK("node_update_fwd");
   return 0;
 }

@@ -32,7 +32,7 @@ __device__ __forceinline__ float4 row_normalize(float4 x, float& rstd) {
 }
 
 // e_out = relu(LN(t)) + e_in ; sigma = sigmoid(e_out) ; by-destination gated mean   (:122-130)
-template <int H>
+template <int H, bool RES = true>
 __global__ __launch_bounds__(kBlock) void ln_edge_gate_fwd_k(
     int64_t N, const float* __restrict__ t, const float* __restrict__ e_in, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ P, const int32_t* __restrict__ isrc,
@@ -53,7 +53,9 @@ __global__ __launch_bounds__(kBlock) void ln_edge_gate_fwd_k(
       const int64_t s = isrc[j];
       float rstd;
       const float4 th = row_normalize<H>(ld4_nt(t + j * H + c4), rstd);
-      const float4 eo = relu4(fma4(th, ga, be)) + ld4_nt(e_in + j * H + c4);
+      float4 er_ = f4(0.f);
+      if constexpr (RES) er_ = ld4_nt(e_in + j * H + c4);
+      const float4 eo = relu4(fma4(th, ga, be)) + er_;
       st4_nt(e_out + j * H + c4, eo);
       const float4 sg = sigmoid4(eo);
       num = fma4(sg, ld4(P + s * (5 * H) + H + c4), num);
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void ln_edge_gate_fwd_k(
 }
 
 // h_out = relu(LN(z)) + h_in                                                        (:147-152)
-template <int H>
+template <int H, bool RES = true>
 __global__ __launch_bounds__(kBlock) void ln_node_update_fwd_k(int64_t N, const float* __restrict__ z,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(kBlock) void ln_node_update_fwd_k(int64_t N, const 
     const int64_t o = (i / G) * H + c4;
     float rstd;
     const float4 zh = row_normalize<H>(ld4(z + o), rstd);
-    st4(h_out + o, relu4(fma4(zh, ld4(gamma + c4), ld4(beta + c4))) + ld4(h_in + o));
+    float4 hr_ = f4(0.f);
+    if constexpr (RES) hr_ = ld4(h_in + o);
+    st4(h_out + o, relu4(fma4(zh, ld4(gamma + c4), ld4(beta + c4))) + hr_);
   }
 }
 
@@ -253,12 +257,16 @@ extern "C" int gnm_ln_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t,
                                     const float* gamma, const float* beta, const float* P,
                                     const int32_t* isrc, const int32_t* in_ptr, float* e_out, float* hf,
                                     float* inv_f, void* stream) {
-  GNM_CHECK_ARG(N >= 0 && E >= 0 && t && e_in && gamma && beta && P && isrc && in_ptr && e_out && hf && inv_f,
-                "ln_edge_gate_fwd: null/neg argument");
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && t && gamma && beta && P && isrc && in_ptr && e_out && hf && inv_f,
+                "ln_edge_gate_fwd: null/neg argument");      // e_in == NULL: no residual
   GNM_DISPATCH_H(H, {
     const int grid = persistent_grid(N, 64, occ_blocks<ln_edge_gate_fwd_k<HH>>());
-    hipLaunchKernelGGL(ln_edge_gate_fwd_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, gamma,
-                       beta, P, isrc, in_ptr, e_out, hf, inv_f, cdivl(N, grid));
+    if (e_in)
+      hipLaunchKernelGGL((ln_edge_gate_fwd_k<HH, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, gamma,
+                         beta, P, isrc, in_ptr, e_out, hf, inv_f, cdivl(N, grid));
+    else
+      hipLaunchKernelGGL((ln_edge_gate_fwd_k<HH, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, gamma,
+                         beta, P, isrc, in_ptr, e_out, hf, inv_f, cdivl(N, grid));
   });
   GNM_LAUNCH_CHECK("ln_edge_gate_fwd");
   return 0;
@@ -266,9 +274,13 @@ extern "C" int gnm_ln_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t,
 
 extern "C" int gnm_ln_node_update_fwd(int64_t N, int H, const float* z, const float* gamma, const float* beta,
                                       const float* h_in, float* h_out, void* stream) {
-  GNM_CHECK_ARG(N >= 0 && z && gamma && beta && h_in && h_out, "ln_node_update_fwd: null/neg argument");
-  GNM_DISPATCH_H(H, hipLaunchKernelGGL(ln_node_update_fwd_k<HH>, dim3(ewgrid(N * (HH / 4))), dim3(kBlock), 0,
-                                       (hipStream_t)stream, N, z, gamma, beta, h_in, h_out));
+  GNM_CHECK_ARG(N >= 0 && z && gamma && beta && h_out, "ln_node_update_fwd: null/neg argument");   // h_in == NULL: no residual
+  GNM_DISPATCH_H(H, {
+    if (h_in)
+      hipLaunchKernelGGL((ln_node_update_fwd_k<HH, true>), dim3(ewgrid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, gamma, beta, h_in, h_out);
+    else
+      hipLaunchKernelGGL((ln_node_update_fwd_k<HH, false>), dim3(ewgrid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, gamma, beta, h_in, h_out);
+  });
   GNM_LAUNCH_CHECK("ln_node_update_fwd");
   return 0;
 }

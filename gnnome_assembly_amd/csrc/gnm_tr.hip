@@ -550,13 +550,12 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     prefetch_rows(0);
     // hipcc merges the vector-memory scoreboard of the loop entry with the back edge's and keeps the weaker
     // guarantee.  Throw-away stores (into this workgroup's slab, rewritten at the end) give the entry the queue a
-    // steady-state iteration leaves behind -- row loads | 1 store | 4 walker stores (waves 0-5) | 6 gathers -- so that phase 0
+    // steady-state iteration leaves behind -- row loads | 1 store | 4 walk stores (EVERY wave: waves 6, 7 store to their dummy
+    // line, else the merged scoreboard makes the walkers wait for their own stores) | 6 gathers -- so that phase 0
     // waits with a COUNTED vmcnt for the row loads only and the gathers / stores stay in flight.
     st4(dummy_row, f4(0.f));
-    if (walker) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st4(dummy_w, f4(0.f));
-    }
+    for (int r = 0; r < 4; ++r) st4(dummy_w + r * 16 * SW, f4(0.f));     // four ADDRESSES: hipcc folds repeated stores to one
     gather(s0, d0);
   }
   for (int64_t k = 0; k < ntile; ++k) {
@@ -648,6 +647,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     }
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
     // ---- column walk (waves 0-5) and BatchNorm sums (waves 6, 7) ----
+    float4 wv0 = f4(0.f), wv1 = f4(0.f), wv2 = f4(0.f), wv3 = f4(0.f);      // what the walk stores, and where (default: the
+    float *wp0 = dummy_w, *wp1 = dummy_w, *wp2 = dummy_w, *wp3 = dummy_w;   //  thread's dummy line)
     if (!(ABL & 1) && walker) {
       const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4 + (4 * wgrp) * SW;
       const int* dk = sdk + ER + 4 * wgrp;
@@ -677,11 +678,14 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         I = fma4(cin, open, s3);
       }
       // every segment is stored once, from its last row
-      float* const o0 = wout + (int64_t)d0 * wpitch;
-      st4(d1 != d0 ? o0 : dummy_w, x0 + cin);
-      st4(d2 != d1 ? wout + (int64_t)d1 * wpitch : dummy_w, fma4(cin, f4(d1 == d0 ? 1.f : 0.f), s1));
-      st4(d3 != d2 ? wout + (int64_t)d2 * wpitch : dummy_w, fma4(cin, f4(d2 == d0 ? 1.f : 0.f), s2));
-      st4(d4 != d3 ? wout + (int64_t)d3 * wpitch : dummy_w, I);
+      if (d1 != d0) wp0 = wout + (int64_t)d0 * wpitch;
+      if (d2 != d1) wp1 = wout + (int64_t)d1 * wpitch;
+      if (d3 != d2) wp2 = wout + (int64_t)d2 * wpitch;
+      if (d4 != d3) wp3 = wout + (int64_t)d3 * wpitch;
+      wv0 = x0 + cin;
+      wv1 = fma4(cin, f4(d1 == d0 ? 1.f : 0.f), s1);
+      wv2 = fma4(cin, f4(d2 == d0 ? 1.f : 0.f), s2);
+      wv3 = I;
       // the tile's last row -> the next tile's group 0
       const int sl_ = 48 + (lane & 15);
       carry = make_float4(__shfl(I.x, sl_, 64), __shfl(I.y, sl_, 64), __shfl(I.z, sl_, 64), __shfl(I.w, sl_, 64));
@@ -699,6 +703,10 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       s_gu[0] += (double)ga_.x; s_gu[1] += (double)ga_.y; s_gu[2] += (double)ga_.z; s_gu[3] += (double)ga_.w;
       s_gut[0] += (double)gb_.x; s_gut[1] += (double)gb_.y; s_gut[2] += (double)gb_.z; s_gut[3] += (double)gb_.w;
     }
+    st4(wp0, wv0);      // outside every branch: the same four stores on every path keep hipcc's vmcnt waits counted
+    st4(wp1, wv1);
+    st4(wp2, wv2);
+    st4(wp3, wv3);
     {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);

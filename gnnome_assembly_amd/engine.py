@@ -298,14 +298,15 @@ class LayerSaved:
 
 def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
     """P = h W5^T + b5 [N,5H] and t = e W3^T + b3 + B1h[src] + B2h[dst] [E,H] (gated_gcn_full.py:107-113,120-121);
-    leaves the BatchNorm partial sums of t in the scratch buffer and their count in nblk."""
+    leaves the BatchNorm partial sums of t in the scratch buffer and their count in nblk.  H is the layer's OUTPUT
+    width; h_in / e_in may be narrower or wider (in_channels != out_channels: the generic GEMM route)."""
     lib = _lib.load()
     dev = h_in.device
     sc = scratch(dev)
     st = _stream()
     P = torch.empty(N, 5 * H, dtype=torch.float32, device=dev)
     t = torch.empty(E, H, dtype=torch.float32, device=dev)
-    if H == 128 and FUSED:
+    if H == 128 and FUSED and h_in.shape[1] == H:
         # W-stationary fused MFMA path: projections, then t + BatchNorm partials in one pass
         need = lib.gnm_rowtile_workspace_bytes(5 * H)
         ws = sc.ws(need)
@@ -323,9 +324,15 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
 
 
 @on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
-def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True):
+def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True,
+                  residual: bool = True):
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
-    Returns (h_out, e_out, LayerSaved or None)."""
+    Returns (h_out, e_out, LayerSaved or None).  H = out_channels; h_in [N,Hin], e_in [E,Hin] with Hin != H only
+    when residual is False (the reference drops the residual then: gated_gcn_full.py:41-42)."""
+    if residual and h_in.shape[1] != H:
+        raise _lib.GnmError("layer_forward: a residual layer needs in_channels == out_channels")
+    res_e = _ptr(e_in) if residual else C.c_void_p(0)
+    res_h = _ptr(h_in) if residual else C.c_void_p(0)
     lib = _lib.load()
     dev = h_in.device
     sc = scratch(dev)
@@ -339,11 +346,11 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     inv_f = torch.empty(N, H, **f32)
     if batch_norm:
         stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
-        _call("gnm_edge_gate_fwd", N, E, H, _ptr(t), _ptr(e_in), _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
+        _call("gnm_edge_gate_fwd", N, E, H, _ptr(t), res_e, _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
               _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
     else:       # LayerNorm: row statistics inside the kernel, no barrier
         stat_e = None
-        _call("gnm_ln_edge_gate_fwd", N, E, H, _ptr(t), _ptr(e_in), _ptr(prm.gamma_e), _ptr(prm.beta_e), _ptr(P),
+        _call("gnm_ln_edge_gate_fwd", N, E, H, _ptr(t), res_e, _ptr(prm.gamma_e), _ptr(prm.beta_e), _ptr(P),
               _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
     # by-source gated mean on the same gate, z, BatchNorm statistics over N (:133-147)
     hb = torch.empty(N, H, **f32)
@@ -355,10 +362,10 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     h_out = torch.empty(N, H, **f32)
     if batch_norm:
         stat_h = bn_finalize(sc.partials, nblk.value, N, H, prm.gamma_h, prm.beta_h)
-        _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), _ptr(h_in), _ptr(h_out), st)
+        _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), res_h, _ptr(h_out), st)
     else:
         stat_h = None
-        _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(h_in), _ptr(h_out), st)
+        _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), res_h, _ptr(h_out), st)
     saved = None
     if save:
         lean = ACTIVATIONS == "lean"
@@ -369,12 +376,15 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
 
 @on_device_of(lambda idx, N, E, H, prm, s, gh_out, *a, **k: gh_out)
 def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True,
-                   out: Optional[Dict[str, torch.Tensor]] = None):
+                   out: Optional[Dict[str, torch.Tensor]] = None, residual: bool = True):
     """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
-    and is OVERWRITTEN with d loss / d e_in.  Returns (gh_in, ge, grads dict).  `out` (optional) names the tensors
+    and is OVERWRITTEN with d loss / d e_in (residual layers; without the residual the returned ge is a fresh [E,Hin]
+    tensor).  Returns (gh_in, ge, grads dict).  `out` (optional) names the tensors
     the parameter gradients are written INTO (keys W5 b5 W3 b3 gamma_e beta_e gamma_h beta_h; contiguous blocks,
     e.g. views of a flat gradient buffer) instead of fresh allocations."""
     out = out or {}
+    Hin = s.h_in.shape[1]
+    fused = H == 128 and FUSED and residual          # the fused backward kernels have the residual adds built in
     new = lambda key, *shape: out[key] if key in out else torch.empty(*shape, dtype=torch.float32, device=gh_out.device)  # noqa: E731
     lib = _lib.load()
     dev = gh_out.device
@@ -387,7 +397,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         s.P, s.t = _proj_and_t(idx, N, E, H, prm, s.h_in, s.e_in, C.c_int(0))
     gP = torch.empty(N, 5 * H, **f32)
     Q = torch.empty(N, (2 if batch_norm else 4) * H, **f32)     # BatchNorm mode: Qf | Qb; LayerNorm mode keeps Rf, Rb too
-    g["W3"] = new("W3", H, H)
+    g["W3"] = new("W3", H, Hin)
     if not batch_norm:
         # ---- LayerNorm mode: no global barriers, gt is produced by the by-destination pass ----
         _call("gnm_ln_node_bwd", N, H, _ptr(s.z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(gh_out), _ptr(s.hf),
@@ -402,7 +412,10 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
         del Q
         g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
-        gemm(NN, gt, prm.W3, ge, resid=ge)
+        if residual:
+            gemm(NN, gt, prm.W3, ge, resid=ge)
+        else:
+            ge = gemm(NN, gt, prm.W3, torch.empty(E, Hin, **f32))
         del gt
     else:
         # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
@@ -424,7 +437,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), 0, st)
         del Ud, Td, Q
         # gt, B_3 gradients, ge_in = ge_tot + gt W3
-        if H == 128 and FUSED:
+        if fused:
             g["b3"] = new("b3", H)
             need = lib.gnm_edge_bwd_fused_workspace_bytes()
             ws = sc.ws(need)
@@ -435,12 +448,15 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(gt), st)
             g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
-            gemm(NN, gt, prm.W3, ge, resid=ge)
+            if residual:
+                gemm(NN, gt, prm.W3, ge, resid=ge)
+            else:
+                ge = gemm(NN, gt, prm.W3, torch.empty(E, Hin, **f32))
             del gt
     # node projections backward
-    g["W5"] = new("W5", 5 * H, H)
-    gh_in = torch.empty(N, H, **f32)
-    if H == 128 and FUSED:
+    g["W5"] = new("W5", 5 * H, Hin)
+    gh_in = torch.empty(N, Hin, **f32)
+    if fused:
         g["b5"] = new("b5", 5 * H)
         need = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
         ws = sc.ws(need)
@@ -449,7 +465,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               _ptr(sc.partials), _ptr(ws), need, 0, st)
     else:
         g["b5"] = gemm_tn_colsum(gP, s.h_in, g["W5"], out.get("b5"))
-        gemm(NN, gP, prm.W5, gh_in, resid=gh_out)
+        gemm(NN, gP, prm.W5, gh_in, resid=gh_out if residual else None)
     return gh_in, ge, g
 
 

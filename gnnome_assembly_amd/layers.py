@@ -20,17 +20,17 @@ class _LayerFn(torch.autograd.Function):
     """One GatedGCN_1d.forward with edge-id-order e at the boundary."""
 
     @staticmethod
-    def forward(ctx, graph, need, batch_norm, h, e, *flat):
+    def forward(ctx, graph, need, batch_norm, residual, h, e, *flat):
         names = _LAYER_KEYS
         P = {"gnn.convs.0." + k: v for k, v in zip(names, flat)}
         idx = graph.index(h.device)
-        N, E, H = graph.num_nodes(), graph.num_edges(), h.shape[1]
+        N, E, H = graph.num_nodes(), graph.num_edges(), flat[0].shape[0]        # H = out_channels (A_1.weight is [out, in])
         perm = idx["perm"].long()
         e_int = e.detach().index_select(0, perm).contiguous()
         prm = engine.layer_params(P, 0)
         h_int = engine.node_rows_in(idx, engine._f32c(h.detach()))       # caller's node numbering -> internal (graph.py)
-        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h_int, e_int, need, batch_norm)
-        ctx.graph, ctx.saved, ctx.P, ctx.dims, ctx.bn = graph, saved, P, (N, E, H), batch_norm
+        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h_int, e_int, need, batch_norm, residual)
+        ctx.graph, ctx.saved, ctx.P, ctx.dims, ctx.bn, ctx.res = graph, saved, P, (N, E, H), batch_norm, residual
         out_e = torch.empty_like(e_out)
         out_e.index_copy_(0, perm, e_out)
         return engine.node_rows_out(idx, h_out), out_e
@@ -45,7 +45,8 @@ class _LayerFn(torch.autograd.Function):
         prm = engine.layer_params(ctx.P, 0)
         ge = ge_out.index_select(0, perm).contiguous()        # fresh buffer, overwritten below
         gh_in, ge_in, g = engine.layer_backward(idx, N, E, H, prm, ctx.saved,
-                                                engine.node_rows_in(idx, engine._f32c(gh_out)), ge, ctx.bn)
+                                                engine.node_rows_in(idx, engine._f32c(gh_out)), ge, ctx.bn,
+                                                residual=ctx.res)
         gh_in = engine.node_rows_out(idx, gh_in)
         ctx.saved = None
         ge_user = torch.empty_like(ge_in)
@@ -54,7 +55,7 @@ class _LayerFn(torch.autograd.Function):
         for j, k in enumerate(engine.LIN5):
             grads += [g["W5"][j * H:(j + 1) * H], g["b5"][j * H:(j + 1) * H]]
         grads += [g["W3"], g["b3"], g["gamma_h"], g["beta_h"], g["gamma_e"], g["beta_e"]]
-        return (None, None, None, gh_in, ge_user) + tuple(grads)
+        return (None, None, None, None, gh_in, ge_user) + tuple(grads)
 
 
 _LAYER_KEYS = tuple(f"{k}.{w}" for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3") for w in ("weight", "bias")) + \
@@ -78,19 +79,15 @@ class GatedGCN_1d(nn.Module):
 
     def __init__(self, in_channels, out_channels, batch_norm, dropout=0, residual=True):
         super().__init__()
-        if in_channels != out_channels:
-            # the reference silently drops the residual (gated_gcn_full.py:41-42); the model never
-            # builds such a layer (processor.py:11-12) and the HIP path does not implement it.
-            raise NotImplementedError("GatedGCN_1d: in_channels != out_channels is outside the hot path")
         if not 0 <= dropout < 1:
             raise ValueError(f"GatedGCN_1d: dropout={dropout}")
-        if not residual:
-            # the kernels always add h_in / e_in (gated_gcn_full.py:149-152 with residual=True, the only
-            # value the model passes, processor.py:11-12): refuse rather than return a silently different result
-            raise NotImplementedError("GatedGCN_1d: residual=False is outside the hot path")
+        if out_channels not in (32, 64, 128, 256):
+            raise NotImplementedError(f"GatedGCN_1d: out_channels={out_channels}: the HIP kernels are built for 32, 64, 128, 256")
         self.dropout = dropout
         self.batch_norm = batch_norm
-        self.residual = residual
+        # gated_gcn_full.py:41-42: a layer that changes the width silently drops the residual.  The model never builds
+        # such a layer (processor.py:11-12); it runs on the generic GEMM route instead of the fused H = 128 kernels.
+        self.residual = bool(residual) and in_channels == out_channels
         for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3"):     # creation order = the reference's
             setattr(self, k, nn.Linear(in_channels, out_channels))
         self.bn_h = _Norm(out_channels)
@@ -100,7 +97,7 @@ class GatedGCN_1d(nn.Module):
         P = dict(self.named_parameters())
         flat = [P[k] for k in _LAYER_KEYS]
         need = torch.is_grad_enabled() and any(t.requires_grad for t in [h, e] + flat)
-        h, e = _LayerFn.apply(g, need, bool(self.batch_norm), h, e, *flat)
+        h, e = _LayerFn.apply(g, need, bool(self.batch_norm), self.residual, h, e, *flat)
         if self.dropout and self.training:
             # gated_gcn_full.py:154: dropout on the node output only, after the residual.  Never enabled by the model
             # (processor.py:12 passes no dropout), so it is not fused: the mask comes from torch's generator on h's device

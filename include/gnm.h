@@ -147,7 +147,9 @@ int gnm_bn_bwd_finalize(const double* partials, int nblk, int64_t count, int H,
  *               (sum t, sum t^2) -> partials.                                   (:120-121) */
 int gnm_edge_t_stats_fwd(int64_t E, int H, float* t, const float* P, const int32_t* isrc,
                          const int32_t* idst, double* partials, int* nblk_out, void* stream);
-/* edge_gate: e_out = relu(t*scale+shift) + e_in; sigma = sigmoid(e_out);
+/* (e_in == NULL / h_in == NULL in the four forward kernels below and their LayerNorm twins: no residual --
+ *  GatedGCN_1d(residual=False), or in_channels != out_channels which drops it: gated_gcn_full.py:41-42,124-125,151-152)
+ * edge_gate: e_out = relu(t*scale+shift) + e_in; sigma = sigmoid(e_out);
  *            hf[v] = sum_{in(v)} sigma*A2h[src] / (sum sigma + 1e-6); inv_f = 1/(sum sigma + 1e-6)
  *                                                                      (:122-130) */
 int gnm_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in,

@@ -71,7 +71,7 @@ def layer_forward(sd, i, src, dst, n, h, e, batch_norm=True, residual=True):
     if residual:
         e_out = e_out + e                                                  # :124-125
     sig = torch.sigmoid(e_out)                                             # :127
-    z0 = torch.zeros((n, h.shape[1]), dtype=h.dtype)
+    z0 = torch.zeros((n, A2h.shape[1]), dtype=h.dtype)                     # out_channels wide (in != out: :41-42)
     f_num = z0.index_add(0, dst, sig * A2h.index_select(0, src))           # :128
     f_den = z0.index_add(0, dst, sig)                                      # :129
     b_num = z0.index_add(0, src, sig * A3h.index_select(0, dst))           # :141

@@ -109,3 +109,40 @@ def branch_exact_rows(src, dst, n, e_raw, pe, y, pw, sd, L, dev):
     return rows, gmax
 
 
+
+
+# -----------------------------------------------------------------------------------------
+# stand-alone GatedGCN_1d variants (residual=False, in_channels != out_channels): inputs and parameters are drawn
+# from seeded numpy streams here -- shared by tests/golden/make_golden_layer.py (which runs the REFERENCE layer on
+# them) and by the tests -- so the fixture only stores the reference's outputs
+# -----------------------------------------------------------------------------------------
+LAYER_VARIANTS = {                # name: (in_channels, out_channels, batch_norm, residual argument)
+    "in48_out32_bn": (48, 32, True, True),
+    "in32_out32_bn_nores": (32, 32, True, False),
+    "in128_out128_bn_nores": (128, 128, True, False),
+    "in16_out32_ln": (16, 32, False, True),
+    "in32_out32_ln_nores": (32, 32, False, False),
+}
+
+
+def layer_variant_case(name):
+    """graph (src, dst, n), fp32 inputs h0 [N,in], e0 [E,in], functional weights wh [N,out], we [E,out] and the layer's
+    state_dict (fp32 numpy, the reference's keys) for one variant."""
+    cin, cout, bn, res = LAYER_VARIANTS[name]
+    src, dst, n = synth.make_graph(60, seed=9, permute_edge_ids=True)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    E = src.size
+    f32 = lambda a: a.astype(np.float32)  # noqa: E731
+    case = dict(src=src, dst=dst, n=n, cin=cin, cout=cout, bn=bn, res=res,
+                h0=f32(rng.standard_normal((n, cin))), e0=f32(rng.standard_normal((E, cin))),
+                wh=f32(rng.standard_normal((n, cout))), we=f32(rng.standard_normal((E, cout))))
+    sd = {}
+    b = 1.0 / np.sqrt(cin)
+    for k in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3"):
+        sd[k + ".weight"] = f32(rng.uniform(-b, b, size=(cout, cin)))
+        sd[k + ".bias"] = f32(rng.uniform(-b, b, size=(cout,)))
+    for k in ("bn_h", "bn_e"):
+        sd[k + ".weight"] = f32(rng.uniform(0.5, 1.5, size=cout))
+        sd[k + ".bias"] = f32(rng.uniform(-0.3, 0.3, size=cout))
+    case["sd"] = sd
+    return case

@@ -104,3 +104,29 @@ def test_pagerank_pe_matches_reference(golden_dir):
     pe = synth.pagerank_pe(z["src"], z["dst"], int(z["n"]))
     assert np.abs(pe - z["pe"]).max() <= 1e-7 * np.abs(z["pe"]).max()
     assert np.array_equal(np.bincount(z["dst"], minlength=int(z["n"])), z["in_deg"].astype(np.int64))
+
+
+def test_oracle_layer_variants_match_the_reference_layer():
+    """GatedGCN_1d(residual=False) and in_channels != out_channels (which drops the residual, gated_gcn_full.py:41-42,
+    124-125,151-152): the oracle's layer against outputs and gradients of the reference's own layer
+    (tests/golden/make_golden_layer.py), fp64 autograd on both sides (the fixture stores fp32)."""
+    import os
+    from helpers import GOLDEN, LAYER_VARIANTS, layer_variant_case, rel_l2
+    from oracle import gatedgcn_oracle as orc
+    z = np.load(os.path.join(GOLDEN, "layer_variants.npz"))
+    for name, (cin, cout, bn, res) in LAYER_VARIANTS.items():
+        c = layer_variant_case(name)
+        residual = res and cin == cout
+        assert bool(z[f"{name}/residual_used"]) == residual
+        p = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in c["sd"].items()}
+        h = torch.from_numpy(c["h0"]).double().requires_grad_(True)
+        e = torch.from_numpy(c["e0"]).double().requires_grad_(True)
+        h1, e1 = orc.layer_forward(p, None, torch.from_numpy(c["src"]).long(), torch.from_numpy(c["dst"]).long(), c["n"], h, e,
+                                   batch_norm=bn, residual=residual)
+        ((h1 * torch.from_numpy(c["wh"]).double()).sum() + (e1 * torch.from_numpy(c["we"]).double()).sum()).backward()
+        got = {"h1": h1, "e1": e1, "gh": h.grad, "ge": e.grad, **{"g/" + k: v.grad for k, v in p.items()}}
+        for k, v in got.items():
+            want = z[f"{name}/{k}"]
+            assert v.shape == want.shape, (name, k)
+            d = np.abs(v.detach().numpy() - want).max()
+            assert rel_l2(v.detach().numpy(), want) < 1e-6 or d < 1e-6 * max(1.0, np.abs(want).max()), (name, k, d)
