@@ -92,8 +92,11 @@ def test_module_surface_and_state_dict_schema():
     assert G.layers.ScorePredictor(32, 64).W1.weight.shape == (64, 96)
     G.layers.NodeEncoder(1, 8), G.layers.EdgeEncoder(2, 8)
     assert G.layers.GatedGCN_1d(32, 32, False).batch_norm is False     # LayerNorm mode exists
+    wide = G.layers.GatedGCN_1d(32, 64, True)                         # in != out: the residual is dropped (gated_gcn_full.py:41-42)
+    assert wide.residual is False and wide.B_3.weight.shape == (64, 32)
+    assert G.layers.GatedGCN_1d(32, 32, True, residual=False).residual is False
     with pytest.raises(NotImplementedError):
-        G.layers.GatedGCN_1d(32, 64, True)
+        G.layers.GatedGCN_1d(32, 48, True)                             # output widths the kernels are not built for
 
 
 def test_product_path_has_no_cpu_fallback():
