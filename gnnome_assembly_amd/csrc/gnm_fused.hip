@@ -1522,6 +1522,8 @@ static int g_tn_variant = 1;     // split mode: 1 = tn_tr_k (transpose reads), 0
 static int g_eb_variant = 1;     // split mode: 1 = edge_bwd_tr_k (16-row tiles, two workgroups per CU), 0 = edge_bwd_fused_k<MmB3>
 namespace gnm {
 int eb_variant() { return g_eb_variant; }
+static int g_chain_variant = 1;  // chained edge backward: 1 = edge_bwd_chain2_k (matrix / gather roles), 0 = edge_bwd_chain_k (round 2)
+int chain_variant() { return g_chain_variant; }
 static int g_enc_bwd = 1;        // edge encoder backward: 1 = fp32-MFMA kernel, 0 = VALU kernel (round 1)
 int enc_bwd_variant() { return g_enc_bwd; }
 static int g_enc_fwd = 1;        // edge encoder forward: 1 = fp32-MFMA kernel, 0 = VALU kernel
@@ -1530,6 +1532,7 @@ int enc_fwd_variant() { return g_enc_fwd; }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "tn")) { g_tn_variant = v; return 0; }
   if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
+  if (what && !strcmp(what, "chain")) { g_chain_variant = v; return 0; }
   if (what && !strcmp(what, "enc_bwd")) { g_enc_bwd = v; return 0; }
   if (what && !strcmp(what, "enc_fwd")) { g_enc_fwd = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");

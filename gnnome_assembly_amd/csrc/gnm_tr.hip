@@ -375,6 +375,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
 }
 
 int eb_variant();   // gnm_fused.hip
+int chain_variant();
 size_t edge_bwd_tr_pack_bytes() { return (size_t)(SW / 16) * (SW / 32) * 3 * 64 * sizeof(bf16x8); }
 // returns the grid size (= number of slabs / partial rows written)
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
@@ -418,6 +419,7 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
 // four row streams AND the six gathered node rows of the NEXT tile are requested a tile ahead, so that no phase
 // waits on memory (the eight waves share every barrier, there is no second workgroup to hide a wait).
 constexpr int CT = 512;                    // threads per workgroup
+constexpr int WG_ = 4;                     // rows per LDS read group of the column walk (8 and 16 measured the same)
 constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 5 * ER * SW * 4 + 3 * 2 * ER * 4;
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
@@ -477,30 +479,26 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   const int trq0 = simg_tr_base(lane, 0), trq1 = simg_tr_base(lane, 1);   // transpose-read bases (gnm_tr.h)
   const int ni = lane & 15, ng = lane >> 4;
   const int nnb = ni * SPITCH + ((((ni & 3) << 2) | (ng ^ (swz(ni) & 3))) << 4);
-  // Column walk (per-destination sums gA3h / Td / Ud of layer i-1), waves 0-5: role = wave >> 1 (0 sums sigma*Qb -> gA3h,
-  // 1 that -> Td, 2 gu -> Ud); a wave covers 64 columns (wave & 1) x the tile's FOUR ROW GROUPS (grp = lane >> 4: rows
-  // 4 grp .. 4 grp + 3, one float4 of columns per lane).  Round 2 walked the 16 rows as ONE dependent chain on 96
-  // threads (2100 cycles of a 7650-cycle tile, every other wave waiting at the next barrier); now a lane chains over 4
-  // rows, and the carry from the groups before it (and from the tile before: `carry` / `cur`) arrives through three
-  // wave-local shuffle rounds -- no barrier, no LDS round trip.  A segment is stored ONCE, by the lane that owns its last
-  // row (destination-sorted rows: the next row's node differs; the next tile's first node is already in the index ring),
-  // through an address select against a per-thread dummy line: still no data-dependent branch around a memory operation.
-  // The BatchNorm column sums of layer i-1 (sum gu, sum gu*that) are taken beside the walk by waves 6 and 7: four rows per
-  // thread summed in fp32, then added to the thread's fp64 accumulators (one conversion per tile instead of per row).
-  const bool walker = wave < 6, bnsum = wave >= 6;
-  const int role = wave >> 1;
-  const int wgrp = lane >> 4;
-  const int wc4 = walker ? ((((wave & 1) << 4) | (lane & 15)) * 4) : (tid & 31) * 4;
-  const int brow = 4 * ((tid >> 5) & 3);    // BatchNorm sums: rows brow .. brow + 3 of a tile
-  int cur = -1;                             // destination node of the previous tile's last row
-  float4 carry = f4(0.f);                   // running sum of that node's segment at the end of the previous tile
+  // column walkers: column wcol; role 0 sums sigma*Qb (-> gA3h), 1 that (-> Td), 2 gu (-> Ud), 3 the BatchNorm column
+  // sums of layer i-1 (sum gu, sum gu*that, fp64)
+  // column walkers: threads 0-95 (waves 0 and 1), one float4 of columns each; role = tid >> 5: 0 sums sigma*Qb
+  // (-> gA3h), 1 that (-> Td), 2 gu (-> Ud).  The BatchNorm column sums of layer i-1 (sum gu, sum gu*that, fp64:
+  // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
+  const bool walker = tid < 96, bnsum = (tid & 128) != 0;      // BatchNorm sums: waves 2, 3, 6, 7, two rows of a tile each
+  const int role = (tid >> 5) & 3, wc4 = (tid & 31) * 4;
+  const int brow = 2 * (((tid >> 8) << 2) | ((tid >> 5) & 3));   // first of this thread's two rows (0, 2, .. 14)
+  int cur = -1;                             // node whose segment is being summed (wave-uniform)
+  float4 acc0 = f4(0.f);
   double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};
+  // Every walker step STORES the running sum to its node's output row (the last store of a segment holds the
+  // whole sum; a node's ~5 stores meet in L2): no data-dependent branch around a memory operation, so hipcc keeps
+  // COUNTED vmcnt waits for the prefetched rows (a store under such a branch costs vmcnt(0) = a full drain of the
+  // software pipeline on every tile).  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
   float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
   const int64_t wpitch = role == 0 ? 5 * SW : SW;
   // target of the throw-away stores (rows past the chunk, scoreboard equalisation): a slab of its own BEHIND the
   // gridDim.x slabs that carry results -- a late throw-away store must never meet this workgroup's final slab store
   float* const dummy_row = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + lc4;
-  float* const dummy_w = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + (size_t)(32 + (tid >> 5)) * SW + (tid & 31) * 4;   // walkers' own line
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
@@ -550,12 +548,13 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     prefetch_rows(0);
     // hipcc merges the vector-memory scoreboard of the loop entry with the back edge's and keeps the weaker
     // guarantee.  Throw-away stores (into this workgroup's slab, rewritten at the end) give the entry the queue a
-    // steady-state iteration leaves behind -- row loads | 1 store | 4 walk stores (EVERY wave: waves 6, 7 store to their dummy
-    // line, else the merged scoreboard makes the walkers wait for their own stores) | 6 gathers -- so that phase 0
+    // steady-state iteration leaves behind -- row loads | 1 store | 16 walker stores (threads 0-95) | 6 gathers -- so that phase 0
     // waits with a COUNTED vmcnt for the row loads only and the gathers / stores stay in flight.
     st4(dummy_row, f4(0.f));
+    if (walker) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st4(dummy_w + r * 16 * SW, f4(0.f));     // four ADDRESSES: hipcc folds repeated stores to one
+      for (int r = 0; r < ER; ++r) st4(dummy_row + SW * (1 + r), f4(0.f));
+    }
     gather(s0, d0);
   }
   for (int64_t k = 0; k < ntile; ++k) {
@@ -646,67 +645,41 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
     }
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
-    // ---- column walk (waves 0-5) and BatchNorm sums (waves 6, 7) ----
-    float4 wv0 = f4(0.f), wv1 = f4(0.f), wv2 = f4(0.f), wv3 = f4(0.f);      // what the walk stores, and where (default: the
-    float *wp0 = dummy_w, *wp1 = dummy_w, *wp2 = dummy_w, *wp3 = dummy_w;   //  thread's dummy line)
+    // ---- column walkers (waves 0 and 1) and BatchNorm sums (waves 2 and 3); the rest go on to the next phase 0 ----
     if (!(ABL & 1) && walker) {
-      const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4 + (4 * wgrp) * SW;
-      const int* dk = sdk + ER + 4 * wgrp;
-      const int d0 = dk[0], d1 = dk[1], d2 = dk[2], d3 = dk[3];
-      // node of the row AFTER this group: the next group's first row, or (last group) the next tile's first row, which
-      // phase 0 put into the ring before this tile's first barrier; the chunk's last tile closes every segment
-      const int dnx = sd[(int)((k + 1) % 3) * 2 * ER + ER];
-      const int d4 = wgrp == 3 ? (k == klast ? -1 : dnx) : sdk[ER + (4 * wgrp + 4 < ER ? 4 * wgrp + 4 : ER - 1)];
-      const float4 x0 = ld4(vsrc), x1 = ld4(vsrc + SW), x2 = ld4(vsrc + 2 * SW), x3 = ld4(vsrc + 3 * SW);
-      // running sums inside the group (a new segment multiplies the running sum by 0; rows past the chunk hold zeros
-      // and repeat the last row's node: they extend its segment by nothing)
-      const float4 s1 = fma4(x0, f4(d1 == d0 ? 1.f : 0.f), x1);
-      const float4 s2 = fma4(s1, f4(d2 == d1 ? 1.f : 0.f), x2);
-      const float4 s3 = fma4(s2, f4(d3 == d2 ? 1.f : 0.f), x3);
-      // carry into the group's first segment: I(g) = s3(g) + [group g is one segment] * cin(g),
-      // cin(g) = [d0(g) == d3(g-1)] * I(g-1), I(-1) = the previous tile's I(3).  Round r makes group r final (a group
-      // recomputed in a later round sees the same, final, neighbour).
-      const int dlp_ = __shfl_up(d3, 16, 64);
-      const float link = d0 == (wgrp == 0 ? cur : dlp_) ? 1.f : 0.f;
-      const float4 open = f4(d0 == d3 ? 1.f : 0.f);
-      float4 cin = carry * link;
-      float4 I = fma4(cin, open, s3);
+      // The 16-step chain is the critical path of this phase (the other waves wait for it at the next barrier), so a
+      // step is kept to two packed FMAs and a store: the destination node is wave-uniform (scalar compare, scalar
+      // part of the address), a new segment multiplies the running sum by 0 instead of selecting, and rows past
+      // the chunk were zeroed when they were written.
+      const float* vsrc = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4;
 #pragma unroll
-      for (int r = 1; r < 4; ++r) {
-        const float4 Ip = make_float4(__shfl_up(I.x, 16, 64), __shfl_up(I.y, 16, 64), __shfl_up(I.z, 16, 64), __shfl_up(I.w, 16, 64));
-        if (wgrp != 0) cin = Ip * link;           // (a select: group 0 keeps the tile carry)
-        I = fma4(cin, open, s3);
+      for (int r4 = 0; r4 < ER; r4 += WG_) {        // WG_ rows' LDS reads up front, then the dependent chain
+        int dn[WG_];
+        float4 xs[WG_];
+#pragma unroll
+        for (int q = 0; q < WG_; ++q) {
+          dn[q] = __builtin_amdgcn_readfirstlane(sdk[ER + r4 + q]);
+          xs[q] = ld4(vsrc + (r4 + q) * SW);
+        }
+#pragma unroll
+        for (int q = 0; q < WG_; ++q) {
+          const float keep = dn[q] == cur ? 1.f : 0.f;
+          acc0 = fma4(acc0, f4(keep), xs[q]);
+          cur = dn[q];
+          st4(wout + (int64_t)cur * wpitch, acc0);
+        }
       }
-      // every segment is stored once, from its last row
-      if (d1 != d0) wp0 = wout + (int64_t)d0 * wpitch;
-      if (d2 != d1) wp1 = wout + (int64_t)d1 * wpitch;
-      if (d3 != d2) wp2 = wout + (int64_t)d2 * wpitch;
-      if (d4 != d3) wp3 = wout + (int64_t)d3 * wpitch;
-      wv0 = x0 + cin;
-      wv1 = fma4(cin, f4(d1 == d0 ? 1.f : 0.f), s1);
-      wv2 = fma4(cin, f4(d2 == d0 ? 1.f : 0.f), s2);
-      wv3 = I;
-      // the tile's last row -> the next tile's group 0
-      const int sl_ = 48 + (lane & 15);
-      carry = make_float4(__shfl(I.x, sl_, 64), __shfl(I.y, sl_, 64), __shfl(I.z, sl_, 64), __shfl(I.w, sl_, 64));
-      cur = sdk[ER + ER - 1];
     }
-    if (!(ABL & 1) && bnsum) {                       // LDS reads, fp32 over four rows, then fp64 (rows past the chunk hold zeros)
-      float4 ga_ = f4(0.f), gb_ = f4(0.f);
+    if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only (rows past the chunk hold zeros)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 2; ++q) {
         const float4 x = ld4(v2 + (brow + q) * SW + wc4);
         const float4 th = ld4(v3 + (brow + q) * SW + wc4);
-        ga_ += x;
-        gb_ = fma4(x, th, gb_);
+        s_gu[0] += (double)x.x; s_gu[1] += (double)x.y; s_gu[2] += (double)x.z; s_gu[3] += (double)x.w;
+        s_gut[0] += (double)x.x * (double)th.x; s_gut[1] += (double)x.y * (double)th.y;
+        s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
       }
-      s_gu[0] += (double)ga_.x; s_gu[1] += (double)ga_.y; s_gu[2] += (double)ga_.z; s_gu[3] += (double)ga_.w;
-      s_gut[0] += (double)gb_.x; s_gut[1] += (double)gb_.y; s_gut[2] += (double)gb_.z; s_gut[3] += (double)gb_.w;
     }
-    st4(wp0, wv0);      // outside every branch: the same four stores on every path keep hipcc's vmcnt waits counted
-    st4(wp1, wv1);
-    st4(wp2, wv2);
-    st4(wp3, wv3);
     {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
@@ -725,10 +698,10 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       sl[m * SW + wc * 32 + li] = tn[x][e];
     }
   __syncthreads();
-  {   // BatchNorm column sums of layer i-1: four row groups (waves 6, 7) -> one row of partials_lo
-    double* bnr = reinterpret_cast<double*>(lds);      // [4 groups][2][128] doubles = 8 KB (the images are dead)
+  {   // BatchNorm column sums of layer i-1: eight row-pair groups (waves 2, 3, 6, 7) -> one row of partials_lo
+    double* bnr = reinterpret_cast<double*>(lds);      // [8 groups][2][128] doubles = 16 KB (the images are dead)
     if (bnsum) {
-      const int grp = brow >> 2;
+      const int grp = brow >> 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bnr[(grp * 2 + 0) * SW + wc4 + j] = s_gu[j];
@@ -739,7 +712,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     if (tid < 2 * SW) {
       double s_ = 0.0;
 #pragma unroll
-      for (int g8 = 0; g8 < 4; ++g8) s_ += bnr[g8 * 2 * SW + tid];
+      for (int g8 = 0; g8 < 8; ++g8) s_ += bnr[g8 * 2 * SW + tid];
       a.partials_lo[(size_t)chunk * 2 * SW + tid] = s_;
     }
     __syncthreads();
@@ -754,6 +727,389 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     double s_ = 0.0;
 #pragma unroll
     for (int k = 0; k < ER; ++k) s_ += red[k * SW + tid];
+    a.partials[(size_t)chunk * SW + tid] = s_;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// CHAINED edge backward, round 3: the same arithmetic as edge_bwd_chain_k with the work split by ROLE instead of by
+// phase.  The round-2 kernel ran eight waves in lock step through phase 0 / MFMAs / gather arithmetic / column walk
+// (three barriers per 16-row tile): per-phase clock stamps (tools/chain_phase_timing) show the phases ADD UP -- 1220 +
+// 1400 + 810 + 2500 of a 7440-cycle tile, the matrix pipe idle in three of four phases -- while the tile's HBM time is
+// 3600 cycles.  Here waves 0-3 (one per SIMD) are the MATRIX role: they ARE edge_bwd_tr_k (phase 0: gt, split images,
+// residual rows; TN + NN MFMAs) one tile ahead; waves 4-7 are the GATHER role: the by-destination arithmetic of layer
+// i-1 on the finished rows, their column walk, the node-row gathers and the BatchNorm sums.  Every SIMD hosts one wave
+// of each role, so the matrix pipe works under the other wave's VALU / LDS / memory instructions; the roles meet at
+// two workgroup barriers per tile:
+//        period p:    matrix: phase 0 (tile p)   | MFMAs (tile p)           gather: walk (tile p-2) | arithmetic (tile p-1)
+// The residual rows (og) and the fp32 e rows (ef) are double-buffered between the roles; the per-edge term images
+// (v1-v3) and the index ring belong to the gather role alone.  The weight fragments (96 registers) and TN accumulators
+// (64) now live only in the matrix waves, the gathered node rows (48) only in the gather waves.
+// ------------------------------------------------------------------------------------------
+
+// The column walk of one 16-row tile by the gather role of edge_bwd_chain2_k (see there): `sdk` = the tile's 16
+// destination nodes (LDS), dnext = the node of the next tile's first row (-1: the chunk ends here), vsrc = this lane's
+// float4 column of the term image, first row of its 8-row group (wgrp).  The same eight stores on every path and for
+// EVERY wave -- a wave with real == false stores to its dummy line -- so hipcc's vmcnt waits stay counted.
+__device__ __forceinline__ void chain2_walk(const int* sdk, int dnext, const float* vsrc, int wgrp, int lane, bool real,
+                                            float* wout, int64_t wpitch, float* dummy, int& cur, float4& carry) {
+  int d[9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = sdk[8 * wgrp + j];
+  d[8] = wgrp == 0 ? sdk[8] : dnext;
+  float4 x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = ld4(vsrc + j * SW);
+  // running sums inside the group: a new segment multiplies the running sum by 0 (rows past the chunk hold zeros and
+  // repeat the last row's node: they extend its segment by nothing)
+#pragma unroll
+  for (int j = 1; j < 8; ++j) x[j] = fma4(x[j - 1], f4(d[j] == d[j - 1] ? 1.f : 0.f), x[j]);
+  // carry into the group's first segment: group 0 from the previous tile, group 1 from group 0
+  const float4 open = f4(d[0] == d[7] ? 1.f : 0.f);
+  const float link0 = d[0] == cur ? 1.f : 0.f;
+  const float4 I0 = fma4(carry * link0, open, x[7]);       // (meaningful in group 0)
+  const float4 Ip = make_float4(__shfl_up(I0.x, 32, 64), __shfl_up(I0.y, 32, 64), __shfl_up(I0.z, 32, 64), __shfl_up(I0.w, 32, 64));
+  const float link1 = d[0] == sdk[7] ? 1.f : 0.f;
+  const float4 cin = wgrp == 0 ? carry * link0 : Ip * link1;
+  const float4 I = fma4(cin, open, x[7]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 val = j == 7 ? I : fma4(cin, f4(d[j] == d[0] ? 1.f : 0.f), x[j]);
+    float* ptr = dummy;
+    if (real && d[j + 1] != d[j] && d[j] >= 0) ptr = wout + (int64_t)d[j] * wpitch;     // (an address select)
+    st4(ptr, val);
+  }
+  carry = make_float4(__shfl(I.x, 32 + (lane & 31), 64), __shfl(I.y, 32 + (lane & 31), 64),
+                      __shfl(I.z, 32 + (lane & 31), 64), __shfl(I.w, 32 + (lane & 31), 64));
+  cur = sdk[ER - 1];
+}
+
+constexpr int C2_LDS = 6 * EIMG + 2 * ER * EOP * 4 + 2 * ER * SW * 4 + 7 * SW * 4 + 4 * SW * 4 + 3 * ER * SW * 4 + 3 * 2 * ER * 4 + 256 * 32;
+
+__global__ __launch_bounds__(CT, 2) void edge_bwd_chain2_k(const ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[C2_LDS];
+  unsigned char* ig = lds;                                               // gt images
+  unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
+  float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // [2] residual ge rows, then ge + gt W3 (row layout)
+  float* ef = og + 2 * ER * EOP;                                         // [2] e_out(i-1) rows in fp32
+  float* cs = ef + 2 * ER * SW;                                          // layer i:   mu, rstd, scale, shift, m1, m2, c
+  float* cl = cs + 7 * SW;                                               // layer i-1: mu, rstd, scale, shift
+  float* v1 = cl + 4 * SW;                                               // sigma * Qb[src]
+  float* v2 = v1 + ER * SW;                                              // gu
+  float* v3 = v2 + ER * SW;                                              // that
+  int* sd = reinterpret_cast<int*>(v3 + ER * SW);                        // ring of 3 tiles x [src 16 | dst 16]
+  double* cgs_all = reinterpret_cast<double*>(sd + 3 * 2 * ER);          // matrix role: 4 fp64 column sums of gt per thread
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool matrix = wave < 4;
+  const int t8 = tid & 255;
+  const int row0 = t8 >> 5, lc4 = (t8 & 31) * 4;                         // this thread's rows: row0 and row0 + 8 (either role)
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t v0 = (int64_t)chunk * a.nodes_per_block < a.N ? (int64_t)chunk * a.nodes_per_block : a.N;
+  const int64_t v1n = v0 + a.nodes_per_block < a.N ? v0 + a.nodes_per_block : a.N;
+  const int64_t rb = a.in_ptr[v0], re = a.in_ptr[v1n];                   // this workgroup's rows
+  const int64_t ntile = (re - rb + ER - 1) / ER;
+  const int64_t klast = ntile - 1;
+  for (int c = tid; c < SW; c += CT) {
+    cs[c] = a.stat_hi[c];
+    cs[SW + c] = a.stat_hi[SW + c];
+    cs[2 * SW + c] = a.stat_hi[2 * SW + c];
+    cs[3 * SW + c] = a.stat_hi[3 * SW + c];
+    cs[4 * SW + c] = a.bstat_hi[c];
+    cs[5 * SW + c] = a.bstat_hi[SW + c];
+    cs[6 * SW + c] = a.gamma_hi[c] * a.stat_hi[SW + c];
+    cl[c] = a.stat_lo[c];
+    cl[SW + c] = a.stat_lo[SW + c];
+    cl[2 * SW + c] = a.stat_lo[2 * SW + c];
+    cl[3 * SW + c] = a.stat_lo[3 * SW + c];
+  }
+  for (int c = tid; c < 3 * ER * SW; c += CT) v1[c] = 0.f;               // the walk of "tile -1" sums zeros ...
+  for (int c = tid; c < 3 * 2 * ER; c += CT) sd[c] = -1;                 // ... of node -1, which is never stored
+  auto clamp_row = [&](int64_t k, int row) __attribute__((always_inline)) {
+    const int64_t left = re - (rb + k * ER);                             // >= 1
+    const int nv = left < ER ? (int)left : ER;
+    return row < nv ? row : nv - 1;
+  };
+  // target of throw-away stores (rows past the chunk, scoreboard equalisation, walk rows that end no segment): a slab
+  // of its own BEHIND the gridDim.x slabs that carry results
+  float* const dummy = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + (size_t)(tid >> 5) * SW + (tid & 31) * 4;
+
+  floatx16 tn[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tn[x][y][e] = 0.f;
+  double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};   // gather role: BatchNorm sums of layer i-1
+  double* cgs = cgs_all + 4 * t8;
+  if (matrix) { cgs[0] = 0.0; cgs[1] = 0.0; cgs[2] = 0.0; cgs[3] = 0.0; }
+  __syncthreads();
+
+  if (matrix) {
+    // =============================== MATRIX role: edge_bwd_tr_k on tiles 0 .. ntile-1 ===============================
+    const int li = lane & 31, lg = lane >> 5;
+    const int wn = wave >> 1, wc = wave & 1;
+    (void)li; (void)lg;
+    W3Frag wf;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const bf16x8* p = a.Wp + ((int64_t)(2 * wave + nb) * (SW / 32) * 3) * 64 + lane;
+#pragma unroll
+      for (int kc = 0; kc < SW / 32; ++kc)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) wf.w[nb][kc][s_] = p[(kc * 3 + s_) * 64];
+    }
+    const int trq0 = simg_tr_base(lane, 0), trq1 = simg_tr_base(lane, 1);
+    const int ni = lane & 15, ng = lane >> 4;
+    const int nnb = ni * SPITCH + ((((ni & 3) << 2) | (ng ^ (swz(ni) & 3))) << 4);
+    float4 pg[2], pt[2], pe_[2];
+    auto prefetch = [&](int64_t k) __attribute__((always_inline)) {
+      const int64_t r0 = rb + k * ER;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int o = clamp_row(k, row0 + 8 * it) * SW + lc4;
+        pg[it] = ld4(a.ge + r0 * SW + o);
+        pt[it] = ld4(a.t_hi + r0 * SW + o);
+        pe_[it] = ld4(a.e_mid + r0 * SW + o);
+      }
+    };
+    if (ntile > 0) prefetch(0);
+    for (int64_t k = 0; k < ntile; ++k) {
+      const int64_t r0 = rb + k * ER;
+      const int nvalid = re - r0 < ER ? (int)(re - r0) : ER;
+      float* ogb = og + (int)(k & 1) * ER * EOP;
+      float* efb = ef + (int)(k & 1) * ER * SW;
+      // ---- phase 0: gt rows and e rows -> split images; residual ge rows -> og; fp32 e rows -> ef ----
+      {
+        double c0 = cgs[0], c1 = cgs[1], c2 = cgs[2], c3 = cgs[3];
+        const float4 mu = ld4(cs + lc4), rs = ld4(cs + SW + lc4), sc = ld4(cs + 2 * SW + lc4),
+                     sh = ld4(cs + 3 * SW + lc4), m1 = ld4(cs + 4 * SW + lc4), m2 = ld4(cs + 5 * SW + lc4),
+                     cc = ld4(cs + 6 * SW + lc4);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = row0 + 8 * it;
+          st4(ogb + row * EOP + lc4, pg[it]);
+          st4(efb + row * SW + lc4, pe_[it]);
+          const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
+          float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
+          if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
+          c0 += (double)gt.x; c1 += (double)gt.y; c2 += (double)gt.z; c3 += (double)gt.w;
+          simg_stage(ig, EIMG, row, lc4, gt);
+          simg_stage(ie, EIMG, row, lc4, pe_[it]);
+        }
+        cgs[0] = c0; cgs[1] = c1; cgs[2] = c2; cgs[3] = c3;
+      }
+      __syncthreads();   // (1) images and rows of tile k staged; the gather role has the term images of tile k-1
+      prefetch(k + 1 < klast ? k + 1 : klast);          // a tile ahead; past the end the last tile is requested again
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- TN: gW3[n][c] += sum_rows gt[row][n] e[row][c], this wave's 64 x 64 block (transpose reads) ----
+      {
+        int tr0 = trq0, tr1 = trq1;
+        asm volatile("" : "+v"(tr0), "+v"(tr1));
+        bf16x8 fa[2][3];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int s_ = 0; s_ < 3; ++s_)
+            fa[x][s_] = simg_col_frag2(ig + s_ * EIMG, tr0 ^ ((2 * wn + x) << 6), tr1 ^ ((2 * wn + x) << 6));
+#pragma unroll
+        for (int sb = 0; sb < 3; ++sb) {
+          const bf16x8 b0 = simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc) << 6), tr1 ^ ((2 * wc) << 6));
+          const bf16x8 b1 = simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc + 1) << 6), tr1 ^ ((2 * wc + 1) << 6));
+#pragma unroll
+          for (int sa = 0; sa < 3; ++sa) {
+            if (sa + sb > 2) continue;               // the three products below 2^-24 are dropped
+            mfb16(tn[0][0], fa[0][sa], b0);
+            mfb16(tn[0][1], fa[0][sa], b1);
+            mfb16(tn[1][0], fa[1][sa], b0);
+            mfb16(tn[1][1], fa[1][sa], b1);
+          }
+        }
+      }
+      // ---- NN: acc = gt W3 (16 rows x this wave's 2 x 16 columns), joined with the residual rows in og ----
+      floatx4_acc acc[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nb][e] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < SW / 32; ++kc) {
+        bf16x8 fa[3];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) fa[s_] = *reinterpret_cast<const bf16x8*>(ig + s_ * EIMG + (nnb ^ (kc << 6)));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          mfb16s(acc[nb], fa[2], wf.w[nb][kc][0]);
+          mfb16s(acc[nb], fa[0], wf.w[nb][kc][2]);
+          mfb16s(acc[nb], fa[1], wf.w[nb][kc][1]);
+          mfb16s(acc[nb], fa[1], wf.w[nb][kc][0]);
+          mfb16s(acc[nb], fa[0], wf.w[nb][kc][1]);
+          mfb16s(acc[nb], fa[0], wf.w[nb][kc][0]);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ogb[(4 * ng + e) * EOP + wave * 32 + nb * 16 + ni] += acc[nb][e];
+      __syncthreads();   // (2) og(k) = ge(i-1) rows of tile k complete; the images may be restaged
+    }
+    if (ntile > 0) {     // the gather role runs two periods longer
+      __syncthreads(); __syncthreads();
+      __syncthreads(); __syncthreads();
+    }
+  } else {
+    // ================== GATHER role: by-destination backward of layer i-1 on tiles 0 .. ntile-1 ===================
+    // column walk: waves 4-6, role = wave - 4 (0 sums sigma*Qb -> gA3h, 1 that -> Td, 2 gu -> Ud); a lane owns one
+    // float4 of columns (lane & 31) of one ROW GROUP (lane >> 5: rows 0-7 / 8-15): an 8-step chain, one shuffle round for
+    // the carry between the groups, one for the carry into the next tile; a segment is stored once, from its last row
+    const int role = wave < 7 ? wave - 4 : 2;
+    const bool walker = wave < 7;
+    const int wgrp = lane >> 5, wc4 = (lane & 31) * 4;
+    float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
+    const int64_t wpitch = role == 0 ? 5 * SW : SW;
+    const float* const vsrc0 = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4 + (8 * wgrp) * SW;
+    int cur = -1;                              // destination node of the previous tile's last row
+    float4 carry = f4(0.f);                    // running sum of that node's segment at the end of the previous tile
+    float4 bna = f4(0.f), bnb = f4(0.f);       // fp32 BatchNorm partial sums (flushed to fp64 every 8 tiles)
+    float4 pl[2];                              // t(i-1) rows of the next tile
+    float4 ga2[2], gqb[2], ghb[2], gqf[2], ghf[2], ga3[2];   // node rows of this thread's two edges: A2h[s] Qb[s] hb[s] | Qf[d] hf[d] A3h[d]
+    int fs[2] = {0, 0}, fd[2] = {0, 0};        // source / destination node of this thread's rows, the tile after the next
+    auto prefetch_idx = [&](int64_t k) __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int64_t r = rb + k * ER + clamp_row(k, row0 + 8 * it);
+        fs[it] = a.isrc[r];
+        fd[it] = a.idst[r];
+      }
+    };
+    auto prefetch_pl = [&](int64_t k) __attribute__((always_inline)) {
+      const int64_t r0 = rb + k * ER;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) pl[it] = ld4_nt(a.t_lo + r0 * SW + clamp_row(k, row0 + 8 * it) * SW + lc4);
+    };
+    auto gather = [&]() __attribute__((always_inline)) {        // node rows of the edges fs -> fd
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int64_t s = fs[it], d = fd[it];
+        ga2[it] = ld4(a.P_lo + s * (5 * SW) + SW + lc4);
+        gqb[it] = ld4(a.Q_lo + s * (2 * SW) + SW + lc4);
+        ghb[it] = ld4(a.hb_lo + s * SW + lc4);
+        gqf[it] = ld4(a.Q_lo + d * (2 * SW) + lc4);
+        ghf[it] = ld4(a.hf_lo + d * SW + lc4);
+        ga3[it] = ld4(a.P_lo + d * (5 * SW) + 2 * SW + lc4);
+      }
+    };
+    auto ring_put = [&](int64_t k) __attribute__((always_inline)) {   // this thread's two rows of tile k -> ring
+      if ((t8 & 31) == 0) {
+        int* sdn = sd + (int)(k % 3) * 2 * ER;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          sdn[row0 + 8 * it] = fs[it];
+          sdn[ER + row0 + 8 * it] = fd[it];
+        }
+      }
+    };
+    if (ntile > 0) {
+      prefetch_idx(0);
+      ring_put(0);
+      st4(dummy, f4(0.f));                     // the loop head's scoreboard: | 2 row stores | 2 pl | 12 gathers | 4 indices |
+      st4(dummy + 16 * SW, f4(0.f));
+      prefetch_pl(0);
+      gather();
+      prefetch_idx(klast < 1 ? klast : 1);
+      __syncthreads();                         // period 0: the matrix role stages and multiplies tile 0
+      __syncthreads();
+      for (int64_t k = 0; k < ntile; ++k) {
+        chain2_walk(sd + (int)((k + 2) % 3) * 2 * ER + ER, sd[(int)(k % 3) * 2 * ER + ER], vsrc0, wgrp, lane, walker, wout, wpitch,
+                    dummy, cur, carry);                // tile k-1 (k = 0: zeros of node -1)
+        __syncthreads();   // (1)
+        // ---- by-destination backward of layer i-1 on this thread's two rows of tile k (edge_bwd_dst_k's arithmetic) ----
+        const int64_t r0 = rb + k * ER;
+        const int nvalid = re - r0 < ER ? (int)(re - r0) : ER;
+        const float* ogb = og + (int)(k & 1) * ER * EOP;
+        const float* efb = ef + (int)(k & 1) * ER * SW;
+        ring_put(k + 1);                       // indices of tile k+1 (requested a tile ago): for the walks of tiles k, k+1
+        {
+          const float4 mu = ld4(cl + lc4), rs = ld4(cl + SW + lc4), sc = ld4(cl + 2 * SW + lc4), sh = ld4(cl + 3 * SW + lc4);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int row = row0 + 8 * it;
+            const float4 ge4 = ld4(ogb + row * EOP + lc4);
+            const float4 tt = pl[it];
+            float4 sg, dsg;
+            sigmoid_grad4(ld4(efb + row * SW + lc4), sg, dsg);
+            const float4 gsig = fma4(gqf[it], ga2[it], fma4(gqb[it], ga3[it], f4(0.f) - gqf[it] * ghf[it] - gqb[it] * ghb[it]));
+            const float4 g = fma4(gsig, dsg, ge4);
+            const bool live = row < nvalid;    // rows past the chunk repeat its last row's indices: their terms are zeroed HERE
+            st4_nt(live ? a.ge_out + (r0 + row) * SW + lc4 : dummy, g);
+            const float4 gu = live ? gate4(fma4(tt, sc, sh), g) : f4(0.f);
+            const float4 th = live ? (tt - mu) * rs : f4(0.f);
+            st4(v1 + row * SW + lc4, live ? sg * gqb[it] : f4(0.f));
+            st4(v2 + row * SW + lc4, gu);
+            st4(v3 + row * SW + lc4, th);
+            bna += gu;
+            bnb = fma4(gu, th, bnb);
+          }
+        }
+        if ((k & 7) == 7) {                    // fp32 over sixteen rows, then fp64 (no memory operation in this branch)
+          s_gu[0] += (double)bna.x; s_gu[1] += (double)bna.y; s_gu[2] += (double)bna.z; s_gu[3] += (double)bna.w;
+          s_gut[0] += (double)bnb.x; s_gut[1] += (double)bnb.y; s_gut[2] += (double)bnb.z; s_gut[3] += (double)bnb.w;
+          bna = f4(0.f);
+          bnb = f4(0.f);
+        }
+        // the next tile's rows: t(i-1), the node rows of its edges (indices in fs / fd), then the indices of the tile after
+        prefetch_pl(k + 1 < klast ? k + 1 : klast);
+        gather();
+        prefetch_idx(k + 2 < klast ? k + 2 : klast);
+        __syncthreads();   // (2) term images of tile k and the ring slot of tile k+1 complete
+      }
+      chain2_walk(sd + (int)(klast % 3) * 2 * ER + ER, -1, vsrc0, wgrp, lane, walker, wout, wpitch, dummy, cur, carry);
+      __syncthreads();
+      __syncthreads();
+      s_gu[0] += (double)bna.x; s_gu[1] += (double)bna.y; s_gu[2] += (double)bna.z; s_gu[3] += (double)bna.w;
+      s_gut[0] += (double)bnb.x; s_gut[1] += (double)bnb.y; s_gut[2] += (double)bnb.z; s_gut[3] += (double)bnb.w;
+    }
+  }
+
+  // ---- results: gW3 slab (matrix role), column sums of gt (matrix role), BatchNorm sums of layer i-1 (gather role) ----
+  if (matrix) {
+    const int li = lane & 31, lg = lane >> 5;
+    const int wn = wave >> 1, wc = wave & 1;
+    float* sl = a.slab + (size_t)chunk * SW * SW;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = (2 * wn + x) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+          sl[m * SW + (2 * wc + y) * 32 + li] = tn[x][y][e];
+        }
+  }
+  __syncthreads();
+  {
+    double* bnr = reinterpret_cast<double*>(lds);      // [8 row groups][2][128] doubles = 16 KB (the images are dead)
+    if (!matrix) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bnr[(row0 * 2 + 0) * SW + lc4 + j] = s_gu[j];
+        bnr[(row0 * 2 + 1) * SW + lc4 + j] = s_gut[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * SW) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) s_ += bnr[g8 * 2 * SW + tid];
+      a.partials_lo[(size_t)chunk * 2 * SW + tid] = s_;
+    }
+  }
+  if (tid < SW) {       // column c of gt is held by the matrix threads 32 k + c/4 (k = 0..7), entry c % 4
+    double s_ = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_ += cgs_all[4 * (32 * k + (tid >> 2)) + (tid & 3)];
     a.partials[(size_t)chunk * SW + tid] = s_;
   }
 }
@@ -802,7 +1158,8 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
     default: break;
   }
 #endif
-  hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);
+  if (chain_variant() == 0) hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);   // round 2: phases in lock step
+  else hipLaunchKernelGGL(edge_bwd_chain2_k, dim3(grid), dim3(CT), 0, st, a);                             // round 3: matrix / gather roles
   return grid;
 }
 

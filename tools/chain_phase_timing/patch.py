@@ -1,4 +1,5 @@
-p='/root/repo/scratch_abl/csrc_t/gnm_tr.hip'; s=open(p).read()
+import sys
+p=sys.argv[1]; s=open(p).read()
 def rep(old, new, cnt=1):
     global s
     assert s.count(old) == cnt, (old, s.count(old))
@@ -54,10 +55,3 @@ extern "C" int gnm_debug_chain_timing(long long* out) {
 }
 """
 open(p,'w').write(s)
-import os
-if os.environ.get("WALK_LDS_STORE"):
-    s=open(p).read()
-    old="          st4(wout + (int64_t)cur * wpitch, acc0);\n"
-    assert s.count(old)==1
-    s=s.replace(old,"          st4(v1 + ((cur & 15) * SW) + wc4, acc0);   // EXPERIMENT: LDS store instead of the global store\n")
-    open(p,'w').write(s)

@@ -13,7 +13,7 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict
 model.to(dev); model.flatten_parameters()
 e = torch.from_numpy(inp["e"]).to(dev); pe = torch.from_numpy(inp["pe"]).to(dev); y = torch.from_numpy(inp["y"]).to(dev)
 crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
-flat = dp.FlatGradients(model.parameters())
+flat = dp.FlatGradients(model.parameters(), direct_write=True)
 for _ in range(3):
     flat.zero_(); loss = crit(model(graph, None, e, pe).squeeze(-1), y); loss.backward()
 torch.cuda.synchronize()
