@@ -1522,7 +1522,7 @@ static int g_tn_variant = 1;     // split mode: 1 = tn_tr_k (transpose reads), 0
 static int g_eb_variant = 1;     // split mode: 1 = edge_bwd_tr_k (16-row tiles, two workgroups per CU), 0 = edge_bwd_fused_k<MmB3>
 namespace gnm {
 int eb_variant() { return g_eb_variant; }
-static int g_chain_variant = 1;  // chained edge backward: 1 = edge_bwd_chain2_k (matrix / gather roles), 0 = edge_bwd_chain_k (round 2)
+static int g_chain_variant = 0;  // chained edge backward: 0 = edge_bwd_chain_k (phases in lock step), 1 = edge_bwd_chain2_k (matrix / gather roles: 3 % slower)
 int chain_variant() { return g_chain_variant; }
 static int g_enc_bwd = 1;        // edge encoder backward: 1 = fp32-MFMA kernel, 0 = VALU kernel (round 1)
 int enc_bwd_variant() { return g_enc_bwd; }

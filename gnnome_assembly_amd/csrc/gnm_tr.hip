@@ -753,32 +753,45 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
 // float4 column of the term image, first row of its 8-row group (wgrp).  The same eight stores on every path and for
 // EVERY wave -- a wave with real == false stores to its dummy line -- so hipcc's vmcnt waits stay counted.
 __device__ __forceinline__ void chain2_walk(const int* sdk, int dnext, const float* vsrc, int wgrp, int lane, bool real,
-                                            float* wout, int64_t wpitch, float* dummy, int& cur, float4& carry) {
-  int d[9];
+                                            float* wout, int wpitch, float* dummy, int& cur, float4& carry) {
+  // Two passes over the group's eight rows with a handful of live registers (a wave of this role also holds 64 gW3
+  // accumulators): the nodes are re-read from the ring (LDS broadcasts) as the chain advances.
+  // Pass 1: the group's total S = s_7 of the running sums s_0 = x_0, s_j = s_(j-1) [d_j == d_(j-1)] + x_j (a new segment
+  // multiplies the running sum by 0; rows past the chunk hold zeros and repeat the last row's node: they extend its
+  // segment by nothing).
+  const int* dg = sdk + 8 * wgrp;
+  const int d0 = dg[0];
+  float4 run = ld4(vsrc);
+  {
+    int dp = d0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) d[j] = sdk[8 * wgrp + j];
-  d[8] = wgrp == 0 ? sdk[8] : dnext;
-  float4 x[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = ld4(vsrc + j * SW);
-  // running sums inside the group: a new segment multiplies the running sum by 0 (rows past the chunk hold zeros and
-  // repeat the last row's node: they extend its segment by nothing)
-#pragma unroll
-  for (int j = 1; j < 8; ++j) x[j] = fma4(x[j - 1], f4(d[j] == d[j - 1] ? 1.f : 0.f), x[j]);
+    for (int j = 1; j < 8; ++j) {
+      const int dj = dg[j];
+      run = fma4(run, f4(dj == dp ? 1.f : 0.f), ld4(vsrc + j * SW));
+      dp = dj;
+    }
+  }
   // carry into the group's first segment: group 0 from the previous tile, group 1 from group 0
-  const float4 open = f4(d[0] == d[7] ? 1.f : 0.f);
-  const float link0 = d[0] == cur ? 1.f : 0.f;
-  const float4 I0 = fma4(carry * link0, open, x[7]);       // (meaningful in group 0)
+  const float4 open = f4(d0 == dg[7] ? 1.f : 0.f);
+  const float link0 = d0 == cur ? 1.f : 0.f;
+  const float4 I0 = fma4(carry * link0, open, run);        // (meaningful in group 0)
   const float4 Ip = make_float4(__shfl_up(I0.x, 32, 64), __shfl_up(I0.y, 32, 64), __shfl_up(I0.z, 32, 64), __shfl_up(I0.w, 32, 64));
-  const float link1 = d[0] == sdk[7] ? 1.f : 0.f;
+  const float link1 = d0 == sdk[7] ? 1.f : 0.f;
   const float4 cin = wgrp == 0 ? carry * link0 : Ip * link1;
-  const float4 I = fma4(cin, open, x[7]);
+  // Pass 2: the same chain started from the carry (it rides through the first segment and is dropped at the first
+  // boundary); a row that ends a segment stores the running sum, the others store to the dummy line.
+  float4 I = ld4(vsrc) + cin;
+  {
+    int dc = d0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float4 val = j == 7 ? I : fma4(cin, f4(d[j] == d[0] ? 1.f : 0.f), x[j]);
-    float* ptr = dummy;
-    if (real && d[j + 1] != d[j] && d[j] >= 0) ptr = wout + (int64_t)d[j] * wpitch;     // (an address select)
-    st4(ptr, val);
+    for (int j = 0; j < 8; ++j) {
+      const int dn = j < 7 ? dg[j + 1] : (wgrp == 0 ? sdk[8] : dnext);     // node of the next row
+      float* ptr = dummy;
+      if (real && dn != dc && dc >= 0) ptr = wout + (int64_t)dc * wpitch;    // (an address select)
+      st4(ptr, I);
+      if (j < 7) I = fma4(I, f4(dn == dc ? 1.f : 0.f), ld4(vsrc + (j + 1) * SW));
+      dc = dn;
+    }
   }
   carry = make_float4(__shfl(I.x, 32 + (lane & 31), 64), __shfl(I.y, 32 + (lane & 31), 64),
                       __shfl(I.z, 32 + (lane & 31), 64), __shfl(I.w, 32 + (lane & 31), 64));
@@ -968,7 +981,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain2_k(const ChainArgs a) {
     const bool walker = wave < 7;
     const int wgrp = lane >> 5, wc4 = (lane & 31) * 4;
     float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
-    const int64_t wpitch = role == 0 ? 5 * SW : SW;
+    const int wpitch = role == 0 ? 5 * SW : SW;
     const float* const vsrc0 = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4 + (8 * wgrp) * SW;
     int cur = -1;                              // destination node of the previous tile's last row
     float4 carry = f4(0.f);                    // running sum of that node's segment at the end of the previous tile
@@ -1114,6 +1127,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain2_k(const ChainArgs a) {
   }
 }
 
+
 // gA3h / Ud / Td rows of the nodes WITHOUT in-edges (the column walkers only ever store to nodes that own rows)
 __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const int32_t* __restrict__ in_ptr,
                                                              float* __restrict__ gP, float* __restrict__ Ud,
@@ -1158,8 +1172,8 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
     default: break;
   }
 #endif
-  if (chain_variant() == 0) hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);   // round 2: phases in lock step
-  else hipLaunchKernelGGL(edge_bwd_chain2_k, dim3(grid), dim3(CT), 0, st, a);                             // round 3: matrix / gather roles
+  if (chain_variant() == 0) hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);   // phases in lock step (the default)
+  else hipLaunchKernelGGL(edge_bwd_chain2_k, dim3(grid), dim3(CT), 0, st, a);                             // matrix / gather roles (measured 3 % slower)
   return grid;
 }
 
