@@ -112,7 +112,7 @@ def op_model(op: str, N: int, E: int, H: int):
 # The committed PMC pass (tools/collect_traffic.sh + tools/traffic_summary.py): HBM bytes per kernel launch on
 # this workload.  PMC counters cannot be collected from inside this process, so the bench line carries the
 # number together with `traffic_source`; C-ABI op -> rocprof kernel name(s) of the op in each matmul mode.
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 OP_KERNELS = {
     "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_fused_k<MmB3>", "edge_bwd_tr_k"]},
     "gnm_edge_bwd_chain": ["edge_bwd_chain_k"],

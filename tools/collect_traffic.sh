@@ -7,10 +7,11 @@
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-mkdir -p $R/gpurun_out/traffic
+D=$R/gpurun_out/${OUTDIR:-traffic}   # OUTDIR: directory under gpurun_out/; EXTRA: further bench.py arguments (e.g. --shuffle-nodes)
+mkdir -p $D
 cd /tmp
-if [ -n "$LAYER" ]; then CMD="python $R/tools/microbench.py --iters 2 --matmul bf16x3"; else CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-matmul"; fi
+if [ -n "$LAYER" ]; then CMD="python $R/tools/microbench.py --iters 2 --matmul bf16x3"; else CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-matmul --no-alt-orders $EXTRA"; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic -o $c -- $CMD > $R/gpurun_out/traffic/$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $D -o $c -- $CMD > $D/$c.log 2>&1
 done
-ls $R/gpurun_out/traffic
+ls $D
