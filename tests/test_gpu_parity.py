@@ -1095,11 +1095,17 @@ def test_degenerate_constant_features_stay_finite_and_match_the_oracle():
         got = model(g, None, torch.from_numpy(e_raw).to(dev), torch.from_numpy(deg_regular).to(dev))
         want = orc.model_forward(sd_to_torch(sd, torch.float64), torch.from_numpy(src).long(), torch.from_numpy(dst).long(), n,
                                  torch.from_numpy(e_raw).double(), torch.from_numpy(deg_regular).double(), True)
+        want32 = orc.model_forward(sd_to_torch(sd, torch.float32), torch.from_numpy(src).long(), torch.from_numpy(dst).long(), n,
+                                   torch.from_numpy(e_raw), torch.from_numpy(deg_regular), True)
     assert bool(torch.isfinite(got).all())
-    # with zero variance the normalised value is a rounding residual times 316: compare on the output scale
+    # With zero variance the normalised value is a rounding residual times 316 (rstd = 1/sqrt(eps)): ANY fp32 evaluation is
+    # far from the fp64 one here, the reference's own arithmetic included.  The bar is therefore the usual 1e-4 of the output
+    # scale OR three times the distance of the oracle's fp32 run from its fp64 run -- not a hand-picked 2e-3.
+    scale = max(1.0, float(want.abs().max()))
     d = float((got.cpu().double() - want).abs().max())
-    print(f"constant-feature graph: max |logit - oracle| = {d:.2e}, |logit| up to {float(want.abs().max()):.3f}")
-    assert d <= 2e-3 * max(1.0, float(want.abs().max()))
+    d32 = float((want32.double() - want).abs().max())
+    print(f"constant-feature graph: max |logit - oracle64| = {d:.2e} (oracle fp32 vs fp64: {d32:.2e}), |logit| up to {scale:.3f}")
+    assert d <= max(1e-4 * scale, 3.0 * d32)
 
 
 def test_non_finite_inputs_stay_confined_and_the_split_mode_divergence_is_as_documented():

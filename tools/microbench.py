@@ -54,7 +54,7 @@ def main():
             engine.layer_backward(idx, n, E, H, prm, s, gh, ge)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / a.iters * 1e3
-    wall_msg = f"layer fwd+bwd wall {wall:.2f} ms (incl. one [E,H] clone, CORUN={engine.CORUN})"
+    wall_msg = f"layer fwd+bwd wall {wall:.2f} ms (incl. one [E,H] clone)"
     tot = 0.0
     for k, (c, t) in sorted(ops.items(), key=lambda kv: -kv[1][1]):
         print(f"{k:34s} calls={c:3d} avg_ms={t / c:8.3f}")
