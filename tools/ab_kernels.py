@@ -66,7 +66,7 @@ def main():
 
             def run():
                 engine._call("gnm_edge_bwd_fused", E, H, ptr(ge0), ptr(ge_out), ptr(t), ptr(e_in), ptr(stat), ptr(bstat),
-                             ptr(gamma), ptr(W3), ptr(gW3), ptr(gb3), ptr(sc.partials), ptr(ws), need, 0, st)
+                             ptr(gamma), ptr(W3), ptr(gW3), ptr(gb3), ptr(sc.partials), ptr(ws), need, st)
             run()
             torch.cuda.synchronize()
             out[v] = (ge_out.clone(), gW3.clone(), gb3.clone(), run)
@@ -111,7 +111,7 @@ def main():
             gW, gb = torch.empty(5 * H, H, device=dev), torch.empty(5 * H, device=dev)
 
             def run():
-                engine._call("gnm_node_proj_bwd_tn", N, H, 5 * H, ptr(gP), ptr(h), ptr(gW), ptr(gb), ptr(sc.partials), ptr(ws), need, st)
+                engine._call("gnm_node_proj_bwd_tn", N, H, 5 * H, ptr(gP), ptr(h), ptr(gW), ptr(gb), ptr(sc.partials), ptr(ws), need, 0, st)
             run()
             torch.cuda.synchronize()
             out[v] = (gW.clone(), gb.clone(), run)
