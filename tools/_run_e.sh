@@ -1,2 +1,4 @@
 O=gpurun_out/r03e; mkdir -p $O
-CHAIN3=1 GNM_LIBRARY=$GRAFT_REPO_ROOT/tools/chain_phase_timing/libgnm_timing3.so python tools/chain_phase_timing/run.py > $O/phase_chain3.txt 2>&1; tail -8 $O/phase_chain3.txt
+for v in old new; do
+GNM_LIBRARY=$GRAFT_REPO_ROOT/tools/chain_phase_timing/libgnm_timing_$v.so python tools/chain_phase_timing/run.py > $O/phase_$v.txt 2>&1; tail -13 $O/phase_$v.txt
+done

@@ -1,5 +1,8 @@
 import sys
-p=sys.argv[1]; s=open(p).read()
+p=sys.argv[1]; full=open(p).read()
+# only edge_bwd_chain_k (the shipped kernel) is patched: everything before the role-specialised variant
+cut = full.index("// The column walk of one 16-row tile by the gather role of edge_bwd_chain2_k") if "edge_bwd_chain2_k" in full else len(full)
+s, rest = full[:cut], full[cut:]
 def rep(old, new, cnt=1):
     global s
     assert s.count(old) == cnt, (old, s.count(old))
@@ -14,6 +17,10 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
 rep("""    const int* sdk = sd + (int)(k % 3) * 2 * ER;
 ""","""    const int* sdk = sd + (int)(k % 3) * 2 * ER;
     TS(0)
+""")
+rep("""      st4(ef + row * SW + lc4, pe_);                  // for the sigmoid of the by-destination pass (cheaper than re-joining the split images)
+""","""      st4(ef + row * SW + lc4, pe_);                  // for the sigmoid of the by-destination pass (cheaper than re-joining the split images)
+      TS(9)
 """)
 rep("""    __syncthreads();   // images, residual rows, the next tile's indices ready
 ""","""    TS(1)
@@ -48,6 +55,7 @@ rep("""  float* sl = a.slab + (size_t)chunk * SW * SW;
   }
   float* sl = a.slab + (size_t)chunk * SW * SW;
 """)
+s = s + rest
 s=s.rstrip('\n')+"""
 
 extern "C" int gnm_debug_chain_timing(long long* out) {
