@@ -1,6 +1,7 @@
 // Host-side pieces of libgnm.so: error reporting, device query, graph index build.
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -143,9 +144,10 @@ extern "C" int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, 
         adj[(size_t)cur[(size_t)dst[k]]++] = src[k];
       }
   }
-  for (int64_t v = 0; v < N; ++v) {           // short lists: insertion sort
+  for (int64_t v = 0; v < N; ++v) {           // short lists: insertion sort (a hub's list: std::sort)
     int32_t* a = adj.data() + ptr[(size_t)v];
     const int32_t n = ptr[(size_t)v + 1] - ptr[(size_t)v];
+    if (n > 64) { std::sort(a, a + n); continue; }
     for (int32_t i = 1; i < n; ++i) {
       const int32_t x = a[i];
       int32_t j = i;
@@ -161,6 +163,8 @@ extern "C" int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, 
       const int32_t u = adj[(size_t)p];
       if (u < v) continue;                    // decided from the smaller end, mirrored below
       int32_t i = ptr[(size_t)v], ie = ptr[(size_t)v + 1], j = ptr[(size_t)u], je = ptr[(size_t)u + 1];
+      if ((int64_t)(ie - i) + (je - j) > 16384) continue;   // a hub (collapsed repeat): its edges stay out of the ordering, and the
+                                                            // merge below stays linear in E instead of quadratic in the hub's degree
       bool tri = false;
       while (i < ie && j < je) {
         const int32_t x = adj[(size_t)i], y = adj[(size_t)j];
