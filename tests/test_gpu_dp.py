@@ -56,21 +56,25 @@ def _log(name, text):
         f.write(text)
 
 
-def test_two_ranks_hip_gradients_average_and_replicas_stay_equal(tmp_path):
-    world, H, L, R = 2, 128, 3, 1500
+@pytest.mark.parametrize("world", [2, 4])      # 4 = the rank count of BASELINE config 3 (4 x chr19 graphs), here on one device
+def test_two_ranks_hip_gradients_average_and_replicas_stay_equal(tmp_path, world):
+    H, L, R = 128, 3, 1500
     port = _free_port()
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
                 GNM_BENCH_DEVICE="0", GNM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), str(tmp_path), str(H), str(L), str(R)]
     procs, outs = _run_group([cmd] * world, [dict(base, RANK=str(r), LOCAL_RANK=str(r)) for r in range(world)], 300)
-    _log("dp2_hip_ranks.log", "\n".join(outs))
+    _log(f"dp{world}_hip_ranks.log", "\n".join(outs))
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
     z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     # (1) one collective, same result everywhere, replicas bit-equal after Adam
-    assert np.array_equal(z[0]["reduced"], z[1]["reduced"]) and np.array_equal(z[0]["w"], z[1]["w"])
-    # (2) == mean of the two single-rank HIP gradients (gloo: fp32 sum, then /W)
-    mean_hip = (z[0]["own"] + z[1]["own"]) / np.float32(world)
-    assert np.array_equal(z[0]["reduced"], mean_hip.astype(np.float32))
+    assert all(np.array_equal(z[0]["reduced"], z[r]["reduced"]) and np.array_equal(z[0]["w"], z[r]["w"]) for r in range(1, world))
+    # (2) == mean of the single-rank HIP gradients (gloo sums in fp32 in an order of its own: bitwise for two ranks, to
+    #     fp32 round-off for more)
+    mean_hip = sum(z[r]["own"].astype(np.float64) for r in range(world)) / world
+    if world == 2:
+        assert np.array_equal(z[0]["reduced"], ((z[0]["own"] + z[1]["own"]) / np.float32(2)).astype(np.float32))
+    assert np.abs(z[0]["reduced"] - mean_hip).max() <= 1e-6 * max(1e-30, np.abs(mean_hip).max())
     # (3) == mean of the two single-graph ORACLE gradients (fp64), per parameter tensor, at the gradient bars of
     #     test_gpu_parity (rel-L2 2e-4, or within 3x the fp32 oracle's own distance: relu-kink noise)
     from gnnome_assembly_amd import synth
