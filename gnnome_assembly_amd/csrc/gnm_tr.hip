@@ -420,6 +420,7 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
 // waits on memory (the eight waves share every barrier, there is no second workgroup to hide a wait).
 constexpr int CT = 512;                    // threads per workgroup
 constexpr int WG_ = 4;                     // rows per LDS read group of the column walk (8 and 16 measured the same)
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 5 * ER * SW * 4 + 3 * 2 * ER * 4;
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
@@ -484,9 +485,11 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // column walkers: threads 0-95 (waves 0 and 1), one float4 of columns each; role = tid >> 5: 0 sums sigma*Qb
   // (-> gA3h), 1 that (-> Td), 2 gu (-> Ud).  The BatchNorm column sums of layer i-1 (sum gu, sum gu*that, fp64:
   // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
-  const bool walker = tid < 96, bnsum = (tid & 128) != 0;      // BatchNorm sums: waves 2, 3, 6, 7, two rows of a tile each
-  const int role = (tid >> 5) & 3, wc4 = (tid & 31) * 4;
-  const int brow = 2 * (((tid >> 8) << 2) | ((tid >> 5) & 3));   // first of this thread's two rows (0, 2, .. 14)
+  // (round 3: one role per WAVE -- lanes 0-31 of waves 0, 1, 2 -- so that the walkers' output is a wave-uniform buffer
+  //  resource; the BatchNorm sums moved to waves 4-7)
+  const bool walker = wave < 3 && lane < 32, bnsum = tid >= 256;   // BatchNorm sums: waves 4-7, two rows of a tile each
+  const int role = wave, wc4 = (tid & 31) * 4;
+  const int brow = 2 * ((tid - 256) >> 5);                         // first of this thread's two rows (0, 2, .. 14)
   int cur = -1;                             // node whose segment is being summed (wave-uniform)
   float4 acc0 = f4(0.f);
   double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};
@@ -494,8 +497,10 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // whole sum; a node's ~5 stores meet in L2): no data-dependent branch around a memory operation, so hipcc keeps
   // COUNTED vmcnt waits for the prefetched rows (a store under such a branch costs vmcnt(0) = a full drain of the
   // software pipeline on every tile).  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
-  float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
-  const int64_t wpitch = role == 0 ? 5 * SW : SW;
+  float* const wout = role == 0 ? a.gP_lo + 2 * SW : role == 1 ? a.Td_lo : a.Ud_lo;      // (wave-uniform)
+  const int wpitch32 = role == 0 ? 5 * SW : SW;
+  // the walkers' output rows as a buffer over THIS workgroup's node range (32-bit offsets whatever N; rows outside are dropped)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(wout + v0 * wpitch32, 0, (int)(v1n - v0) * wpitch32 * 4, 0x00020000);
   // target of the throw-away stores (rows past the chunk, scoreboard equalisation): a slab of its own BEHIND the
   // gridDim.x slabs that carry results -- a late throw-away store must never meet this workgroup's final slab store
   float* const dummy_row = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + lc4;
@@ -661,12 +666,23 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
           dn[q] = __builtin_amdgcn_readfirstlane(sdk[ER + r4 + q]);
           xs[q] = ld4(vsrc + (r4 + q) * SW);
         }
+        // node of the row after this group of rows: the next group's first, or (tile end) the next tile's first row, which
+        // phase 0 put into the ring before this tile's first barrier; the chunk's last tile closes every segment
+        const int dafter = r4 + WG_ < ER ? __builtin_amdgcn_readfirstlane(sdk[ER + r4 + WG_])
+                                         : (k == klast ? -1 : __builtin_amdgcn_readfirstlane(sd[(int)((k + 1) % 3) * 2 * ER + ER]));
 #pragma unroll
         for (int q = 0; q < WG_; ++q) {
           const float keep = dn[q] == cur ? 1.f : 0.f;
           acc0 = fma4(acc0, f4(keep), xs[q]);
           cur = dn[q];
-          st4(wout + (int64_t)cur * wpitch, acc0);
+          // Round 3: only the LAST row of a segment reaches memory.  The store stays unconditional (a buffer store: a row that
+          // does not end its segment carries an out-of-range offset and is dropped by the hardware), so there is still no
+          // data-dependent branch around a memory operation; what goes away is 4/5 of the walk's traffic through the CU's
+          // vector-memory path (24 KB of 136 KB per tile).
+          const bool ends = (q + 1 < WG_ ? dn[q + 1] : dafter) != cur;
+          const u32x4_ bits = {__builtin_bit_cast(unsigned, acc0.x), __builtin_bit_cast(unsigned, acc0.y),
+                               __builtin_bit_cast(unsigned, acc0.z), __builtin_bit_cast(unsigned, acc0.w)};
+          __builtin_amdgcn_raw_buffer_store_b128(bits, wrs, ends ? ((cur - (int)v0) * wpitch32 + wc4) * 4 : -1, 0, 0);
         }
       }
     }
