@@ -299,6 +299,7 @@ def main():
     flat = dp.FlatGradients(model.parameters(), direct_write=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
+    opt_ev = None   # (start, end) events around optimizer.step() of the per-op timing step: SURVEY 8(d) "optimizer step reported separately"
     own = []        # world > 1: (event before the step, event before the gradient exchange) = this rank's OWN compute
 
     def step():
@@ -316,7 +317,11 @@ def main():
             e1.record()
             own.append((e0, e1))
         flat.all_reduce_mean()
+        if opt_ev is not None:
+            opt_ev[0].record()
         opt.step()
+        if opt_ev is not None:
+            opt_ev[1].record()
         return loss
 
     dbg(f"setup done E={E}")
@@ -369,8 +374,14 @@ def main():
     # the step (it contains the gradient all-reduce); only rank 0 records and reports.
     if rank == 0:
         engine.profile_ops(True)
+        opt_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     step()
     ops = engine.profile_ops(False) if rank == 0 else None
+    optimizer_ms = None
+    if rank == 0 and not args.inference:
+        torch.cuda.synchronize()
+        optimizer_ms = opt_ev[0].elapsed_time(opt_ev[1])
+    opt_ev = None
     dbg("profile step done")
     # the other matmul mode of the fused kernels (include/gnm.h), measured the same way right after the
     # default run; reported beside `value`, never as `value`
@@ -475,6 +486,7 @@ def main():
             "roofline": roof,
             "op_ms": {k: round(v[1], 3) for k, v in ranked},
             "op_total_ms": round(tot, 3),
+            "optimizer_ms": None if optimizer_ms is None else round(optimizer_ms, 3),
             "peak_mem_gib": round(peak_saved / 2 ** 30, 1),
         }
         if alt:
