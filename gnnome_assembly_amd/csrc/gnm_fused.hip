@@ -1626,13 +1626,23 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
 extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void);
 
 // The fused edge backward of layer i chained with the by-destination backward pass of layer i-1 (gnm.h).
-extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
-                                  const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
-                                  const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
-                                  const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
-                                  const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
-                                  const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
-                                  int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+// the partition every sweep kernel (and the sweep plan built for them) uses: one 512-thread workgroup per CU
+extern "C" int gnm_sweep_partition(int64_t N, int64_t* nodes_per_block, int* grid_out) {
+  GNM_CHECK_ARG(N > 0 && nodes_per_block, "sweep_partition: bad argument");
+  const int grid = persistent_grid(N, 64, 1, 8);     // call cap 8 > 1: the process-wide occupancy knob does not apply
+  *nodes_per_block = (N + grid - 1) / grid;
+  if (grid_out) *grid_out = grid;
+  return 0;
+}
+
+static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
+                               const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
+                               const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
+                               const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
+                               const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
+                               const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
+                               const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block, float* UT_lo,
+                               int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(H == FH, "edge_bwd_chain: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(g_matmul_mode == 1, "edge_bwd_chain: only built for the bf16x3 matmul mode");
   GNM_CHECK_ARG(N > 0 && E > 0 && ge && ge_out && t_hi && e_mid && stat_hi && bstat_hi && gamma_hi && W3_hi && gW3_hi &&
@@ -1651,12 +1661,51 @@ extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, 
   a.t_lo = t_lo; a.stat_lo = stat_lo; a.P_lo = P_lo; a.Q_lo = Q_lo; a.hf_lo = hf_lo; a.hb_lo = hb_lo;
   a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
   a.gP_lo = gP_lo; a.Ud_lo = Ud_lo; a.Td_lo = Td_lo; a.partials_lo = partials_lo;
+  a.sinfo = sinfo; a.UT_lo = UT_lo; a.margin = kSweepMargin; a.dinfo = dinfo;
+  a.ud_pitch = Td_lo == Ud_lo + FH ? 2 * FH : FH;       // [Ud | Td] as one [N,2H] array, or two [N,H] arrays
+  GNM_CHECK_ARG(!dinfo || a.ud_pitch == 2 * FH, "edge_bwd_chain_src: with dinfo, Ud_lo / Td_lo must be the halves of one [N,2H] array");
+  int64_t npb = 0;
+  gnm_sweep_partition(N, &npb, nullptr);
+  // the walkers' / run sums' rows are addressed through 32-bit buffer offsets over the workgroup's node range
+  GNM_CHECK_ARG((npb + 2 * kSweepMargin) * 5 * FH * 4 < (int64_t)INT32_MAX, "edge_bwd_chain: %lld nodes per workgroup exceed the 32-bit buffer offsets",
+                (long long)npb);
+  if (sinfo) {
+    GNM_CHECK_ARG(UT_lo, "edge_bwd_chain_src: UT_lo is null");
+    GNM_CHECK_ARG(plan_nodes_per_block == npb, "edge_bwd_chain_src: the sweep plan was built for %lld nodes per workgroup, the kernel uses %lld "
+                  "(gnm_sweep_partition)", (long long)plan_nodes_per_block, (long long)npb);
+  }
   const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st);
   GNM_LAUNCH_CHECK("edge_bwd_chain");
   hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3_hi);
   GNM_LAUNCH_CHECK("edge_bwd_chain slab reduce");
   *nblk_out = grid;
   return gnm_reduce_partials(partials_hi, grid, 1, FH, gb3_hi, stream) ? -3 : 0;
+}
+
+extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
+                                  const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
+                                  const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
+                                  const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
+                                  const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
+                                  const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
+                                  int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  return edge_bwd_chain_impl(N, E, H, ge, ge_out, t_hi, e_mid, stat_hi, bstat_hi, gamma_hi, W3_hi, gW3_hi, gb3_hi, partials_hi,
+                             t_lo, stat_lo, P_lo, Q_lo, hf_lo, hb_lo, isrc, idst, in_ptr, gP_lo, Ud_lo, Td_lo, partials_lo,
+                             nullptr, nullptr, 0, nullptr, nblk_out, ws, ws_bytes, stream);
+}
+
+extern "C" int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
+                                      const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
+                                      const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
+                                      const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
+                                      const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
+                                      const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
+                                      const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
+                                      float* UT_lo, int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(sinfo, "edge_bwd_chain_src: sinfo is null");
+  return edge_bwd_chain_impl(N, E, H, ge, ge_out, t_hi, e_mid, stat_hi, bstat_hi, gamma_hi, W3_hi, gW3_hi, gb3_hi, partials_hi,
+                             t_lo, stat_lo, P_lo, Q_lo, hf_lo, hb_lo, isrc, idst, in_ptr, gP_lo, Ud_lo, Td_lo, partials_lo,
+                             sinfo, dinfo, plan_nodes_per_block, UT_lo, nblk_out, ws, ws_bytes, stream);
 }
 
 extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void) {

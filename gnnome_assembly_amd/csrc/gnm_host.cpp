@@ -217,6 +217,132 @@ extern "C" int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, 
 // (src, dst) -> edge id dict (graph_parser.py:13-73); here both directions are CSR arrays whose
 // `eid` column already holds that dict's answer (the LAST edge id of a duplicated pair).
 // ------------------------------------------------------------------------------------------
+// Sweep plan: what lets ONE destination-sorted sweep also form the by-SOURCE sums (the reference aggregates the same
+// gate on g and on dgl.reverse(g), gated_gcn_full.py:128-129,141-142; the backward duals likewise).  A workgroup of the
+// sweep owns the rows of a contiguous range of destination nodes and walks them in tiles of `tile_rows`; the out-edges
+// of a source land in a few nearby tiles (overlap graphs are banded once the nodes are numbered along the genome:
+// <= 28 sources are open at any time on the chr19-scale graph, profiles/r04_band_histogram.txt), so a source's sum is
+// carried from tile to tile in one of `nslots` accumulator slots of the workgroup's LDS.  Everything data dependent
+// is decided HERE, once per graph, so that the kernels stay branch-free around their memory operations and
+// deterministic (one owner per source and tile, fixed order of additions, no atomics):
+//   sinfo[j] != 0  iff row j is the FIRST row of its source inside its tile (the "leader") and the source is local:
+//     bits 0-15  the tile rows that share the source (bit r = row r of the tile), always including the leader's;
+//     bits 16-21 the accumulator slot;  bit 22 OPEN: first tile of the source (the slot is not read);
+//     bit 23     CLOSE: last tile of the source (the sum goes to memory, the slot is not written).
+//   dinfo[j]: the same for the destination of row j (its rows are contiguous; two slots alternate).
+//   fix_nodes: the sources the sweep does NOT serve -- out-edges in more than one workgroup (boundaries, repeat
+//     edges), no free slot, or outside [first node - margin, last node + margin) of the workgroup (the sums are
+//     stored through 32-bit buffer offsets) -- plus the nodes without out-edges; a small gather kernel covers them.
+// A slot freed by a CLOSE is handed out again from the NEXT tile on (inside a tile every leader runs concurrently).
+// ------------------------------------------------------------------------------------------
+extern "C" int gnm_graph_build_sweep_plan(const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, int64_t N,
+                                          int64_t E, int64_t nodes_per_block, int tile_rows, int nslots, int64_t margin,
+                                          uint32_t* sinfo, uint32_t* dinfo, int32_t* fix_nodes, int64_t* nfix_out,
+                                          int32_t* peak_live_out) {
+  GNM_CHECK_ARG(N >= 0 && E >= 0 && N < INT32_MAX && E < INT32_MAX && nodes_per_block > 0 && tile_rows > 0 &&
+                    tile_rows <= 16 && nslots > 0 && nslots <= 64 && margin >= 0,
+                "graph_build_sweep_plan: bad extent (tile_rows <= 16, nslots <= 64)");
+  GNM_CHECK_ARG((E == 0 || (isrc && idst && sinfo && dinfo)) && in_ptr && (N == 0 || fix_nodes) && nfix_out,
+                "graph_build_sweep_plan: null argument");
+  constexpr uint32_t kOpen = 1u << 22, kClose = 1u << 23;
+  std::memset(sinfo, 0, sizeof(uint32_t) * (size_t)E);
+  std::memset(dinfo, 0, sizeof(uint32_t) * (size_t)E);
+  std::vector<int32_t> first((size_t)N, -1), last((size_t)N, -1);
+  for (int64_t j = 0; j < E; ++j) {
+    const int32_t s = isrc[j];
+    if (s < 0 || s >= N || idst[j] < 0 || idst[j] >= N) {
+      gnm::set_error("graph_build_sweep_plan: row %lld = (%d -> %d) outside [0, %lld)", (long long)j, s, idst[j], (long long)N);
+      return -2;
+    }
+    if (first[(size_t)s] < 0) first[(size_t)s] = (int32_t)j;
+    last[(size_t)s] = (int32_t)j;
+  }
+  // state per source: -1 = not served by the sweep, -2 = served without a slot so far, >= 0 = its slot
+  std::vector<int8_t> slot_of((size_t)N, -1);
+  std::vector<uint8_t> served((size_t)N, 0);
+  int peak = 0;
+  const int64_t nblk = (N + nodes_per_block - 1) / nodes_per_block;
+  std::vector<int> free_slots, pending;
+  for (int64_t w = 0; w < nblk; ++w) {
+    const int64_t v0 = w * nodes_per_block, v1 = std::min<int64_t>(N, v0 + nodes_per_block);
+    const int64_t rb = in_ptr[v0], re = in_ptr[v1];
+    free_slots.clear();
+    pending.clear();
+    for (int q = nslots - 1; q >= 0; --q) free_slots.push_back(q);
+    int live = 0, dslot = 0;
+    for (int64_t r0 = rb; r0 < re; r0 += tile_rows) {
+      const int nv = (int)std::min<int64_t>(tile_rows, re - r0);
+      for (int q : pending) free_slots.push_back(q);       // closed in the previous tile
+      live -= (int)pending.size();
+      pending.clear();
+      // ---- sources ----
+      for (int r = 0; r < nv; ++r) {
+        const int64_t j = r0 + r;
+        const int32_t s = isrc[j];
+        bool leader = true;
+        for (int q = 0; q < r; ++q) leader = leader && isrc[r0 + q] != s;
+        if (!leader) continue;
+        const int64_t f = first[(size_t)s], l = last[(size_t)s];
+        const bool opens = f >= r0;                           // the source's first row is in this tile (it is a leader's)
+        const bool closes = l < r0 + nv;
+        if (opens) {
+          // all out-edges inside this workgroup's rows, and close enough for 32-bit store offsets
+          const bool inside = f >= rb && l < re && s >= v0 - margin && s < v1 + margin;
+          if (!inside) continue;
+          if (!closes) {
+            if (free_slots.empty()) continue;                 // no slot: left to the fix-up pass
+            slot_of[(size_t)s] = (int8_t)free_slots.back();
+            free_slots.pop_back();
+            ++live;
+            peak = std::max(peak, live);
+          } else {
+            slot_of[(size_t)s] = -2;
+          }
+          served[(size_t)s] = 1;
+        }
+        if (!served[(size_t)s]) continue;
+        uint32_t mask = 0;
+        for (int q = r; q < nv; ++q) mask |= (isrc[r0 + q] == s) ? (1u << q) : 0u;
+        uint32_t wd = mask;
+        const int sl = slot_of[(size_t)s];
+        if (sl >= 0) wd |= (uint32_t)sl << 16;
+        if (opens) wd |= kOpen;
+        if (closes) {
+          wd |= kClose;
+          if (sl >= 0) pending.push_back(sl);
+        }
+        sinfo[j] = wd;
+      }
+      // ---- destinations (contiguous runs; a run that crosses the tile boundary carries its sum in one of two slots) ----
+      for (int r = 0; r < nv;) {
+        const int32_t d = idst[r0 + r];
+        int q = r;
+        uint32_t mask = 0;
+        while (q < nv && idst[r0 + q] == d) mask |= 1u << q++;
+        const bool opens = r0 + r == in_ptr[d];
+        const bool closes = r0 + q == in_ptr[d + 1];
+        uint32_t wd = mask;
+        if (!opens) wd |= (uint32_t)dslot << 16;              // continues the run of the previous tile: its slot
+        if (opens) wd |= kOpen;
+        if (closes) wd |= kClose;
+        if (!closes) {                                        // carried into the next tile
+          if (opens) dslot ^= 1;                              // a fresh slot (the other one may still be read in this tile)
+          wd = (wd & ~(63u << 16)) | ((uint32_t)dslot << 16);
+        }
+        dinfo[r0 + r] = wd;
+        r = q;
+      }
+    }
+  }
+  int64_t nfix = 0;
+  for (int64_t v = 0; v < N; ++v)
+    if (!served[(size_t)v]) fix_nodes[nfix++] = (int32_t)v;
+  *nfix_out = nfix;
+  if (peak_live_out) *peak_live_out = peak;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 namespace {
 
 void csr_by(const int32_t* key, const int32_t* other, int64_t N, int64_t E, int32_t* ptr, int32_t* nbr, int32_t* eid) {

@@ -344,6 +344,75 @@ __global__ __launch_bounds__(kBlock, 7) void edge_bwd_src_k(
   }
 }
 
+// Two-sided sweep (gnm_edge_bwd_chain_src): the by-source sums of the nodes the sweep plan does NOT serve (sources
+// with out-edges in more than one workgroup of the sweep -- chunk boundaries, repeat edges --, and the nodes without
+// out-edges), one node of the list per wave, by gathers like edge_bwd_src_k:  RAW sums
+//   gP[v][H:2H] = sum_out sigma * Qf[dst],   UT[v] = [ sum_out gu | sum_out that ]
+template <int H>
+__global__ __launch_bounds__(kBlock, 7) void edge_bwd_src_fix_k(
+    int64_t nfix, const int32_t* __restrict__ fix_nodes, const float* __restrict__ e_out, const float* __restrict__ t,
+    const float* __restrict__ stat, const float* __restrict__ ge, const float* __restrict__ Q,
+    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
+    float* __restrict__ gP, float* __restrict__ UT) {
+  constexpr int G = H / 4, RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / G, c4 = (lane % G) * 4;
+  const float4 mu = ld4(stat + c4), rs = ld4(stat + H + c4);
+  const float4 sc = ld4(stat + 2 * H + c4), sh = ld4(stat + 3 * H + c4);
+  for (int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave; i < nfix; i += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t v = fix_nodes[i];
+    const int a = out_ptr[v], b = out_ptr[v + 1];
+    float4 a2acc = f4(0.f), us = f4(0.f), ts = f4(0.f);
+    for (int64_t m = a + sub; m < b; m += RPW) {
+      const int64_t j = out_pos[m], d = out_dst[m];
+      const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
+      const float4 qf_d = ld4(Q + d * (2 * H) + c4);
+      const float4 tt = ld4_nt(t + j * H + c4);
+      const float4 gu = gate4(fma4(tt, sc, sh), ld4_nt(ge + j * H + c4));
+      a2acc = fma4(sg, qf_d, a2acc);
+      us += gu;
+      ts += (tt - mu) * rs;
+    }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+      a2acc += shfl_xor4(a2acc, off);
+      us += shfl_xor4(us, off);
+      ts += shfl_xor4(ts, off);
+    }
+    if (sub == 0) {
+      st4_nt(gP + v * (5 * H) + H + c4, a2acc);
+      st4_nt(UT + v * (2 * H) + c4, us);
+      st4_nt(UT + v * (2 * H) + H + c4, ts);
+    }
+  }
+}
+
+// ... and what edge_bwd_src_k did once the BatchNorm-backward means m1, m2 of the layer are known (linearity):
+//   gP[v][3H:4H] = gB1h = c (Us - outdeg m1 - m2 Ts),   gP[v][4H:5H] = gB2h = c (Ud - indeg m1 - m2 Td),  c = gamma rstd
+template <int H>
+__global__ __launch_bounds__(kBlock) void node_bgrad_k(int64_t N, const float* __restrict__ stat,
+                                                       const float* __restrict__ bstat, const float* __restrict__ gamma,
+                                                       const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ out_ptr,
+                                                       const float* __restrict__ UT, const float* __restrict__ Ud,
+                                                       const float* __restrict__ Td, int ud_pitch, float* __restrict__ gP) {
+  constexpr int G = H / 4;
+  const int64_t total = N * G;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int c4 = (int)(i % G) * 4;
+    const int64_t v = i / G;
+    const float4 m1 = ld4(bstat + c4), m2 = ld4(bstat + H + c4);
+    const float4 c = ld4(gamma + c4) * ld4(stat + H + c4);
+    const float outdeg = (float)(out_ptr[v + 1] - out_ptr[v]);
+    const float indeg = (float)(in_ptr[v + 1] - in_ptr[v]);
+    const float4 us = ld4_nt(UT + v * (2 * H) + c4), ts = ld4_nt(UT + v * (2 * H) + H + c4);
+    const float4 ud = ld4_nt(Ud + v * ud_pitch + c4), td = ld4_nt(Td + v * ud_pitch + c4);
+    float* g = gP + v * (5 * H) + c4;
+    st4_nt(g + 3 * H, c * (us - m1 * outdeg - m2 * ts));
+    st4_nt(g + 4 * H, c * (ud - m1 * indeg - m2 * td));
+  }
+}
+
 // gt = gamma*rstd*(gu - m1 - that*m2)
 template <int H>
 __global__ __launch_bounds__(kBlock) void edge_bwd_gt_k(int64_t E, const float* __restrict__ ge,
@@ -572,6 +641,36 @@ extern "C" int gnm_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out,
     hipLaunchKernelGGL(edge_bwd_src_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, e_out, t, stat_e, bstat_e, gamma_e, ge, Q, in_ptr, out_ptr, out_pos, out_dst, Ud, Td, gP, npb);
   });
   GNM_LAUNCH_CHECK("edge_bwd_src");
+  return 0;
+}
+
+extern "C" int gnm_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int64_t N, int64_t E, int H,
+                                    const float* e_out, const float* t, const float* stat_e, const float* ge,
+                                    const float* Q, const int32_t* out_ptr, const int32_t* out_pos,
+                                    const int32_t* out_dst, float* gP, float* UT, void* stream) {
+  GNM_CHECK_ARG(nfix >= 0 && N >= 0 && E >= 0 && (nfix == 0 || fix_nodes) && e_out && t && stat_e && ge && Q && out_ptr &&
+                    out_pos && out_dst && gP && UT, "edge_bwd_src_fix: null/neg argument");
+  if (nfix == 0) return 0;
+  GNM_DISPATCH_H(H, {
+    int64_t grid = ceil_div64(nfix, kWavesPerBlock);
+    const int64_t cap = (int64_t)num_cus() * occ_blocks<edge_bwd_src_fix_k<HH>>();
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(edge_bwd_src_fix_k<HH>, dim3((int)grid), dim3(kBlock), 0, (hipStream_t)stream, nfix, fix_nodes,
+                       e_out, t, stat_e, ge, Q, out_ptr, out_pos, out_dst, gP, UT);
+  });
+  GNM_LAUNCH_CHECK("edge_bwd_src_fix");
+  return 0;
+}
+
+extern "C" int gnm_node_bgrad(int64_t N, int H, const float* stat_e, const float* bstat_e, const float* gamma_e,
+                              const int32_t* in_ptr, const int32_t* out_ptr, const float* UT, const float* Ud,
+                              const float* Td, float* gP, void* stream) {
+  GNM_CHECK_ARG(N >= 0 && stat_e && bstat_e && gamma_e && in_ptr && out_ptr && UT && Ud && Td && gP,
+                "node_bgrad: null/neg argument");
+  const int ud_pitch = Td == Ud + H ? 2 * H : H;      // [Ud | Td] as one [N,2H] array, or two [N,H] arrays
+  GNM_DISPATCH_H(H, hipLaunchKernelGGL(node_bgrad_k<HH>, dim3(ew_grid(N * (HH / 4))), dim3(kBlock), 0,
+                                       (hipStream_t)stream, N, stat_e, bstat_e, gamma_e, in_ptr, out_ptr, UT, Ud, Td, ud_pitch, gP));
+  GNM_LAUNCH_CHECK("node_bgrad");
   return 0;
 }
 

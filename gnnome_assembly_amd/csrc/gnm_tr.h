@@ -151,6 +151,16 @@ struct ChainArgs {
   const int32_t* isrc; const int32_t* idst; const int32_t* in_ptr;
   float* gP_lo; float* Ud_lo; float* Td_lo; double* partials_lo;   // gP[:,2H:3H], [N,H], [N,H], [grid][2][128]
   int64_t nodes_per_block;
+  // two-sided sweep (edge_bwd_chain_k<., true>): the by-SOURCE sums of layer i-1 through the sweep plan
+  // (gnm_graph_build_sweep_plan over THIS partition): gA2h -> gP_lo[:,H:2H], Us | Ts -> UT_lo [N,2H]
+  // RUN variant: the by-destination sums through dinfo as well (no column walk); Ud_lo / Td_lo are then the two halves of
+  // ONE [N,2H] array (ud_pitch = 2H; H for two separate arrays)
+  const uint32_t* sinfo; float* UT_lo; int64_t margin; const uint32_t* dinfo; int ud_pitch;
 };
+
+constexpr int kSweepTileRows = 16;      // rows per tile of the sweep kernels (= ER of gnm_tr.hip)
+constexpr int kSweepSlots = 32;         // accumulator slots per workgroup (<= 28 are ever live on the chr19-scale graph)
+constexpr int64_t kSweepMargin = 1 << 16;   // a served source lies within this many ids of its workgroup's node range
+constexpr unsigned kSweepOpen = 1u << 22, kSweepClose = 1u << 23;
 
 }  // namespace gnm

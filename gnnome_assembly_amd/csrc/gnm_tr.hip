@@ -422,13 +422,31 @@ constexpr int CT = 512;                    // threads per workgroup
 constexpr int WG_ = 4;                     // rows per LDS read group of the column walk (8 and 16 measured the same)
 typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 5 * ER * SW * 4 + 3 * 2 * ER * 4;
+// two-sided sweep: + ring of the plan words, the sigma * Qf[dst] image, three accumulator slot arrays (gA2h, Us, Ts)
+constexpr int CH_LDS_SRC = CH_LDS + 3 * ER * 4 + ER * SW * 4 + 3 * kSweepSlots * SW * 4;
+// ... + ring of the destination plan words, two x three accumulator slots of the by-destination sums
+constexpr int CH_LDS_RUN = CH_LDS_SRC + 3 * ER * 4 + 3 * 2 * SW * 4 + 64;
+static_assert(ER == kSweepTileRows, "the sweep plan is built for the chained kernel's tile");
+static_assert(CH_LDS % 16 == 0 && CH_LDS_SRC % 16 == 0 && CH_LDS_RUN <= 160 * 1024, "LDS layout");
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
 
 // ABL (timing experiments only, results wrong when non-zero): bit 0 no column walk, bit 1 no gather arithmetic, bit 2 no MFMAs
-template <int ABL>
+// SRC: the two-sided sweep.  The by-SOURCE sums of layer i-1 (gA2h = sum_out sigma*Qf[dst], Us = sum_out gu, Ts = sum_out
+// that: what edge_bwd_src_k re-read three [E,H] streams for) are formed here too, from the per-edge terms that are in LDS
+// anyway, by the waves the column walk leaves idle (3-7): row q of the tile is served by one half-wave, which -- if the
+// row LEADS its source in this tile (sweep plan, gnm_graph_build_sweep_plan) -- adds up the tile's rows of that source, joins
+// the sum carried in the source's accumulator slot and either parks it there again or, in the source's last tile, stores
+// it.  One owner per source and tile, fixed order: deterministic, no atomics.  The stores are unconditional buffer stores
+// (offset out of range unless the leader closes its source), like the walkers'.
+// SRC = 2: the by-DESTINATION sums (gA3h, Ud, Td) are taken the same way (dinfo of the plan; a destination's rows are
+// contiguous, two slots alternate for the run that crosses a tile boundary) by the half-wave of the run's first row: the
+// sequential column walk -- 16 dependent steps per tile on three waves while the other five wait at the next barrier --
+// is gone; all sixteen half-waves serve their own row's destination and source.
+template <int ABL, int SRC, bool WSKIP = true>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[CH_LDS];
+  constexpr bool RUN = SRC == 2;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RUN ? CH_LDS_RUN : SRC ? CH_LDS_SRC : CH_LDS];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
   float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // residual ge rows, then ge + gt W3 (row layout)
@@ -440,6 +458,11 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   float* tl = v3 + ER * SW;                                              // t(i-1) rows (written and read by the same thread)
   float* ef = tl + ER * SW;                                              // e_out(i-1) rows in fp32 (same thread writes and reads)
   int* sd = reinterpret_cast<int*>(ef + ER * SW);                        // ring of 3 tiles x [src 16 | dst 16]
+  unsigned* si = reinterpret_cast<unsigned*>(sd + 3 * 2 * ER);           // SRC: ring of 3 tiles x [plan word 16]
+  float* v5 = reinterpret_cast<float*>(si + 3 * ER);                     // SRC: sigma * Qf[dst]
+  float* slots = v5 + ER * SW;                                           // SRC: [3 sums][kSweepSlots][128]
+  float* dslots = slots + 3 * kSweepSlots * SW;                          // RUN: [3 sums][2][128]
+  unsigned* di = reinterpret_cast<unsigned*>(dslots + 3 * 2 * SW);       // RUN: ring of 3 tiles x [destination plan word 16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -487,7 +510,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
   // (round 3: one role per WAVE -- lanes 0-31 of waves 0, 1, 2 -- so that the walkers' output is a wave-uniform buffer
   //  resource; the BatchNorm sums moved to waves 4-7)
-  const bool walker = wave < 3 && lane < 32, bnsum = tid >= 256;   // BatchNorm sums: waves 4-7, two rows of a tile each
+  const bool walker = !RUN && wave < 3 && lane < 32, bnsum = tid >= 256;   // BatchNorm sums: waves 4-7, two rows of a tile each
   const int role = wave, wc4 = (tid & 31) * 4;
   const int brow = 2 * ((tid - 256) >> 5);                         // first of this thread's two rows (0, 2, .. 14)
   int cur = -1;                             // node whose segment is being summed (wave-uniform)
@@ -498,17 +521,31 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // COUNTED vmcnt waits for the prefetched rows (a store under such a branch costs vmcnt(0) = a full drain of the
   // software pipeline on every tile).  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
   float* const wout = role == 0 ? a.gP_lo + 2 * SW : role == 1 ? a.Td_lo : a.Ud_lo;      // (wave-uniform)
-  const int wpitch32 = role == 0 ? 5 * SW : SW;
+  const int wpitch32 = role == 0 ? 5 * SW : a.ud_pitch;
   // the walkers' output rows as a buffer over THIS workgroup's node range (32-bit offsets whatever N; rows outside are dropped)
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(wout + v0 * wpitch32, 0, (int)(v1n - v0) * wpitch32 * 4, 0x00020000);
   // target of the throw-away stores (rows past the chunk, scoreboard equalisation): a slab of its own BEHIND the
   // gridDim.x slabs that carry results -- a late throw-away store must never meet this workgroup's final slab store
   float* const dummy_row = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + lc4;
+  // SRC: the by-source sums' output rows as buffers over [v0 - margin, v1 + margin) (the plan serves no source outside)
+  const int64_t vbase = v0 - a.margin;
+  const int nspan = (int)(v1n - v0 + 2 * a.margin);
+  const __amdgpu_buffer_rsrc_t srs_g = __builtin_amdgcn_make_buffer_rsrc(
+      SRC ? a.gP_lo + vbase * (5 * SW) + SW : a.gP_lo, 0, SRC ? nspan * 5 * SW * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs_u = __builtin_amdgcn_make_buffer_rsrc(
+      SRC ? a.UT_lo + vbase * (2 * SW) : a.gP_lo, 0, SRC ? nspan * 2 * SW * 4 : 0, 0x00020000);
+  // RUN: the by-destination sums' rows over this workgroup's own node range: gP_lo[:,2H:3H] and [Ud | Td] (one [N,2H] array)
+  const __amdgpu_buffer_rsrc_t drs_g = __builtin_amdgcn_make_buffer_rsrc(
+      a.gP_lo + v0 * (5 * SW) + 2 * SW, 0, RUN ? (int)(v1n - v0) * 5 * SW * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs_u = __builtin_amdgcn_make_buffer_rsrc(
+      a.Ud_lo + v0 * (2 * SW), 0, RUN ? (int)(v1n - v0) * 2 * SW * 4 : 0, 0x00020000);
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
   float4 ga2, gqb, ghb, gqf, ghf, ga3;       // the node rows of this thread's edge: A2h[s] Qb[s] hb[s] | Qf[d] hf[d] A3h[d]
   int fs = 0, fd = 0;                        // source / destination node of this thread's row TWO tiles ahead (in flight)
+  unsigned fi = 0;                           // SRC: its plan word (0 for the clamped rows past the chunk)
+  unsigned fj = 0;                           // RUN: its destination plan word
   // Software pipeline (every request is issued a full tile before its first use; sd is a ring of three tiles):
   //   after the first barrier of tile k:   indices of tile k+2 (registers), row streams of tile k+1 (registers)
   //   phase 0 of tile k+1:                 indices of tile k+2 -> sd ring;  rows of tile k+1 -> images
@@ -521,9 +558,18 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     return row < nv ? row : nv - 1;
   };
   auto prefetch_idx = [&](int64_t k) __attribute__((always_inline)) {
-    const int64_t r = rb + k * ER + clamp_row(k);
+    const int cr = clamp_row(k);
+    const int64_t r = rb + k * ER + cr;
     fs = a.isrc[r];
     fd = a.idst[r];
+    if constexpr (SRC) {
+      const unsigned w = a.sinfo[r];
+      fi = cr == row ? w : 0u;
+    }
+    if constexpr (RUN) {
+      const unsigned w = a.dinfo[r];
+      fj = cr == row ? w : 0u;
+    }
   };
   auto prefetch_rows = [&](int64_t k) __attribute__((always_inline)) {
     const int64_t r0 = rb + k * ER;
@@ -548,6 +594,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     if ((tid & 31) == 0) {
       sd[row] = s0;
       sd[ER + row] = d0;
+      if constexpr (SRC) si[row] = fi;
+      if constexpr (RUN) di[row] = fj;
     }
     prefetch_idx(klast < 1 ? klast : 1);            // written to the ring in phase 0 of tile 0
     prefetch_rows(0);
@@ -584,6 +632,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
         sdn[row] = fs;
         sdn[ER + row] = fd;
+        if constexpr (SRC) si[(int)((k + 1) % 3) * ER + row] = fi;
+        if constexpr (RUN) di[(int)((k + 1) % 3) * ER + row] = fj;
       }
     }
     __syncthreads();   // images, residual rows, the next tile's indices ready
@@ -648,6 +698,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       st4(v1 + row * SW + lc4, live ? sg * gqb : f4(0.f));
       st4(v2 + row * SW + lc4, live ? gate4(fma4(tt, sc, sh), g) : f4(0.f));
       st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
+      if constexpr (SRC) st4(v5 + row * SW + lc4, live ? sg * gqf : f4(0.f));
     }
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
     // ---- column walkers (waves 0 and 1) and BatchNorm sums (waves 2 and 3); the rest go on to the next phase 0 ----
@@ -682,7 +733,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
           const bool ends = (q + 1 < WG_ ? dn[q + 1] : dafter) != cur;
           const u32x4_ bits = {__builtin_bit_cast(unsigned, acc0.x), __builtin_bit_cast(unsigned, acc0.y),
                                __builtin_bit_cast(unsigned, acc0.z), __builtin_bit_cast(unsigned, acc0.w)};
-          __builtin_amdgcn_raw_buffer_store_b128(bits, wrs, ends ? ((cur - (int)v0) * wpitch32 + wc4) * 4 : -1, 0, 0);
+          if (WSKIP) { if (ends) __builtin_amdgcn_raw_buffer_store_b128(bits, wrs, ((cur - (int)v0) * wpitch32 + wc4) * 4, 0, 0); }
+          else __builtin_amdgcn_raw_buffer_store_b128(bits, wrs, ends ? ((cur - (int)v0) * wpitch32 + wc4) * 4 : (int)0x80000000, 0, 0);
         }
       }
     }
@@ -696,7 +748,83 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
       }
     }
-    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
+    if constexpr (SRC == 1) {                      // issued BEFORE the run sums: the next tile's per-edge phase waits on these
+      const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
+      gather(sdn[row], sdn[ER + row]);
+    }
+    if constexpr (SRC) {
+      // one run sum: the rows `m` of the three images, joined with / parked in the slot, or (last tile) handed back for the store
+      auto run3 = [&](unsigned w, const float* i1, const float* i2, const float* i3, float* sl, int nsl, float4& s1, float4& s2,
+                      float4& s3) __attribute__((always_inline)) {
+        unsigned m = w & 0xffffu;
+        s1 = f4(0.f); s2 = f4(0.f); s3 = f4(0.f);
+        while (m) {                                  // the tile's rows of this node, in row order (LDS only)
+          const int b = __builtin_ctz(m);
+          m &= m - 1;
+          s1 += ld4(i1 + b * SW + wc4);
+          s2 += ld4(i2 + b * SW + wc4);
+          s3 += ld4(i3 + b * SW + wc4);
+        }
+        const bool lead = (w & 0xffffu) != 0;
+        float* p = sl + ((w >> 16) & 63u) * SW + wc4;
+        if (lead && !(w & kSweepOpen)) {
+          s1 += ld4(p);
+          s2 += ld4(p + nsl * SW);
+          s3 += ld4(p + 2 * nsl * SW);
+        }
+        if (lead && !(w & kSweepClose)) {
+          st4(p, s1);
+          st4(p + nsl * SW, s2);
+          st4(p + 2 * nsl * SW, s3);
+        }
+        return lead && (w & kSweepClose);
+      };
+      auto bits4 = [](const float4& v) __attribute__((always_inline)) {
+        const u32x4_ b = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                          __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+        return b;
+      };
+      // ~3 of a tile's 16 rows close a source (a destination): a wave whose rows do not skips the three store instructions
+      // (each costs the CU's vector-memory path 16 cycles whether its lanes are in range or not); the branch is wave-uniform
+      // and holds stores only -- it leaves the counted vmcnt waits of the row pipeline alone (checked in the ISA)
+      auto by_source = [&](int rr, unsigned w) __attribute__((always_inline)) {
+        float4 s1, s2, s3;
+        const bool out = run3(w, v5, v2, v3, slots, kSweepSlots, s1, s2, s3);
+        const int sn = sdk[rr] - (int)vbase;
+        const int og_ = out ? (sn * (5 * SW) + wc4) * 4 : (int)0x80000000;
+        const int ou_ = out ? (sn * (2 * SW) + wc4) * 4 : (int)0x80000000;
+        if (__builtin_amdgcn_ballot_w64(out) != 0) {
+          __builtin_amdgcn_raw_buffer_store_b128(bits4(s1), srs_g, og_, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(bits4(s2), srs_u, ou_, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(bits4(s3), srs_u, ou_, SW * 4, 0);
+        }
+      };
+      if constexpr (RUN) {
+        if (!(ABL & 1)) {                              // every half-wave serves its own row: destination, then source
+          float4 s1, s2, s3;
+          const unsigned w = di[(int)(k % 3) * ER + row];
+          const bool out = run3(w, v1, v2, v3, dslots, 2, s1, s2, s3);
+          const int dn_ = sdk[ER + row] - (int)v0;
+          const int og_ = out ? (dn_ * (5 * SW) + wc4) * 4 : (int)0x80000000;
+          const int ou_ = out ? (dn_ * (2 * SW) + wc4) * 4 : (int)0x80000000;
+          if (__builtin_amdgcn_ballot_w64(out) != 0) {
+            __builtin_amdgcn_raw_buffer_store_b128(bits4(s1), drs_g, og_, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(bits4(s2), drs_u, ou_, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(bits4(s3), drs_u, ou_, SW * 4, 0);
+          }
+          by_source(row, si[(int)(k % 3) * ER + row]);
+        }
+      } else if (!(ABL & 1) && wave >= 3) {           // beside the column walk: half-wave q serves the tile rows q and q + 10
+        const int q = (tid - 192) >> 5;                // 0 .. 9
+        const unsigned* sik = si + (int)(k % 3) * ER;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int rr = q + 10 * pass;
+          by_source(rr & (ER - 1), rr < ER ? sik[rr & (ER - 1)] : 0u);
+        }
+      }
+    }
+    if constexpr (SRC != 1) {                      // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
     }
@@ -748,406 +876,10 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// CHAINED edge backward, round 3: the same arithmetic as edge_bwd_chain_k with the work split by ROLE instead of by
-// phase.  The round-2 kernel ran eight waves in lock step through phase 0 / MFMAs / gather arithmetic / column walk
-// (three barriers per 16-row tile): per-phase clock stamps (tools/chain_phase_timing) show the phases ADD UP -- 1220 +
-// 1400 + 810 + 2500 of a 7440-cycle tile, the matrix pipe idle in three of four phases -- while the tile's HBM time is
-// 3600 cycles.  Here waves 0-3 (one per SIMD) are the MATRIX role: they ARE edge_bwd_tr_k (phase 0: gt, split images,
-// residual rows; TN + NN MFMAs) one tile ahead; waves 4-7 are the GATHER role: the by-destination arithmetic of layer
-// i-1 on the finished rows, their column walk, the node-row gathers and the BatchNorm sums.  Every SIMD hosts one wave
-// of each role, so the matrix pipe works under the other wave's VALU / LDS / memory instructions; the roles meet at
-// two workgroup barriers per tile:
-//        period p:    matrix: phase 0 (tile p)   | MFMAs (tile p)           gather: walk (tile p-2) | arithmetic (tile p-1)
-// The residual rows (og) and the fp32 e rows (ef) are double-buffered between the roles; the per-edge term images
-// (v1-v3) and the index ring belong to the gather role alone.  The weight fragments (96 registers) and TN accumulators
-// (64) now live only in the matrix waves, the gathered node rows (48) only in the gather waves.
-// ------------------------------------------------------------------------------------------
-
-// The column walk of one 16-row tile by the gather role of edge_bwd_chain2_k (see there): `sdk` = the tile's 16
-// destination nodes (LDS), dnext = the node of the next tile's first row (-1: the chunk ends here), vsrc = this lane's
-// float4 column of the term image, first row of its 8-row group (wgrp).  The same eight stores on every path and for
-// EVERY wave -- a wave with real == false stores to its dummy line -- so hipcc's vmcnt waits stay counted.
-__device__ __forceinline__ void chain2_walk(const int* sdk, int dnext, const float* vsrc, int wgrp, int lane, bool real,
-                                            float* wout, int wpitch, float* dummy, int& cur, float4& carry) {
-  // Two passes over the group's eight rows with a handful of live registers (a wave of this role also holds 64 gW3
-  // accumulators): the nodes are re-read from the ring (LDS broadcasts) as the chain advances.
-  // Pass 1: the group's total S = s_7 of the running sums s_0 = x_0, s_j = s_(j-1) [d_j == d_(j-1)] + x_j (a new segment
-  // multiplies the running sum by 0; rows past the chunk hold zeros and repeat the last row's node: they extend its
-  // segment by nothing).
-  const int* dg = sdk + 8 * wgrp;
-  const int d0 = dg[0];
-  float4 run = ld4(vsrc);
-  {
-    int dp = d0;
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      const int dj = dg[j];
-      run = fma4(run, f4(dj == dp ? 1.f : 0.f), ld4(vsrc + j * SW));
-      dp = dj;
-    }
-  }
-  // carry into the group's first segment: group 0 from the previous tile, group 1 from group 0
-  const float4 open = f4(d0 == dg[7] ? 1.f : 0.f);
-  const float link0 = d0 == cur ? 1.f : 0.f;
-  const float4 I0 = fma4(carry * link0, open, run);        // (meaningful in group 0)
-  const float4 Ip = make_float4(__shfl_up(I0.x, 32, 64), __shfl_up(I0.y, 32, 64), __shfl_up(I0.z, 32, 64), __shfl_up(I0.w, 32, 64));
-  const float link1 = d0 == sdk[7] ? 1.f : 0.f;
-  const float4 cin = wgrp == 0 ? carry * link0 : Ip * link1;
-  // Pass 2: the same chain started from the carry (it rides through the first segment and is dropped at the first
-  // boundary); a row that ends a segment stores the running sum, the others store to the dummy line.
-  float4 I = ld4(vsrc) + cin;
-  {
-    int dc = d0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int dn = j < 7 ? dg[j + 1] : (wgrp == 0 ? sdk[8] : dnext);     // node of the next row
-      float* ptr = dummy;
-      if (real && dn != dc && dc >= 0) ptr = wout + (int64_t)dc * wpitch;    // (an address select)
-      st4(ptr, I);
-      if (j < 7) I = fma4(I, f4(dn == dc ? 1.f : 0.f), ld4(vsrc + (j + 1) * SW));
-      dc = dn;
-    }
-  }
-  carry = make_float4(__shfl(I.x, 32 + (lane & 31), 64), __shfl(I.y, 32 + (lane & 31), 64),
-                      __shfl(I.z, 32 + (lane & 31), 64), __shfl(I.w, 32 + (lane & 31), 64));
-  cur = sdk[ER - 1];
-}
-
-constexpr int C2_LDS = 6 * EIMG + 2 * ER * EOP * 4 + 2 * ER * SW * 4 + 7 * SW * 4 + 4 * SW * 4 + 3 * ER * SW * 4 + 3 * 2 * ER * 4 + 256 * 32;
-
-__global__ __launch_bounds__(CT, 2) void edge_bwd_chain2_k(const ChainArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[C2_LDS];
-  unsigned char* ig = lds;                                               // gt images
-  unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
-  float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // [2] residual ge rows, then ge + gt W3 (row layout)
-  float* ef = og + 2 * ER * EOP;                                         // [2] e_out(i-1) rows in fp32
-  float* cs = ef + 2 * ER * SW;                                          // layer i:   mu, rstd, scale, shift, m1, m2, c
-  float* cl = cs + 7 * SW;                                               // layer i-1: mu, rstd, scale, shift
-  float* v1 = cl + 4 * SW;                                               // sigma * Qb[src]
-  float* v2 = v1 + ER * SW;                                              // gu
-  float* v3 = v2 + ER * SW;                                              // that
-  int* sd = reinterpret_cast<int*>(v3 + ER * SW);                        // ring of 3 tiles x [src 16 | dst 16]
-  double* cgs_all = reinterpret_cast<double*>(sd + 3 * 2 * ER);          // matrix role: 4 fp64 column sums of gt per thread
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool matrix = wave < 4;
-  const int t8 = tid & 255;
-  const int row0 = t8 >> 5, lc4 = (t8 & 31) * 4;                         // this thread's rows: row0 and row0 + 8 (either role)
-  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  const int64_t v0 = (int64_t)chunk * a.nodes_per_block < a.N ? (int64_t)chunk * a.nodes_per_block : a.N;
-  const int64_t v1n = v0 + a.nodes_per_block < a.N ? v0 + a.nodes_per_block : a.N;
-  const int64_t rb = a.in_ptr[v0], re = a.in_ptr[v1n];                   // this workgroup's rows
-  const int64_t ntile = (re - rb + ER - 1) / ER;
-  const int64_t klast = ntile - 1;
-  for (int c = tid; c < SW; c += CT) {
-    cs[c] = a.stat_hi[c];
-    cs[SW + c] = a.stat_hi[SW + c];
-    cs[2 * SW + c] = a.stat_hi[2 * SW + c];
-    cs[3 * SW + c] = a.stat_hi[3 * SW + c];
-    cs[4 * SW + c] = a.bstat_hi[c];
-    cs[5 * SW + c] = a.bstat_hi[SW + c];
-    cs[6 * SW + c] = a.gamma_hi[c] * a.stat_hi[SW + c];
-    cl[c] = a.stat_lo[c];
-    cl[SW + c] = a.stat_lo[SW + c];
-    cl[2 * SW + c] = a.stat_lo[2 * SW + c];
-    cl[3 * SW + c] = a.stat_lo[3 * SW + c];
-  }
-  for (int c = tid; c < 3 * ER * SW; c += CT) v1[c] = 0.f;               // the walk of "tile -1" sums zeros ...
-  for (int c = tid; c < 3 * 2 * ER; c += CT) sd[c] = -1;                 // ... of node -1, which is never stored
-  auto clamp_row = [&](int64_t k, int row) __attribute__((always_inline)) {
-    const int64_t left = re - (rb + k * ER);                             // >= 1
-    const int nv = left < ER ? (int)left : ER;
-    return row < nv ? row : nv - 1;
-  };
-  // target of throw-away stores (rows past the chunk, scoreboard equalisation, walk rows that end no segment): a slab
-  // of its own BEHIND the gridDim.x slabs that carry results
-  float* const dummy = a.slab + (size_t)(gridDim.x + chunk) * SW * SW + (size_t)(tid >> 5) * SW + (tid & 31) * 4;
-
-  floatx16 tn[2][2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) tn[x][y][e] = 0.f;
-  double s_gu[4] = {0.0, 0.0, 0.0, 0.0}, s_gut[4] = {0.0, 0.0, 0.0, 0.0};   // gather role: BatchNorm sums of layer i-1
-  double* cgs = cgs_all + 4 * t8;
-  if (matrix) { cgs[0] = 0.0; cgs[1] = 0.0; cgs[2] = 0.0; cgs[3] = 0.0; }
-  __syncthreads();
-
-  if (matrix) {
-    // =============================== MATRIX role: edge_bwd_tr_k on tiles 0 .. ntile-1 ===============================
-    const int li = lane & 31, lg = lane >> 5;
-    const int wn = wave >> 1, wc = wave & 1;
-    (void)li; (void)lg;
-    W3Frag wf;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const bf16x8* p = a.Wp + ((int64_t)(2 * wave + nb) * (SW / 32) * 3) * 64 + lane;
-#pragma unroll
-      for (int kc = 0; kc < SW / 32; ++kc)
-#pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) wf.w[nb][kc][s_] = p[(kc * 3 + s_) * 64];
-    }
-    const int trq0 = simg_tr_base(lane, 0), trq1 = simg_tr_base(lane, 1);
-    const int ni = lane & 15, ng = lane >> 4;
-    const int nnb = ni * SPITCH + ((((ni & 3) << 2) | (ng ^ (swz(ni) & 3))) << 4);
-    float4 pg[2], pt[2], pe_[2];
-    auto prefetch = [&](int64_t k) __attribute__((always_inline)) {
-      const int64_t r0 = rb + k * ER;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int o = clamp_row(k, row0 + 8 * it) * SW + lc4;
-        pg[it] = ld4(a.ge + r0 * SW + o);
-        pt[it] = ld4(a.t_hi + r0 * SW + o);
-        pe_[it] = ld4(a.e_mid + r0 * SW + o);
-      }
-    };
-    if (ntile > 0) prefetch(0);
-    for (int64_t k = 0; k < ntile; ++k) {
-      const int64_t r0 = rb + k * ER;
-      const int nvalid = re - r0 < ER ? (int)(re - r0) : ER;
-      float* ogb = og + (int)(k & 1) * ER * EOP;
-      float* efb = ef + (int)(k & 1) * ER * SW;
-      // ---- phase 0: gt rows and e rows -> split images; residual ge rows -> og; fp32 e rows -> ef ----
-      {
-        double c0 = cgs[0], c1 = cgs[1], c2 = cgs[2], c3 = cgs[3];
-        const float4 mu = ld4(cs + lc4), rs = ld4(cs + SW + lc4), sc = ld4(cs + 2 * SW + lc4),
-                     sh = ld4(cs + 3 * SW + lc4), m1 = ld4(cs + 4 * SW + lc4), m2 = ld4(cs + 5 * SW + lc4),
-                     cc = ld4(cs + 6 * SW + lc4);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int row = row0 + 8 * it;
-          st4(ogb + row * EOP + lc4, pg[it]);
-          st4(efb + row * SW + lc4, pe_[it]);
-          const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
-          float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
-          if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
-          c0 += (double)gt.x; c1 += (double)gt.y; c2 += (double)gt.z; c3 += (double)gt.w;
-          simg_stage(ig, EIMG, row, lc4, gt);
-          simg_stage(ie, EIMG, row, lc4, pe_[it]);
-        }
-        cgs[0] = c0; cgs[1] = c1; cgs[2] = c2; cgs[3] = c3;
-      }
-      __syncthreads();   // (1) images and rows of tile k staged; the gather role has the term images of tile k-1
-      prefetch(k + 1 < klast ? k + 1 : klast);          // a tile ahead; past the end the last tile is requested again
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- TN: gW3[n][c] += sum_rows gt[row][n] e[row][c], this wave's 64 x 64 block (transpose reads) ----
-      {
-        int tr0 = trq0, tr1 = trq1;
-        asm volatile("" : "+v"(tr0), "+v"(tr1));
-        bf16x8 fa[2][3];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int s_ = 0; s_ < 3; ++s_)
-            fa[x][s_] = simg_col_frag2(ig + s_ * EIMG, tr0 ^ ((2 * wn + x) << 6), tr1 ^ ((2 * wn + x) << 6));
-#pragma unroll
-        for (int sb = 0; sb < 3; ++sb) {
-          const bf16x8 b0 = simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc) << 6), tr1 ^ ((2 * wc) << 6));
-          const bf16x8 b1 = simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc + 1) << 6), tr1 ^ ((2 * wc + 1) << 6));
-#pragma unroll
-          for (int sa = 0; sa < 3; ++sa) {
-            if (sa + sb > 2) continue;               // the three products below 2^-24 are dropped
-            mfb16(tn[0][0], fa[0][sa], b0);
-            mfb16(tn[0][1], fa[0][sa], b1);
-            mfb16(tn[1][0], fa[1][sa], b0);
-            mfb16(tn[1][1], fa[1][sa], b1);
-          }
-        }
-      }
-      // ---- NN: acc = gt W3 (16 rows x this wave's 2 x 16 columns), joined with the residual rows in og ----
-      floatx4_acc acc[2];
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[nb][e] = 0.f;
-#pragma unroll
-      for (int kc = 0; kc < SW / 32; ++kc) {
-        bf16x8 fa[3];
-#pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) fa[s_] = *reinterpret_cast<const bf16x8*>(ig + s_ * EIMG + (nnb ^ (kc << 6)));
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          mfb16s(acc[nb], fa[2], wf.w[nb][kc][0]);
-          mfb16s(acc[nb], fa[0], wf.w[nb][kc][2]);
-          mfb16s(acc[nb], fa[1], wf.w[nb][kc][1]);
-          mfb16s(acc[nb], fa[1], wf.w[nb][kc][0]);
-          mfb16s(acc[nb], fa[0], wf.w[nb][kc][1]);
-          mfb16s(acc[nb], fa[0], wf.w[nb][kc][0]);
-        }
-      }
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ogb[(4 * ng + e) * EOP + wave * 32 + nb * 16 + ni] += acc[nb][e];
-      __syncthreads();   // (2) og(k) = ge(i-1) rows of tile k complete; the images may be restaged
-    }
-    if (ntile > 0) {     // the gather role runs two periods longer
-      __syncthreads(); __syncthreads();
-      __syncthreads(); __syncthreads();
-    }
-  } else {
-    // ================== GATHER role: by-destination backward of layer i-1 on tiles 0 .. ntile-1 ===================
-    // column walk: waves 4-6, role = wave - 4 (0 sums sigma*Qb -> gA3h, 1 that -> Td, 2 gu -> Ud); a lane owns one
-    // float4 of columns (lane & 31) of one ROW GROUP (lane >> 5: rows 0-7 / 8-15): an 8-step chain, one shuffle round for
-    // the carry between the groups, one for the carry into the next tile; a segment is stored once, from its last row
-    const int role = wave < 7 ? wave - 4 : 2;
-    const bool walker = wave < 7;
-    const int wgrp = lane >> 5, wc4 = (lane & 31) * 4;
-    float* const wout = role == 0 ? a.gP_lo + 2 * SW + wc4 : role == 1 ? a.Td_lo + wc4 : a.Ud_lo + wc4;
-    const int wpitch = role == 0 ? 5 * SW : SW;
-    const float* const vsrc0 = (role == 0 ? v1 : role == 1 ? v3 : v2) + wc4 + (8 * wgrp) * SW;
-    int cur = -1;                              // destination node of the previous tile's last row
-    float4 carry = f4(0.f);                    // running sum of that node's segment at the end of the previous tile
-    float4 bna = f4(0.f), bnb = f4(0.f);       // fp32 BatchNorm partial sums (flushed to fp64 every 8 tiles)
-    float4 pl[2];                              // t(i-1) rows of the next tile
-    float4 ga2[2], gqb[2], ghb[2], gqf[2], ghf[2], ga3[2];   // node rows of this thread's two edges: A2h[s] Qb[s] hb[s] | Qf[d] hf[d] A3h[d]
-    int fs[2] = {0, 0}, fd[2] = {0, 0};        // source / destination node of this thread's rows, the tile after the next
-    auto prefetch_idx = [&](int64_t k) __attribute__((always_inline)) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int64_t r = rb + k * ER + clamp_row(k, row0 + 8 * it);
-        fs[it] = a.isrc[r];
-        fd[it] = a.idst[r];
-      }
-    };
-    auto prefetch_pl = [&](int64_t k) __attribute__((always_inline)) {
-      const int64_t r0 = rb + k * ER;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) pl[it] = ld4_nt(a.t_lo + r0 * SW + clamp_row(k, row0 + 8 * it) * SW + lc4);
-    };
-    auto gather = [&]() __attribute__((always_inline)) {        // node rows of the edges fs -> fd
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int64_t s = fs[it], d = fd[it];
-        ga2[it] = ld4(a.P_lo + s * (5 * SW) + SW + lc4);
-        gqb[it] = ld4(a.Q_lo + s * (2 * SW) + SW + lc4);
-        ghb[it] = ld4(a.hb_lo + s * SW + lc4);
-        gqf[it] = ld4(a.Q_lo + d * (2 * SW) + lc4);
-        ghf[it] = ld4(a.hf_lo + d * SW + lc4);
-        ga3[it] = ld4(a.P_lo + d * (5 * SW) + 2 * SW + lc4);
-      }
-    };
-    auto ring_put = [&](int64_t k) __attribute__((always_inline)) {   // this thread's two rows of tile k -> ring
-      if ((t8 & 31) == 0) {
-        int* sdn = sd + (int)(k % 3) * 2 * ER;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          sdn[row0 + 8 * it] = fs[it];
-          sdn[ER + row0 + 8 * it] = fd[it];
-        }
-      }
-    };
-    if (ntile > 0) {
-      prefetch_idx(0);
-      ring_put(0);
-      st4(dummy, f4(0.f));                     // the loop head's scoreboard: | 2 row stores | 2 pl | 12 gathers | 4 indices |
-      st4(dummy + 16 * SW, f4(0.f));
-      prefetch_pl(0);
-      gather();
-      prefetch_idx(klast < 1 ? klast : 1);
-      __syncthreads();                         // period 0: the matrix role stages and multiplies tile 0
-      __syncthreads();
-      for (int64_t k = 0; k < ntile; ++k) {
-        chain2_walk(sd + (int)((k + 2) % 3) * 2 * ER + ER, sd[(int)(k % 3) * 2 * ER + ER], vsrc0, wgrp, lane, walker, wout, wpitch,
-                    dummy, cur, carry);                // tile k-1 (k = 0: zeros of node -1)
-        __syncthreads();   // (1)
-        // ---- by-destination backward of layer i-1 on this thread's two rows of tile k (edge_bwd_dst_k's arithmetic) ----
-        const int64_t r0 = rb + k * ER;
-        const int nvalid = re - r0 < ER ? (int)(re - r0) : ER;
-        const float* ogb = og + (int)(k & 1) * ER * EOP;
-        const float* efb = ef + (int)(k & 1) * ER * SW;
-        ring_put(k + 1);                       // indices of tile k+1 (requested a tile ago): for the walks of tiles k, k+1
-        {
-          const float4 mu = ld4(cl + lc4), rs = ld4(cl + SW + lc4), sc = ld4(cl + 2 * SW + lc4), sh = ld4(cl + 3 * SW + lc4);
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const int row = row0 + 8 * it;
-            const float4 ge4 = ld4(ogb + row * EOP + lc4);
-            const float4 tt = pl[it];
-            float4 sg, dsg;
-            sigmoid_grad4(ld4(efb + row * SW + lc4), sg, dsg);
-            const float4 gsig = fma4(gqf[it], ga2[it], fma4(gqb[it], ga3[it], f4(0.f) - gqf[it] * ghf[it] - gqb[it] * ghb[it]));
-            const float4 g = fma4(gsig, dsg, ge4);
-            const bool live = row < nvalid;    // rows past the chunk repeat its last row's indices: their terms are zeroed HERE
-            st4_nt(live ? a.ge_out + (r0 + row) * SW + lc4 : dummy, g);
-            const float4 gu = live ? gate4(fma4(tt, sc, sh), g) : f4(0.f);
-            const float4 th = live ? (tt - mu) * rs : f4(0.f);
-            st4(v1 + row * SW + lc4, live ? sg * gqb[it] : f4(0.f));
-            st4(v2 + row * SW + lc4, gu);
-            st4(v3 + row * SW + lc4, th);
-            bna += gu;
-            bnb = fma4(gu, th, bnb);
-          }
-        }
-        if ((k & 7) == 7) {                    // fp32 over sixteen rows, then fp64 (no memory operation in this branch)
-          s_gu[0] += (double)bna.x; s_gu[1] += (double)bna.y; s_gu[2] += (double)bna.z; s_gu[3] += (double)bna.w;
-          s_gut[0] += (double)bnb.x; s_gut[1] += (double)bnb.y; s_gut[2] += (double)bnb.z; s_gut[3] += (double)bnb.w;
-          bna = f4(0.f);
-          bnb = f4(0.f);
-        }
-        // the next tile's rows: t(i-1), the node rows of its edges (indices in fs / fd), then the indices of the tile after
-        prefetch_pl(k + 1 < klast ? k + 1 : klast);
-        gather();
-        prefetch_idx(k + 2 < klast ? k + 2 : klast);
-        __syncthreads();   // (2) term images of tile k and the ring slot of tile k+1 complete
-      }
-      chain2_walk(sd + (int)(klast % 3) * 2 * ER + ER, -1, vsrc0, wgrp, lane, walker, wout, wpitch, dummy, cur, carry);
-      __syncthreads();
-      __syncthreads();
-      s_gu[0] += (double)bna.x; s_gu[1] += (double)bna.y; s_gu[2] += (double)bna.z; s_gu[3] += (double)bna.w;
-      s_gut[0] += (double)bnb.x; s_gut[1] += (double)bnb.y; s_gut[2] += (double)bnb.z; s_gut[3] += (double)bnb.w;
-    }
-  }
-
-  // ---- results: gW3 slab (matrix role), column sums of gt (matrix role), BatchNorm sums of layer i-1 (gather role) ----
-  if (matrix) {
-    const int li = lane & 31, lg = lane >> 5;
-    const int wn = wave >> 1, wc = wave & 1;
-    float* sl = a.slab + (size_t)chunk * SW * SW;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = (2 * wn + x) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-          sl[m * SW + (2 * wc + y) * 32 + li] = tn[x][y][e];
-        }
-  }
-  __syncthreads();
-  {
-    double* bnr = reinterpret_cast<double*>(lds);      // [8 row groups][2][128] doubles = 16 KB (the images are dead)
-    if (!matrix) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bnr[(row0 * 2 + 0) * SW + lc4 + j] = s_gu[j];
-        bnr[(row0 * 2 + 1) * SW + lc4 + j] = s_gut[j];
-      }
-    }
-    __syncthreads();
-    if (tid < 2 * SW) {
-      double s_ = 0.0;
-#pragma unroll
-      for (int g8 = 0; g8 < 8; ++g8) s_ += bnr[g8 * 2 * SW + tid];
-      a.partials_lo[(size_t)chunk * 2 * SW + tid] = s_;
-    }
-  }
-  if (tid < SW) {       // column c of gt is held by the matrix threads 32 k + c/4 (k = 0..7), entry c % 4
-    double s_ = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s_ += cgs_all[4 * (32 * k + (tid >> 2)) + (tid & 3)];
-    a.partials[(size_t)chunk * SW + tid] = s_;
-  }
-}
-
-
 // gA3h / Ud / Td rows of the nodes WITHOUT in-edges (the column walkers only ever store to nodes that own rows)
 __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const int32_t* __restrict__ in_ptr,
                                                              float* __restrict__ gP, float* __restrict__ Ud,
-                                                             float* __restrict__ Td) {
+                                                             float* __restrict__ Td, int ud_pitch) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   const int64_t stride = (int64_t)gridDim.x * 4 * 64;
@@ -1162,9 +894,9 @@ __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const in
       const int c4 = (lane & 31) * 4;
       if (lane < 32) {
         st4(gP + u * (5 * SW) + 2 * SW + c4, f4(0.f));
-        st4(Td + u * SW + c4, f4(0.f));
+        st4(Td + u * ud_pitch + c4, f4(0.f));
       } else {
-        st4(Ud + u * SW + c4, f4(0.f));
+        st4(Ud + u * ud_pitch + c4, f4(0.f));
       }
     }
   }
@@ -1175,21 +907,22 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   ChainArgs a = in;
   a.Wp = (const bf16x8*)wpack;
-  const int grid = persistent_grid(a.N, 64, 1);        // one 512-thread workgroup per CU
-  a.nodes_per_block = (a.N + grid - 1) / grid;
-  hipLaunchKernelGGL(zero_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo);
+  int grid = 0;
+  gnm_sweep_partition(a.N, &a.nodes_per_block, &grid);  // one 512-thread workgroup per CU
+  hipLaunchKernelGGL(zero_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo, a.ud_pitch);
 #ifdef GNM_TIMING_ABLATIONS      // builds for timing experiments only: the ablated kernels give wrong results
   static const int abl = getenv("GNM_CHAIN_ABL") ? atoi(getenv("GNM_CHAIN_ABL")) : 0;
   switch (abl) {
-    case 1: hipLaunchKernelGGL(edge_bwd_chain_k<1>, dim3(grid), dim3(CT), 0, st, a); return grid;
-    case 2: hipLaunchKernelGGL(edge_bwd_chain_k<2>, dim3(grid), dim3(CT), 0, st, a); return grid;
-    case 4: hipLaunchKernelGGL(edge_bwd_chain_k<4>, dim3(grid), dim3(CT), 0, st, a); return grid;
-    case 7: hipLaunchKernelGGL(edge_bwd_chain_k<7>, dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 1: hipLaunchKernelGGL((edge_bwd_chain_k<1, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 2: hipLaunchKernelGGL((edge_bwd_chain_k<2, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 4: hipLaunchKernelGGL((edge_bwd_chain_k<4, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 7: hipLaunchKernelGGL((edge_bwd_chain_k<7, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
     default: break;
   }
 #endif
-  if (chain_variant() == 0) hipLaunchKernelGGL(edge_bwd_chain_k<0>, dim3(grid), dim3(CT), 0, st, a);   // phases in lock step (the default)
-  else hipLaunchKernelGGL(edge_bwd_chain2_k, dim3(grid), dim3(CT), 0, st, a);                             // matrix / gather roles (measured 3 % slower)
+  if (a.sinfo && a.dinfo && chain_variant() == 0) hipLaunchKernelGGL((edge_bwd_chain_k<0, 2>), dim3(grid), dim3(CT), 0, st, a);   // run sums both ways
+  else if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, 1>), dim3(grid), dim3(CT), 0, st, a);     // column walk + by-source run sums
+  else hipLaunchKernelGGL((edge_bwd_chain_k<0, 0>), dim3(grid), dim3(CT), 0, st, a);
   return grid;
 }
 

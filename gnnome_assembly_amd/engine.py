@@ -486,18 +486,29 @@ TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
 SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 
 
+# The chained kernel as a TWO-SIDED sweep (gnm_edge_bwd_chain_src): layer i-1's by-source sums (gA2h, Us, Ts) come out of the
+# same pass through the graph's sweep plan (graph.sweep_plan), the separate by-source pass -- three [E,H] streams re-read per
+# layer -- shrinks to a gather over the few per cent of the nodes the plan does not serve plus an [N,H]-sized conversion
+# once the BatchNorm-backward means are known.  GNM_TWO_SIDED=0 / engine.TWO_SIDED = False keeps the separate pass.
+TWO_SIDED = os.environ.get("GNM_TWO_SIDED", "1") != "0"
+# ... with the by-destination sums as run sums too (no sequential column walk); GNM_RUN_SUMS=0 keeps the walkers
+RUN_SUMS = os.environ.get("GNM_RUN_SUMS", "1") != "0"
+
+
 def chain_eligible(H: int, batch_norm: bool) -> bool:
     return CHAIN and FUSED and H == 128 and batch_norm and _lib.get_matmul_mode() == "bf16x3"
 
 
 def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tensor], L: int, saved: List[LayerSaved],
-                            gh, ge, outs: List[Optional[Dict[str, torch.Tensor]]]):
+                            gh, ge, outs: List[Optional[Dict[str, torch.Tensor]]], plan: Optional[dict] = None):
     """Backward of the L-layer stack (layers L-1 .. 0), same arithmetic as L x layer_backward, other schedule:
         node(L-1), dst(L-1);   then for i = L-1 .. 0:   finalize_e(i), src(i), proj(i),
                                                          i > 0:  node(i-1), CHAIN[fused(i) + dst(i-1)]
                                                          i = 0:  fused(0)
     `ge` is updated in place through all layers.  Returns (gh_in of layer 0, ge_in of layer 0, [grads dict per layer]);
-    saved[i] is released as soon as layer i is done.  outs[i]: write-into targets as in layer_backward (or None)."""
+    saved[i] is released as soon as layer i is done.  outs[i]: write-into targets as in layer_backward (or None).
+    With `plan` (graph.sweep_plan) the chained kernel is the two-sided sweep: src(i) for i < L-1 becomes
+    fix(i) [right after CHAIN(i+1, i)] + bgrad(i) [after finalize_e(i)]."""
     lib = _lib.load()
     dev = gh.device
     sc, sc2 = scratch(dev), scratch(dev, "side")
@@ -549,6 +560,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     main = torch.cuda.current_stream()
     pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
     held: List[torch.Tensor] = []   # what the side stream is reading; dropped only after the main stream has waited for it
+    UT = None                   # two-sided sweep: the raw by-source sums [Us | Ts] of the current layer (None: src(i) forms them)
     while True:
         prm, s = prms[i], saved[i]
         o = outs[i] or {}
@@ -570,10 +582,15 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             held.extend((pgP, ph))
             pending = None
             src_cap = SRC_SIDE_CAP
-        _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
-              _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
-              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), src_cap, st)
+        if UT is None:
+            _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+                  _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
+                  _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), src_cap, st)
+        else:       # the sums are there (chain_src + fix): only the conversion through m1, m2 is left
+            _call("gnm_node_bgrad", N, H, _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(idx["in_ptr"]),
+                  _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), _ptr(gP), st)
         del Ud, Td, Q
+        UT = None
         g["W5"], g["b5"] = tgt(i, "W5", 5 * H, H), tgt(i, "b5", 5 * H)
         gh_in = torch.empty(N, H, **f32)
         ws = sc.ws(max(need_p, need_f))
@@ -597,12 +614,27 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
         j = i - 1
         prm_j, s_j = ensure(j)
         gP, Q = node(j, gh)
-        Ud, Td = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
-        _call("gnm_edge_bwd_chain", N, E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
-              _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc2.partials),
-              _ptr(s_j.t), _ptr(s_j.stat_e), _ptr(s_j.P), _ptr(Q), _ptr(s_j.hf), _ptr(s_j.hb),
-              _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td), _ptr(sc.partials),
-              C.byref(nblk), _ptr(ws), need_f, st)
+        if plan is None:
+            Ud, Td = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
+            _call("gnm_edge_bwd_chain", N, E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
+                  _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc2.partials),
+                  _ptr(s_j.t), _ptr(s_j.stat_e), _ptr(s_j.P), _ptr(Q), _ptr(s_j.hf), _ptr(s_j.hb),
+                  _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td), _ptr(sc.partials),
+                  C.byref(nblk), _ptr(ws), need_f, st)
+        else:
+            UT = torch.empty(N, 2 * H, **f32)
+            DT = torch.empty(N, 2 * H, **f32)       # [Ud | Td] in one array (the run-sum variant stores both through one buffer)
+            Ud, Td = DT[:, :H], DT[:, H:]
+            _call("gnm_edge_bwd_chain_src", N, E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
+                  _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc2.partials),
+                  _ptr(s_j.t), _ptr(s_j.stat_e), _ptr(s_j.P), _ptr(Q), _ptr(s_j.hf), _ptr(s_j.hb),
+                  _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td), _ptr(sc.partials),
+                  _ptr(plan["sinfo"]), _ptr(plan["dinfo"]) if RUN_SUMS else C.c_void_p(0), plan["nodes_per_block"], _ptr(UT),
+                  C.byref(nblk), _ptr(ws), need_f, st)
+            # the sources the plan does not serve (chunk boundaries, repeat edges, no out-edges): ge holds ge_tot(j) now
+            _call("gnm_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s_j.e_out), _ptr(s_j.t),
+                  _ptr(s_j.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
+                  _ptr(gP), _ptr(UT), st)
         saved[i] = None         # release layer i's activations
         if ACTIVATIONS == "lean":
             s_j.P = None        # rebuilt for the by-destination pass only; nothing after it reads P
@@ -838,7 +870,8 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     louts = [grad_targets(out, i) if out else None for i in range(num_layers)]
     chained = None
     if chain_eligible(H, batch_norm):
-        gh, ge, chained = layers_backward_chained(idx, N, E, H, P, num_layers, ms.layers, gh, ge, louts)
+        plan = graph.sweep_plan(dev) if TWO_SIDED and hasattr(graph, "sweep_plan") else None
+        gh, ge, chained = layers_backward_chained(idx, N, E, H, P, num_layers, ms.layers, gh, ge, louts, plan)
     for i in reversed(range(num_layers)):
         p = f"gnn.convs.{i}."
         lout = louts[i]

@@ -88,6 +88,7 @@ class AssemblyGraph:
         g._src_np = g._dst_np = None
         g._host_index = None
         g._dev_index = {}
+        g._plans = {}
         g._dev_edges = {src.device: (g._src_t, g._dst_t)}
         g.device = src.device
         g.ndata = {}
@@ -124,6 +125,7 @@ class AssemblyGraph:
         self._src_t = self._dst_t = None
         self._host_index = None
         self._dev_index = {}      # device -> dict of int32 tensors
+        self._plans = {}          # device -> sweep plan (or None)
         self._dev_edges = {}      # device -> (src, dst) tensors
         self.device = torch.device("cpu")
         self.ndata = {}
@@ -234,6 +236,47 @@ class AssemblyGraph:
                 h = self.host_index()
                 self._dev_index[device] = {k: torch.from_numpy(v).to(device) for k, v in h.items()}
         return self._dev_index[device]
+
+
+    def sweep_plan(self, device=None):
+        """The sweep plan of this graph on `device` (gnm_graph_build_sweep_plan over the partition the sweep kernels use
+        there): dict(sinfo, dinfo [E] int32 tensors holding the plan words, fix_nodes [nfix] int32, nodes_per_block,
+        nfix, peak_live), or None for a graph that was born on a device (its index never visits the host; the
+        engine then keeps the separate by-source passes)."""
+        device = torch.device(device) if device is not None else self.device
+        if device in self._plans:
+            return self._plans[device]
+        plan = None
+        if (self._src_t is None or self._host_index is not None) and self.num_edges() > 0 and device.type == "cuda":
+            lib = _lib.load()
+            h = self.host_index()
+            n, e = self._n, self.num_edges()
+            npb, grid = C.c_int64(0), C.c_int(0)
+            with torch.cuda.device(device):
+                _lib.check(lib.gnm_sweep_partition(n, C.byref(npb), C.byref(grid)), "gnm_sweep_partition")
+            plan = build_sweep_plan(h, n, npb.value)
+            plan = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
+        self._plans[device] = plan
+        return plan
+
+
+SWEEP_TILE_ROWS, SWEEP_SLOTS, SWEEP_MARGIN = 16, 32, 1 << 16      # = kSweepTileRows / kSweepSlots / kSweepMargin (gnm_tr.h)
+
+
+def build_sweep_plan(host_index, n: int, nodes_per_block: int, nslots: int = SWEEP_SLOTS, margin: int = SWEEP_MARGIN):
+    """gnm_graph_build_sweep_plan on a host index (dict of int32 numpy arrays): numpy arrays sinfo / dinfo (the plan
+    words, viewed as int32) and fix_nodes, plus nodes_per_block, nfix, peak_live."""
+    lib = _lib.load()
+    e = int(host_index["isrc"].size)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    sinfo, dinfo = np.zeros(e, np.uint32), np.zeros(e, np.uint32)
+    fix = np.empty(max(n, 1), np.int32)
+    nfix, peak = C.c_int64(0), C.c_int(0)
+    _lib.check(lib.gnm_graph_build_sweep_plan(ptr(host_index["isrc"]), ptr(host_index["idst"]), ptr(host_index["in_ptr"]), n, e,
+                                              int(nodes_per_block), SWEEP_TILE_ROWS, nslots, margin, ptr(sinfo), ptr(dinfo),
+                                              ptr(fix), C.byref(nfix), C.byref(peak)), "gnm_graph_build_sweep_plan")
+    return {"sinfo": sinfo.view(np.int32), "dinfo": dinfo.view(np.int32), "fix_nodes": fix[:nfix.value].copy(),
+            "nodes_per_block": int(nodes_per_block), "nfix": int(nfix.value), "peak_live": int(peak.value)}
 
 
 def _to_numpy(a):

@@ -78,6 +78,23 @@ int gnm_graph_edge_locality(const int32_t* src, const int32_t* dst, int64_t N, i
 int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, int64_t N, int64_t E, int32_t* order,
                              int32_t* rank, double* core_frac_out);
 
+/* ---- sweep plan (HOST pointers): lets ONE destination-sorted sweep also form the by-SOURCE sums the reference takes
+ *      on dgl.reverse(g) (gated_gcn_full.py:115,133-143 and their autograd duals) instead of a second pass over the
+ *      [E,H] tensors.  Input: the internal index (isrc / idst / in_ptr of gnm_graph_build_index) and the partition of
+ *      the sweep kernels (gnm_sweep_partition).  Output, per internal row j:
+ *        sinfo[j] != 0 iff row j is the first row of its source inside its tile AND the sweep serves that source:
+ *          bits 0-15 tile rows sharing the source | bits 16-21 accumulator slot | bit 22 first tile | bit 23 last tile
+ *        dinfo[j]: the same for the row's destination (contiguous rows, two alternating slots);
+ *      fix_nodes[0 .. *nfix_out): the nodes the sweep does not serve (out-edges in more than one workgroup, no free
+ *      slot, farther than `margin` ids from the workgroup's node range, or no out-edges at all): the *_fix kernels
+ *      cover them.  tile_rows <= 16, nslots <= 64; *peak_live_out (optional) = most slots ever in use.            */
+int gnm_graph_build_sweep_plan(const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, int64_t N, int64_t E,
+                               int64_t nodes_per_block, int tile_rows, int nslots, int64_t margin, uint32_t* sinfo,
+                               uint32_t* dinfo, int32_t* fix_nodes, int64_t* nfix_out, int32_t* peak_live_out);
+/* the partition of the sweep kernels on the current device: workgroup w owns the destination nodes
+ * [w * nodes_per_block, (w+1) * nodes_per_block); *grid_out (optional) = workgroups launched                  */
+int gnm_sweep_partition(int64_t N, int64_t* nodes_per_block, int* grid_out);
+
 /* ---- greedy decode (HOST pointers, sequential CPU work; inference.py:31-77,182-253) ----------
  * build_adjacency: successors / predecessors of every node in edge-id order, as the reference's
  *   succ / pred dicts (graph_parser.py:13-73); *_eid[p] = edges[(node, nbr)] of its edges dict, i.e. the
@@ -262,6 +279,31 @@ int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_o
                        const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
                        const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
                        int* nblk_out, void* ws, size_t ws_bytes, void* stream);
+/* edge_bwd_chain_src: gnm_edge_bwd_chain as a TWO-SIDED sweep -- layer i-1's by-SOURCE sums (what gnm_edge_bwd_src
+ * re-reads e_out, t and ge for) are formed in the same pass from the per-edge terms that are on chip, through the
+ * sweep plan (sinfo of gnm_graph_build_sweep_plan, built for plan_nodes_per_block = gnm_sweep_partition's), RAW:
+ *   gP_lo[:,H:2H] = sum_out sigma*Qf[dst],  UT_lo[N,2H] = [ sum_out gu | sum_out that ]    (served sources only)
+ * gnm_edge_bwd_src_fix then writes the same three sums for the plan's fix_nodes (gathers; needs layer i-1's
+ * e_out, t, stat_e, Q and ge = this call's ge_out), and once layer i-1's BatchNorm-backward means are known
+ * gnm_node_bgrad turns the raw sums into gP[:,3H:4H] = gB1h = c (Us - outdeg m1 - m2 Ts) and gP[:,4H:5H] = gB2h =
+ * c (Ud - indeg m1 - m2 Td).  Together = gnm_edge_bwd_src.  dinfo (optional, the plan's destination words): the
+ * by-destination sums gA3h / Ud / Td are run sums too (no sequential column walk); Ud_lo / Td_lo must then be the
+ * two halves of one [N,2H] array (Td_lo == Ud_lo + H, row pitch 2H; gnm_node_bgrad accepts either layout).
+ *                                                                     autograd of gated_gcn_full.py:133-143 */
+int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
+                           const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
+                           const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
+                           const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
+                           const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
+                           const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
+                           const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block, float* UT_lo,
+                           int* nblk_out, void* ws, size_t ws_bytes, void* stream);
+int gnm_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int64_t N, int64_t E, int H, const float* e_out,
+                         const float* t, const float* stat_e, const float* ge, const float* Q, const int32_t* out_ptr,
+                         const int32_t* out_pos, const int32_t* out_dst, float* gP, float* UT, void* stream);
+int gnm_node_bgrad(int64_t N, int H, const float* stat_e, const float* bstat_e, const float* gamma_e,
+                   const int32_t* in_ptr, const int32_t* out_ptr, const float* UT, const float* Ud, const float* Td,
+                   float* gP, void* stream);
 size_t gnm_node_proj_bwd_workspace_bytes(int ncols);
 int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
                       const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,

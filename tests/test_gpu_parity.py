@@ -936,6 +936,58 @@ def test_chained_backward_matches_the_layer_by_layer_backward():
 
 
 @pytest.mark.default_mode_only
+@pytest.mark.parametrize("ids", ["sorted", "shuffled"])
+def test_two_sided_sweep_matches_the_separate_by_source_pass(ids):
+    """engine.TWO_SIDED (default): the chained kernel also forms layer i-1's by-SOURCE sums (gA2h, Us, Ts) through the
+    graph's sweep plan, edge_bwd_src_k's three re-read [E,H] streams shrink to a gather over the nodes the plan does
+    not serve + the m1 / m2 conversion.  Same per-edge terms, another (fixed) order of the additions inside a
+    source's sum: every gradient agrees with the separate-pass schedule to 2e-5, two runs are bit-identical, the
+    forward does not change.  Node ids as the generator gives them and shuffled (renumbered by the index)."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(40000, 128, 4, 7, dev)
+    pe_np, e_np = inp["pe"], inp["e"]
+    if ids == "shuffled":
+        p = np.random.default_rng(3).permutation(n).astype(np.int32)
+        src, dst = p[src], p[dst]
+        pe_s = np.empty_like(pe_np)
+        pe_s[p] = pe_np
+        pe_np = pe_s
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    e, pe, y = torch.from_numpy(e_np).to(dev), torch.from_numpy(pe_np).to(dev), torch.from_numpy(inp["y"]).to(dev)
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    plan = g.sweep_plan(dev)
+    assert plan is not None and 0 < plan["nfix"] < 0.2 * n, plan and plan["nfix"]
+    print(f"sweep plan [{ids}]: {plan['nfix']} of {n} nodes left to the fix-up pass, peak live slots {plan['peak_live']}")
+
+    def run(two_sided):
+        old, engine.TWO_SIDED = engine.TWO_SIDED, two_sided
+        try:
+            model.zero_grad(set_to_none=True)
+            s = model(g, None, e, pe)
+            loss = crit(s.squeeze(-1), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
+        finally:
+            engine.TWO_SIDED = old
+    s0, l0, g0 = run(False)
+    s1, l1, g1 = run(True)
+    s2, l2, g2 = run(True)
+    assert torch.equal(s0, s1) and l0 == l1
+    assert all(torch.equal(g1[k], g2[k]) for k in g1), "two-sided sweep is not run-to-run deterministic"
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    bad = []
+    for k in g0:
+        a, b = g1[k].double(), g0[k].double()
+        r = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        if r > 2e-5 and float((a - b).abs().max()) > 1e-6 * gmax:
+            bad.append((k, r))
+    assert not bad, bad
+
+
+@pytest.mark.default_mode_only
 def test_chr1_scale_inference_at_size():
     """BASELINE config 5 at its size (chr1 = 4.03 x chr19 -> R=3 M reads, N=6 M nodes, E~30 M edges,
     H=128, L=8), forward only under no_grad as inference.py:444-454 calls the model.  E*H = 3.9 G elements
