@@ -1626,15 +1626,6 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
 extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void);
 
 // The fused edge backward of layer i chained with the by-destination backward pass of layer i-1 (gnm.h).
-// the partition every sweep kernel (and the sweep plan built for them) uses: one 512-thread workgroup per CU
-extern "C" int gnm_sweep_partition(int64_t N, int64_t* nodes_per_block, int* grid_out) {
-  GNM_CHECK_ARG(N > 0 && nodes_per_block, "sweep_partition: bad argument");
-  const int grid = persistent_grid(N, 64, 1, 8);     // call cap 8 > 1: the process-wide occupancy knob does not apply
-  *nodes_per_block = (N + grid - 1) / grid;
-  if (grid_out) *grid_out = grid;
-  return 0;
-}
-
 static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
                                const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
                                const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,
@@ -1665,14 +1656,14 @@ static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, flo
   a.ud_pitch = Td_lo == Ud_lo + FH ? 2 * FH : FH;       // [Ud | Td] as one [N,2H] array, or two [N,H] arrays
   GNM_CHECK_ARG(!dinfo || a.ud_pitch == 2 * FH, "edge_bwd_chain_src: with dinfo, Ud_lo / Td_lo must be the halves of one [N,2H] array");
   int64_t npb = 0;
-  gnm_sweep_partition(N, &npb, nullptr);
+  gnm_sweep_partition(N, 1, &npb, nullptr);      // one 512-thread workgroup per CU
   // the walkers' / run sums' rows are addressed through 32-bit buffer offsets over the workgroup's node range
   GNM_CHECK_ARG((npb + 2 * kSweepMargin) * 5 * FH * 4 < (int64_t)INT32_MAX, "edge_bwd_chain: %lld nodes per workgroup exceed the 32-bit buffer offsets",
                 (long long)npb);
   if (sinfo) {
     GNM_CHECK_ARG(UT_lo, "edge_bwd_chain_src: UT_lo is null");
     GNM_CHECK_ARG(plan_nodes_per_block == npb, "edge_bwd_chain_src: the sweep plan was built for %lld nodes per workgroup, the kernel uses %lld "
-                  "(gnm_sweep_partition)", (long long)plan_nodes_per_block, (long long)npb);
+                  "(gnm_sweep_partition(N, 1))", (long long)plan_nodes_per_block, (long long)npb);
   }
   const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st);
   GNM_LAUNCH_CHECK("edge_bwd_chain");

@@ -1,0 +1,316 @@
+// Two-sided forward sweep of one GatedGCN layer (gfx950, H = 128).
+//
+// The reference aggregates ONE gate twice: by destination on g (gated_gcn_full.py:128-130) and by source on
+// dgl.reverse(g) (:133-143).  edge_gate_fwd_k + node_agg_src_fwd_k did that as two passes: the second re-read the whole
+// e_out [E,H] only to sum, per source, rows the first pass had on chip.  Here ONE destination-sorted sweep forms both:
+//   e_out = relu(bn_e(t)) + e_in;  sigma = sigmoid(e_out)                                             :122-127
+//   hf[v] = sum_in  sigma A2h[src] / (sum_in  sigma + 1e-6)   (rows of v are contiguous)              :128-130
+//   hb[v] = sum_out sigma A3h[dst] / (sum_out sigma + 1e-6)   (rows of v lie in a few nearby tiles)   :141-143
+// through the sweep plan of the graph (gnm_graph_build_sweep_plan): a workgroup owns the rows of a contiguous range of
+// destination nodes and walks them in 16-row tiles, thread (row, 4 columns); the per-edge terms of a tile go to three
+// [16,128] fp32 images in LDS; then every half-wave serves its own row: if the row LEADS its destination (its source) in
+// the tile it adds up the tile's rows of that node, joins the sum carried in the node's accumulator slot and parks it
+// there again or -- last tile of the node -- normalises and stores it.  One owner per node and tile, fixed order of the
+// additions: deterministic, no atomics.  Nodes the plan does not serve (out-edges in more than one workgroup: chunk
+// boundaries, repeat edges; no out-edges) are covered by node_agg_src_fix_k (gathers, a few per cent of the rows);
+// z = A1h + hf + hb and the BatchNorm_h column sums by node_z_stats_k.                                 :145-147
+#include "gnm_tr.h"
+
+namespace gnm {
+
+constexpr int GT = 512;                     // threads per workgroup (8 waves), two workgroups per CU
+constexpr int GR = kSweepTileRows;          // rows per tile
+typedef unsigned int u32x4g_ __attribute__((ext_vector_type(4)));
+
+struct Gate2Args {
+  int64_t N, E;
+  const float* t; const float* e_in; const float* stat; const float* P;
+  const int32_t* isrc; const int32_t* idst; const int32_t* in_ptr;
+  const uint32_t* sinfo; const uint32_t* dinfo;
+  float* e_out; float* hf; float* inv_f; float* hb; float* inv_b;
+  int64_t nodes_per_block, margin;
+};
+
+constexpr int G2_LDS = 3 * GR * SW * 4 + 2 * kSweepSlots * SW * 4 + 2 * 2 * SW * 4 + 2 * SW * 4 + 3 * 4 * GR * 4;
+
+__device__ __forceinline__ u32x4g_ bits4g(const float4& v) {
+  const u32x4g_ b = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                     __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+  return b;
+}
+
+template <bool RES>
+__global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G2_LDS];
+  float* i1 = reinterpret_cast<float*>(lds);          // sigma * A2h[src]
+  float* i2 = i1 + GR * SW;                            // sigma
+  float* i3 = i2 + GR * SW;                            // sigma * A3h[dst]
+  float* sslots = i3 + GR * SW;                        // [2 sums][kSweepSlots][128]
+  float* dslots = sslots + 2 * kSweepSlots * SW;       // [2 sums][2][128]
+  float* cs = dslots + 2 * 2 * SW;                     // scale, shift
+  int* ring = reinterpret_cast<int*>(cs + 2 * SW);     // 3 tiles x [src | dst | sinfo | dinfo] x 16
+  const int tid = threadIdx.x;
+  const int row = tid >> 5, c4 = (tid & 31) * 4;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t v0 = (int64_t)chunk * a.nodes_per_block < a.N ? (int64_t)chunk * a.nodes_per_block : a.N;
+  const int64_t v1 = v0 + a.nodes_per_block < a.N ? v0 + a.nodes_per_block : a.N;
+  const int64_t rb = a.in_ptr[v0], re = a.in_ptr[v1];
+  const int64_t ntile = (re - rb + GR - 1) / GR;
+  for (int c = tid; c < SW; c += GT) {
+    cs[c] = a.stat[2 * SW + c];
+    cs[SW + c] = a.stat[3 * SW + c];
+  }
+  // outputs as buffers: rows outside the range (a lane that has nothing to store carries offset 0x80000000) are dropped
+  const int64_t vbase = v0 - a.margin;
+  const int nspan = (int)(v1 - v0 + 2 * a.margin);
+  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(a.e_out + rb * SW, 0, (int)(re - rb) * SW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hf = __builtin_amdgcn_make_buffer_rsrc(a.hf + v0 * SW, 0, (int)(v1 - v0) * SW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_if = __builtin_amdgcn_make_buffer_rsrc(a.inv_f + v0 * SW, 0, (int)(v1 - v0) * SW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hb = __builtin_amdgcn_make_buffer_rsrc(a.hb + vbase * SW, 0, nspan * SW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ib = __builtin_amdgcn_make_buffer_rsrc(a.inv_b + vbase * SW, 0, nspan * SW * 4, 0x00020000);
+  __syncthreads();
+  if (ntile == 0) return;
+
+  float4 pt, pe_ = f4(0.f);                  // the next tile's rows of t, e_in
+  float4 ga2, ga3;                           // A2h[src], A3h[dst] of this thread's edge
+  int fs = 0, fd = 0;                        // indices / plan words of this thread's row two tiles ahead
+  unsigned fi = 0, fj = 0;
+  const int64_t klast = ntile - 1;
+  auto clamp_row = [&](int64_t k) __attribute__((always_inline)) {
+    const int64_t left = re - (rb + k * GR);
+    const int nv = left < GR ? (int)left : GR;
+    return row < nv ? row : nv - 1;
+  };
+  auto prefetch_idx = [&](int64_t k) __attribute__((always_inline)) {
+    const int cr = clamp_row(k);
+    const int64_t r = rb + k * GR + cr;
+    fs = a.isrc[r];
+    fd = a.idst[r];
+    const unsigned w1 = a.sinfo[r], w2 = a.dinfo[r];
+    fi = cr == row ? w1 : 0u;
+    fj = cr == row ? w2 : 0u;
+  };
+  auto prefetch_rows = [&](int64_t k) __attribute__((always_inline)) {
+    const int64_t o = (rb + k * GR + clamp_row(k)) * SW + c4;
+    pt = ld4_nt(a.t + o);
+    if constexpr (RES) pe_ = ld4_nt(a.e_in + o);
+  };
+  auto gather = [&](int64_t s, int64_t d) __attribute__((always_inline)) {
+    ga2 = ld4(a.P + s * (5 * SW) + SW + c4);
+    ga3 = ld4(a.P + d * (5 * SW) + 2 * SW + c4);
+  };
+  auto ring_put = [&](int64_t k) __attribute__((always_inline)) {
+    if ((tid & 31) == 0) {
+      int* rk = ring + (int)(k % 3) * 4 * GR;
+      rk[row] = fs;
+      rk[GR + row] = fd;
+      rk[2 * GR + row] = (int)fi;
+      rk[3 * GR + row] = (int)fj;
+    }
+  };
+  // sum of the rows `w & 0xffff` of two images, joined with / parked in the node's slot; true: last tile of the node
+  auto run2 = [&](unsigned w, const float* ia, const float* ib, float* sl, int nsl, float4& s1, float4& s2) __attribute__((always_inline)) {
+    unsigned m = w & 0xffffu;
+    s1 = f4(0.f);
+    s2 = f4(0.f);
+    while (m) {
+      const int b = __builtin_ctz(m);
+      m &= m - 1;
+      s1 += ld4(ia + b * SW + c4);
+      s2 += ld4(ib + b * SW + c4);
+    }
+    const bool lead = (w & 0xffffu) != 0;
+    float* p = sl + ((w >> 16) & 63u) * SW + c4;
+    if (lead && !(w & kSweepOpen)) {
+      s1 += ld4(p);
+      s2 += ld4(p + nsl * SW);
+    }
+    if (lead && !(w & kSweepClose)) {
+      st4(p, s1);
+      st4(p + nsl * SW, s2);
+    }
+    return lead && (w & kSweepClose);
+  };
+
+  prefetch_idx(0);
+  ring_put(0);
+  const int s0 = fs, d0 = fd;
+  prefetch_idx(klast < 1 ? klast : 1);
+  prefetch_rows(0);
+  gather(s0, d0);
+  const float4 sc = ld4(cs + c4), sh = ld4(cs + SW + c4);
+  for (int64_t k = 0; k < ntile; ++k) {
+    const int64_t r0 = rb + k * GR;
+    const int nvalid = re - r0 < GR ? (int)(re - r0) : GR;
+    const int* rk = ring + (int)(k % 3) * 4 * GR;
+    // ---- per-edge arithmetic of this thread's row: e_out, sigma, the three images ----
+    {
+      const bool live = row < nvalid;
+      const float4 eo = relu4(fma4(pt, sc, sh)) + pe_;
+      __builtin_amdgcn_raw_buffer_store_b128(bits4g(eo), rs_e, live ? (int)(((k * GR + row) * SW + c4) * 4) : (int)0x80000000, 0, 2);
+      const float4 sg = live ? sigmoid4(eo) : f4(0.f);
+      st4(i1 + row * SW + c4, sg * ga2);
+      st4(i2 + row * SW + c4, sg);
+      st4(i3 + row * SW + c4, sg * ga3);
+      ring_put(k + 1);                             // indices of tile k+1 (requested a tile ago)
+    }
+    __syncthreads();
+    prefetch_idx(k + 2 < klast ? k + 2 : klast);
+    prefetch_rows(k + 1 < klast ? k + 1 : klast);
+    // ---- run sums: this half-wave's row as the leader of its destination, then of its source ----
+    {
+      float4 num, den;
+      bool out = run2((unsigned)rk[3 * GR + row], i1, i2, dslots, 2, num, den);
+      if (__builtin_amdgcn_ballot_w64(out) != 0) {
+        const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen), 1.f / (den.z + kEpsDen),
+                                       1.f / (den.w + kEpsDen));
+        const int o = out ? ((rk[GR + row] - (int)v0) * SW + c4) * 4 : (int)0x80000000;
+        __builtin_amdgcn_raw_buffer_store_b128(bits4g(num * inv), rs_hf, o, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_if, o, 0, 2);
+      }
+      out = run2((unsigned)rk[2 * GR + row], i3, i2, sslots, kSweepSlots, num, den);
+      if (__builtin_amdgcn_ballot_w64(out) != 0) {
+        const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen), 1.f / (den.z + kEpsDen),
+                                       1.f / (den.w + kEpsDen));
+        const int o = out ? ((rk[row] - (int)vbase) * SW + c4) * 4 : (int)0x80000000;
+        __builtin_amdgcn_raw_buffer_store_b128(bits4g(num * inv), rs_hb, o, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_ib, o, 0, 2);
+      }
+    }
+    {                                              // the next tile's node rows (its indices went to the ring before the barrier)
+      const int* rn = ring + (int)((k + 1) % 3) * 4 * GR;
+      gather(rn[row], rn[GR + row]);
+    }
+    __syncthreads();                               // the images are free again
+  }
+}
+
+// hf / inv_f of the nodes WITHOUT in-edges (the sweep only ever stores to nodes that own rows): 0 and 1 / 1e-6
+__global__ __launch_bounds__(256) void gate2_empty_segments_k(int64_t N, const int32_t* __restrict__ in_ptr,
+                                                              float* __restrict__ hf, float* __restrict__ inv_f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int64_t stride = (int64_t)gridDim.x * 4 * 64;
+  for (int64_t base = wave0; base < N; base += stride) {
+    const int64_t v = base + lane;
+    const bool empty = v < N && in_ptr[v + 1] == in_ptr[v];
+    unsigned long long m = __ballot(empty);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int64_t u = base + b;
+      const int c4 = (lane & 31) * 4;
+      if (lane < 32) st4(hf + u * SW + c4, f4(0.f));
+      else st4(inv_f + u * SW + c4, f4(1.f / kEpsDen));
+    }
+  }
+}
+
+// hb / inv_b of the nodes the sweep plan does not serve: node_agg_src_fwd_k's gathers over a node list
+__global__ __launch_bounds__(kBlock, 8) void node_agg_src_fix_k(int64_t nfix, const int32_t* __restrict__ fix_nodes,
+                                                                const float* __restrict__ e_out, const float* __restrict__ P,
+                                                                const int32_t* __restrict__ out_ptr,
+                                                                const int32_t* __restrict__ out_pos,
+                                                                const int32_t* __restrict__ out_dst, float* __restrict__ hb,
+                                                                float* __restrict__ inv_b) {
+  constexpr int H = SW, G = H / 4, RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / G, c4 = (lane % G) * 4;
+  for (int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave; i < nfix; i += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t v = fix_nodes[i];
+    const int a = out_ptr[v], b = out_ptr[v + 1];
+    float4 num = f4(0.f), den = f4(0.f);
+    for (int64_t m = a + sub; m < b; m += RPW) {
+      const int64_t j = out_pos[m], d = out_dst[m];
+      const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
+      num = fma4(sg, ld4(P + d * (5 * H) + 2 * H + c4), num);
+      den += sg;
+    }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+      num += shfl_xor4(num, off);
+      den += shfl_xor4(den, off);
+    }
+    if (sub == 0) {
+      const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen), 1.f / (den.z + kEpsDen),
+                                     1.f / (den.w + kEpsDen));
+      st4_nt(hb + v * H + c4, num * inv);
+      st4_nt(inv_b + v * H + c4, inv);
+    }
+  }
+}
+
+// z = A1h + hf + hb, partial (sum z, sum z^2)                                     gated_gcn_full.py:145-147
+__global__ __launch_bounds__(kBlock) void node_z_stats_k(int64_t N, const float* __restrict__ P, const float* __restrict__ hf,
+                                                         const float* __restrict__ hb, float* __restrict__ z,
+                                                         double* __restrict__ partials, int64_t rows_per_block) {
+  constexpr int H = SW, G = H / 4, RPW = 64 / G;
+  __shared__ double lds[kWavesPerBlock * 2 * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / G, c4 = (lane % G) * 4;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t r0 = (int64_t)chunk * rows_per_block;
+  const int64_t r1 = min(N, r0 + rows_per_block);
+  Stat4 st;
+  st.zero();
+  for (int64_t v = r0 + wave * RPW + sub; v < r1; v += kWavesPerBlock * RPW) {
+    const float4 zz = ld4_nt(P + v * (5 * H) + c4) + ld4_nt(hf + v * H + c4) + ld4_nt(hb + v * H + c4);
+    st4_nt(z + v * H + c4, zz);
+    st.add_prod(zz, zz);
+  }
+  block_stat_store<H>(st, lds, partials, chunk);
+}
+
+}  // namespace gnm
+
+using namespace gnm;
+
+extern "C" int gnm_sweep_partition(int64_t N, int wg_per_cu, int64_t* nodes_per_block, int* grid_out) {
+  GNM_CHECK_ARG(N > 0 && nodes_per_block && wg_per_cu >= 1 && wg_per_cu <= 8, "sweep_partition: bad argument");
+  const int grid = persistent_grid(N, 64, wg_per_cu, 8);     // call cap 8 >= wg_per_cu: the process-wide occupancy knob does not apply
+  *nodes_per_block = (N + grid - 1) / grid;
+  if (grid_out) *grid_out = grid;
+  return 0;
+}
+
+extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* stat_e,
+                                  const float* P, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr,
+                                  const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
+                                  int64_t nfix, const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos,
+                                  const int32_t* out_dst, float* e_out, float* hf, float* inv_f, float* hb, float* inv_b,
+                                  float* z, double* partials, int* nblk_out, void* stream) {
+  GNM_CHECK_ARG(H == SW, "edge_gate2_fwd: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(N > 0 && E > 0 && t && stat_e && P && isrc && idst && in_ptr && sinfo && dinfo && (nfix == 0 || fix_nodes) &&
+                    nfix >= 0 && out_ptr && out_pos && out_dst && e_out && hf && inv_f && hb && inv_b && z && partials &&
+                    nblk_out, "edge_gate2_fwd: null/neg argument");      // e_in == NULL: no residual
+  hipStream_t st = (hipStream_t)stream;
+  Gate2Args a{};
+  a.N = N; a.E = E; a.t = t; a.e_in = e_in; a.stat = stat_e; a.P = P; a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
+  a.sinfo = sinfo; a.dinfo = dinfo; a.e_out = e_out; a.hf = hf; a.inv_f = inv_f; a.hb = hb; a.inv_b = inv_b;
+  a.margin = kSweepMargin;
+  int grid = 0;
+  gnm_sweep_partition(N, 2, &a.nodes_per_block, &grid);
+  GNM_CHECK_ARG(plan_nodes_per_block == a.nodes_per_block, "edge_gate2_fwd: the sweep plan was built for %lld nodes per workgroup, the "
+                "kernel uses %lld (gnm_sweep_partition(N, 2))", (long long)plan_nodes_per_block, (long long)a.nodes_per_block);
+  // 32-bit buffer offsets: the rows of one workgroup (x 512 B) and its node range + margins (x 512 B)
+  GNM_CHECK_ARG((a.nodes_per_block + 2 * kSweepMargin) * SW * 4 < (int64_t)INT32_MAX && E / grid < (1 << 21),
+                "edge_gate2_fwd: a workgroup's share exceeds the 32-bit buffer offsets");
+  hipLaunchKernelGGL(gate2_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, N, in_ptr, hf, inv_f);
+  if (e_in) hipLaunchKernelGGL(edge_gate2_fwd_k<true>, dim3(grid), dim3(GT), 0, st, a);
+  else hipLaunchKernelGGL(edge_gate2_fwd_k<false>, dim3(grid), dim3(GT), 0, st, a);
+  GNM_LAUNCH_CHECK("edge_gate2_fwd");
+  if (nfix > 0) {
+    int64_t g2 = (nfix + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (g2 > cap) g2 = cap;
+    hipLaunchKernelGGL(node_agg_src_fix_k, dim3((int)g2), dim3(kBlock), 0, st, nfix, fix_nodes, e_out, P, out_ptr, out_pos,
+                       out_dst, hb, inv_b);
+    GNM_LAUNCH_CHECK("edge_gate2_fwd fix");
+  }
+  const int gz = persistent_grid(N, 256, occ_blocks<node_z_stats_k>());
+  hipLaunchKernelGGL(node_z_stats_k, dim3(gz), dim3(kBlock), 0, st, N, P, hf, hb, z, partials, (N + gz - 1) / gz);
+  GNM_LAUNCH_CHECK("edge_gate2_fwd z");
+  *nblk_out = gz;
+  return 0;
+}

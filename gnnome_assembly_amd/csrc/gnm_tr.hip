@@ -908,7 +908,7 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   ChainArgs a = in;
   a.Wp = (const bf16x8*)wpack;
   int grid = 0;
-  gnm_sweep_partition(a.N, &a.nodes_per_block, &grid);  // one 512-thread workgroup per CU
+  gnm_sweep_partition(a.N, 1, &a.nodes_per_block, &grid);  // one 512-thread workgroup per CU
   hipLaunchKernelGGL(zero_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo, a.ud_pitch);
 #ifdef GNM_TIMING_ABLATIONS      // builds for timing experiments only: the ablated kernels give wrong results
   static const int abl = getenv("GNM_CHAIN_ABL") ? atoi(getenv("GNM_CHAIN_ABL")) : 0;

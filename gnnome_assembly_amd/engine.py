@@ -325,10 +325,11 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
 
 @on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
 def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True,
-                  residual: bool = True):
+                  residual: bool = True, plan: Optional[dict] = None):
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
     Returns (h_out, e_out, LayerSaved or None).  H = out_channels; h_in [N,Hin], e_in [E,Hin] with Hin != H only
-    when residual is False (the reference drops the residual then: gated_gcn_full.py:41-42)."""
+    when residual is False (the reference drops the residual then: gated_gcn_full.py:41-42).
+    plan (graph.sweep_plan(device, 2), BatchNorm, H = 128): gate + by-source aggregation as ONE two-sided sweep."""
     if residual and h_in.shape[1] != H:
         raise _lib.GnmError("layer_forward: a residual layer needs in_channels == out_channels")
     res_e = _ptr(e_in) if residual else C.c_void_p(0)
@@ -344,7 +345,17 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
     inv_f = torch.empty(N, H, **f32)
-    if batch_norm:
+    two_sided = plan is not None and batch_norm and H == 128 and TWO_SIDED_FWD
+    if two_sided:
+        hb = torch.empty(N, H, **f32)
+        inv_b = torch.empty(N, H, **f32)
+        z = torch.empty(N, H, **f32)
+        stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
+        _call("gnm_edge_gate2_fwd", N, E, H, _ptr(t), res_e, _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),
+              _ptr(idx["in_ptr"]), _ptr(plan["sinfo"]), _ptr(plan["dinfo"]), plan["nodes_per_block"], plan["nfix"],
+              _ptr(plan["fix_nodes"]), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(e_out),
+              _ptr(hf), _ptr(inv_f), _ptr(hb), _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st)
+    elif batch_norm:
         stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
         _call("gnm_edge_gate_fwd", N, E, H, _ptr(t), res_e, _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]),
               _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
@@ -353,12 +364,13 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
         _call("gnm_ln_edge_gate_fwd", N, E, H, _ptr(t), res_e, _ptr(prm.gamma_e), _ptr(prm.beta_e), _ptr(P),
               _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
     # by-source gated mean on the same gate, z, BatchNorm statistics over N (:133-147)
-    hb = torch.empty(N, H, **f32)
-    inv_b = torch.empty(N, H, **f32)
-    z = torch.empty(N, H, **f32)
-    _call("gnm_node_agg_src_fwd", N, E, H, _ptr(e_out), _ptr(P), _ptr(idx["out_ptr"]),
-          _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(hf), _ptr(hb),
-          _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st)
+    if not two_sided:
+        hb = torch.empty(N, H, **f32)
+        inv_b = torch.empty(N, H, **f32)
+        z = torch.empty(N, H, **f32)
+        _call("gnm_node_agg_src_fwd", N, E, H, _ptr(e_out), _ptr(P), _ptr(idx["out_ptr"]),
+              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(hf), _ptr(hb),
+              _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st)
     h_out = torch.empty(N, H, **f32)
     if batch_norm:
         stat_h = bn_finalize(sc.partials, nblk.value, N, H, prm.gamma_h, prm.beta_h)
@@ -483,6 +495,9 @@ CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
 # per-op timing mode always does).
 TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
 TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
+# when the deferred weight-gradient kernel of layer i is launched: "next" = at the head of layer i-1's iteration (beside its
+# by-source pass / conversion), "now" = right after layer i's own by-source pass or conversion (beside nn(i), node(i-1))
+TN_AT = os.environ.get("GNM_TN_AT", "next")
 SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 
 
@@ -491,8 +506,13 @@ SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 # layer -- shrinks to a gather over the few per cent of the nodes the plan does not serve plus an [N,H]-sized conversion
 # once the BatchNorm-backward means are known.  GNM_TWO_SIDED=0 / engine.TWO_SIDED = False keeps the separate pass.
 TWO_SIDED = os.environ.get("GNM_TWO_SIDED", "1") != "0"
-# ... with the by-destination sums as run sums too (no sequential column walk); GNM_RUN_SUMS=0 keeps the walkers
-RUN_SUMS = os.environ.get("GNM_RUN_SUMS", "1") != "0"
+# ... with the by-destination sums as run sums too (no sequential column walk): GNM_RUN_SUMS=1.  Measured SLOWER (chained
+# kernel 7.58 vs 7.22 ms per launch, same box): the walk on three waves overlaps the other waves' next phase 0, run sums
+# on all sixteen half-waves do not.  Kept as an opt-in variant of the kernel.
+RUN_SUMS = os.environ.get("GNM_RUN_SUMS", "0") != "0"
+# the forward twin (gnm_edge_gate2_fwd): gate + by-destination AND by-source aggregation in one sweep; GNM_TWO_SIDED_FWD=0
+# keeps edge_gate_fwd + node_agg_src_fwd
+TWO_SIDED_FWD = os.environ.get("GNM_TWO_SIDED_FWD", "1") != "0"
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
@@ -594,8 +614,20 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
         g["W5"], g["b5"] = tgt(i, "W5", 5 * H, H), tgt(i, "b5", 5 * H)
         gh_in = torch.empty(N, H, **f32)
         ws = sc.ws(max(need_p, need_f))
-        _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
-        if side is not None and i > 0:
+        if not (side is not None and TN_AT == "now"):
+            _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
+        if side is not None and TN_AT == "now":
+            main.wait_stream(side)
+            held.clear()
+            side.wait_stream(main)
+            sc3 = scratch(dev, "tn")
+            ws3 = sc3.ws(need_p)
+            _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc3.partials),
+                                                _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
+                       "gnm_node_proj_bwd_tn")
+            held.extend((gP, s.h_in))
+            _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
+        elif side is not None and i > 0:
             pending = (gP, s.h_in, g["W5"], g["b5"])
         else:
             _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
@@ -822,8 +854,9 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw) if save else None
+    plan2 = graph.sweep_plan(dev, 2) if (TWO_SIDED_FWD and batch_norm and H == 128 and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
-        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm)
+        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2)
         if save:
             ms.layers.append(ls)
     scores, ps = predictor_forward(idx, N, E, H, P["predictor.W1.weight"], P["predictor.W1.bias"],

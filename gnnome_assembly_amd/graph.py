@@ -238,14 +238,15 @@ class AssemblyGraph:
         return self._dev_index[device]
 
 
-    def sweep_plan(self, device=None):
-        """The sweep plan of this graph on `device` (gnm_graph_build_sweep_plan over the partition the sweep kernels use
-        there): dict(sinfo, dinfo [E] int32 tensors holding the plan words, fix_nodes [nfix] int32, nodes_per_block,
+    def sweep_plan(self, device=None, wg_per_cu: int = 1):
+        """The sweep plan of this graph on `device` (gnm_graph_build_sweep_plan over the partition the sweep kernel with
+        `wg_per_cu` workgroups per CU uses there -- 1: the chained backward, 2: the two-sided forward gate): dict(sinfo, dinfo [E] int32 tensors holding the plan words, fix_nodes [nfix] int32, nodes_per_block,
         nfix, peak_live), or None for a graph that was born on a device (its index never visits the host; the
         engine then keeps the separate by-source passes)."""
         device = torch.device(device) if device is not None else self.device
-        if device in self._plans:
-            return self._plans[device]
+        key = (device, wg_per_cu)
+        if key in self._plans:
+            return self._plans[key]
         plan = None
         if (self._src_t is None or self._host_index is not None) and self.num_edges() > 0 and device.type == "cuda":
             lib = _lib.load()
@@ -253,10 +254,10 @@ class AssemblyGraph:
             n, e = self._n, self.num_edges()
             npb, grid = C.c_int64(0), C.c_int(0)
             with torch.cuda.device(device):
-                _lib.check(lib.gnm_sweep_partition(n, C.byref(npb), C.byref(grid)), "gnm_sweep_partition")
+                _lib.check(lib.gnm_sweep_partition(n, wg_per_cu, C.byref(npb), C.byref(grid)), "gnm_sweep_partition")
             plan = build_sweep_plan(h, n, npb.value)
             plan = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
-        self._plans[device] = plan
+        self._plans[key] = plan
         return plan
 
 

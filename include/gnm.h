@@ -91,9 +91,10 @@ int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, int64_t N, 
 int gnm_graph_build_sweep_plan(const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, int64_t N, int64_t E,
                                int64_t nodes_per_block, int tile_rows, int nslots, int64_t margin, uint32_t* sinfo,
                                uint32_t* dinfo, int32_t* fix_nodes, int64_t* nfix_out, int32_t* peak_live_out);
-/* the partition of the sweep kernels on the current device: workgroup w owns the destination nodes
- * [w * nodes_per_block, (w+1) * nodes_per_block); *grid_out (optional) = workgroups launched                  */
-int gnm_sweep_partition(int64_t N, int64_t* nodes_per_block, int* grid_out);
+/* the partition of a sweep kernel on the current device: workgroup w owns the destination nodes
+ * [w * nodes_per_block, (w+1) * nodes_per_block); *grid_out (optional) = workgroups launched.
+ * wg_per_cu: 1 for gnm_edge_bwd_chain_src, 2 for gnm_edge_gate2_fwd (a plan serves ONE partition)            */
+int gnm_sweep_partition(int64_t N, int wg_per_cu, int64_t* nodes_per_block, int* grid_out);
 
 /* ---- greedy decode (HOST pointers, sequential CPU work; inference.py:31-77,182-253) ----------
  * build_adjacency: successors / predecessors of every node in edge-id order, as the reference's
@@ -172,6 +173,16 @@ int gnm_edge_t_stats_fwd(int64_t E, int H, float* t, const float* P, const int32
 int gnm_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in,
                       const float* stat_e, const float* P, const int32_t* isrc,
                       const int32_t* in_ptr, float* e_out, float* hf, float* inv_f, void* stream);
+/* edge_gate2 (H = 128): gnm_edge_gate_fwd AND gnm_node_agg_src_fwd as ONE two-sided sweep over the destination-sorted
+ *   rows (same outputs: e_out, hf, inv_f, hb, inv_b, z, BatchNorm_h partials; e_out is not re-read): the by-source
+ *   sums through the sweep plan (sinfo / dinfo / fix_nodes of gnm_graph_build_sweep_plan over
+ *   gnm_sweep_partition(N, 2)); the plan's fix_nodes are covered by gathers.                         (:122-147) */
+int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* stat_e,
+                       const float* P, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr,
+                       const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block, int64_t nfix,
+                       const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
+                       float* e_out, float* hf, float* inv_f, float* hb, float* inv_b, float* z, double* partials,
+                       int* nblk_out, void* stream);
 /* node_agg_src: hb[v] = sum_{out(v)} sigma*A3h[dst] / (sum sigma + 1e-6), inv_b likewise;
  *               z = A1h + hf + hb; per-block (sum z, sum z^2) -> partials   (:133-145) */
 int gnm_node_agg_src_fwd(int64_t N, int64_t E, int H, const float* e_out, const float* P,
@@ -281,7 +292,7 @@ int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_o
                        int* nblk_out, void* ws, size_t ws_bytes, void* stream);
 /* edge_bwd_chain_src: gnm_edge_bwd_chain as a TWO-SIDED sweep -- layer i-1's by-SOURCE sums (what gnm_edge_bwd_src
  * re-reads e_out, t and ge for) are formed in the same pass from the per-edge terms that are on chip, through the
- * sweep plan (sinfo of gnm_graph_build_sweep_plan, built for plan_nodes_per_block = gnm_sweep_partition's), RAW:
+ * sweep plan (sinfo of gnm_graph_build_sweep_plan, built for plan_nodes_per_block = gnm_sweep_partition(N, 1)'s), RAW:
  *   gP_lo[:,H:2H] = sum_out sigma*Qf[dst],  UT_lo[N,2H] = [ sum_out gu | sum_out that ]    (served sources only)
  * gnm_edge_bwd_src_fix then writes the same three sums for the plan's fix_nodes (gathers; needs layer i-1's
  * e_out, t, stat_e, Q and ge = this call's ge_out), and once layer i-1's BatchNorm-backward means are known
