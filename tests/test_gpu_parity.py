@@ -499,15 +499,74 @@ def test_chr19_scale_step_is_finite_and_self_consistent():
     assert gn2 > 0
     print(f"chr19-scale: E={src.size} loss={loss.item():.6f} |g|^2={gn2:.4e} "
           f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
-    # directional derivative: L(p - eps*g) - L(p) ~= -eps*|g|^2
-    eps = 1e-2 / max(gn2 ** 0.5, 1e-12)
+    # directional derivative along the gradient, central difference (the curvature term cancels, so the step can be
+    # small enough for a 5 % bar and large enough for fp32 losses): L(p - eps*g) - L(p + eps*g) ~= -2*eps*|g|^2
+    eps = 3e-3 / max(gn2 ** 0.5, 1e-12)
     with torch.no_grad():
         for prm in model.parameters():
             prm -= eps * prm.grad
-        l2 = crit(model(g, None, e, pe).squeeze(-1), y).item()
-    pred = -eps * gn2
-    print(f"directional: dL={l2 - loss.item():.4e} predicted={pred:.4e}")
-    assert (l2 - loss.item()) < 0 and abs((l2 - loss.item()) - pred) <= 0.25 * abs(pred) + 2e-6
+        lm = crit(model(g, None, e, pe).squeeze(-1), y).item()
+        for prm in model.parameters():
+            prm += 2 * eps * prm.grad
+        lp = crit(model(g, None, e, pe).squeeze(-1), y).item()
+    pred = -2 * eps * gn2
+    print(f"directional: L(p - eps g) - L(p + eps g) = {lm - lp:.4e} predicted = {pred:.4e}")
+    assert lm < loss.item() < lp and abs((lm - lp) - pred) <= 0.05 * abs(pred) + 2e-6
+
+
+@pytest.mark.default_mode_only
+def test_full_size_logits_match_the_oracle():
+    """Parity AT THE METRIC'S SIZE (BASELINE config 2: R = 750 k, N = 1.5 M, E = 7.54 M, H = 128, L = 8): all E logits of
+    the HIP forward against oracle.model_forward on the host (no_grad; fp64 when the host has the memory for it, else fp32),
+    bar = assert_parity (rtol 1e-4, atol 1e-5, rel-L2 <= 1e-4).  The 1 k-read fixtures cannot exercise BatchNorm sums over
+    7.5 M rows, the int32 / int64 offset arithmetic or the sweep plans at one workgroup per CU; this does.  Run twice on the
+    device: node ids as the generator gives them, and shuffled (the internal renumbering: the same oracle logits apply,
+    logits belong to edges)."""
+    import time
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    from oracle import gatedgcn_oracle as orc
+    dev = _dev()
+    R, H, L, seed = 750000, 128, 8, 0
+    model, src, dst, n, inp = _model_and_inputs(R, H, L, seed, dev)
+    sd = synth.synth_state_dict(H, L, seed)
+    E = int(src.size)
+    model.eval()
+
+    def hip(src_, dst_, pe_np):
+        g = G.AssemblyGraph(src_, dst_, n).to(dev)
+        with torch.no_grad():
+            s = model(g, None, torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(pe_np).to(dev))
+        torch.cuda.synchronize()
+        out = s.squeeze(-1).cpu().numpy()
+        del g, s
+        torch.cuda.empty_cache()
+        return out
+    s_sorted = hip(src, dst, inp["pe"])
+    p = np.random.default_rng(17).permutation(n).astype(np.int32)
+    pe_s = np.empty_like(inp["pe"])
+    pe_s[p] = inp["pe"]
+    s_shuf = hip(p[src], p[dst], pe_s)
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+    except (ValueError, OSError):
+        avail = 0.0
+    dt = torch.float64 if avail > 220 else torch.float32          # ~22 [E,H] tensors alive at the oracle's peak
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = orc.model_forward(sd_to_torch(sd, dt), torch.from_numpy(src), torch.from_numpy(dst), n,
+                                torch.from_numpy(inp["e"]).to(dt), torch.from_numpy(inp["pe"]).to(dt)).squeeze(-1).double().numpy()
+    secs = time.perf_counter() - t0
+    r1, r2 = rel_l2(s_sorted, ref), rel_l2(s_shuf, ref)
+    line = (f"full size E={E} N={n} H={H} L={L}: logits rel_l2 vs the {str(dt).split('.')[-1]} oracle = {r1:.3e} (generator ids), "
+            f"{r2:.3e} (shuffled ids, renumbered); max_abs {np.abs(s_sorted - ref).max():.3e} / {np.abs(s_shuf - ref).max():.3e}; "
+            f"oracle forward {secs:.0f} s on {torch.get_num_threads()} threads, host memory available {avail:.0f} GiB")
+    print(line)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "logit_parity_fullsize.txt"), "w") as f:
+        f.write(line + "\n")
+    assert_parity(s_sorted, ref, "full-size logits, generator ids")
+    assert_parity(s_shuf, ref, "full-size logits, shuffled ids")
 
 
 def test_no_grad_forward_keeps_no_activations():
