@@ -263,7 +263,11 @@ def main():
     if args.matmul:
         G._lib.set_matmul_mode(args.matmul)
     backend_name = None
-    if world > 1:
+    # GNM_FORCE_COLLECTIVE=1: take the distributed path at world size 1 too (process group up, the flat gradient buffer
+    # all-reduced through RCCL, per_rank reported): the 8-GPU node is the driver's, this is how the collective path
+    # gets executed on the one GPU a lease has (tests/test_gpu_dp.py::test_rccl_all_reduce_executes_at_world_size_one)
+    dist_on = world > 1 or dp.FORCE_COLLECTIVE
+    if dist_on:
         dp.init_process_group(os.environ.get("GNM_BENCH_BACKEND", "nccl"))
         backend_name = {"nccl": "RCCL"}.get(dist.get_backend(), dist.get_backend())     # what actually carries the all-reduce
         dbg("process group up")
@@ -306,14 +310,14 @@ def main():
         if args.inference:
             with torch.no_grad():
                 return model(W["graph"], None, W["e"], W["pe"])
-        if world > 1:
+        if dist_on:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         flat.zero_()
         scores = model(W["graph"], None, W["e"], W["pe"])
         loss = W["crit"](scores.squeeze(-1), W["y"])
         loss.backward()
-        if world > 1:
+        if dist_on:
             e1.record()
             own.append((e0, e1))
         flat.all_reduce_mean()
@@ -334,7 +338,7 @@ def main():
     def timed_run(nsteps):
         """EXACTLY nsteps steps between barrier + synchronize on both sides; max over ranks."""
         nonlocal per_rank
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         own.clear()
@@ -342,12 +346,12 @@ def main():
         for _ in range(nsteps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
         tt = torch.tensor([dt_, float(E)], dtype=torch.float64, device=dev)
-        if world > 1:
+        if dist_on:
             tmax = tt[0:1].clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             esum = tt[1:2].clone()
@@ -476,7 +480,7 @@ def main():
             "dtype": "f32 (bf16x3 split products, f32 accumulate)" if mode == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"synthetic chr19-scale assembly graph per GPU: R={R} reads, N={n} nodes, "
                                    f"E={E} edges, hidden={H}, layers={L}, BCE fwd+bwd + Adam"
-                                   + (f", {backend_name} grad all-reduce" if world > 1 else ""),
+                                   + (f", {backend_name} grad all-reduce" if dist_on else ""),
                        "reads": R, "nodes": n, "edges": E, "edges_total": int(total_edges), "hidden": H, "layers": L,
                        "parallelism": f"dp{world}", "edge_layers_per_s": value * L, "matmul": mode,
                        "activations": engine.ACTIVATIONS,
@@ -501,7 +505,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

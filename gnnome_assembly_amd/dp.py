@@ -18,6 +18,8 @@ import torch.distributed as dist
 __all__ = ["init_process_group", "FlatGradients", "shard_graphs", "steps_per_epoch", "fresh_flat_gradients"]
 
 _live = weakref.WeakSet()      # the FlatGradients objects alive in this process
+# GNM_FORCE_COLLECTIVE=1: do not skip the collectives at world size 1 (lets a 1-GPU box execute the RCCL path end to end)
+FORCE_COLLECTIVE = os.environ.get("GNM_FORCE_COLLECTIVE", "0") == "1"
 
 
 def fresh_flat_gradients(params) -> "Optional[FlatGradients]":
@@ -85,6 +87,7 @@ class FlatGradients:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
             o += p.numel()
         self.fresh = True          # all zeros: a kernel may WRITE a gradient instead of accumulating it
+        self.contributors = None   # after all_reduce_mean: how many ranks contributed a graph to the step (device scalar)
         self._ids = {id(p) for p in self.params}
         _live.add(self)
 
@@ -108,11 +111,14 @@ class FlatGradients:
         calls zero_() and all_reduce_mean(contributed=False).  `async_op` is accepted for callers of the round-1
         signature and ignored: the collective is stream-ordered, there is nothing to wait for on the host."""
         self.fresh = False          # the buffer now holds a gradient: the next backward must accumulate, not overwrite
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVE):
             return None
         self.flat[-1] = 1.0 if contributed else 0.0
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.grads.div_(self.flat[-1].clamp(min=1.0))    # a step no rank contributed to leaves a zero gradient, not 0/0
+        # a step no rank contributed to leaves a zero gradient, not 0/0 -- steps_per_epoch keeps that unreachable; the summed
+        # count stays readable (a device scalar: no host sync here) for a caller or a debug run that wants to assert it
+        self.contributors = self.flat[-1].clone()
+        self.grads.div_(self.contributors.clamp(min=1.0))
         return None
 
 
@@ -120,7 +126,7 @@ def steps_per_epoch(local_steps: int, device=None) -> int:
     """The number of optimizer steps EVERY rank takes in an epoch: the maximum of the ranks' local counts
     (shard_graphs gives uneven shards whenever num_graphs % world != 0); shorter ranks pad with
     zero-contribution steps so that the collectives stay matched."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVE):
         return int(local_steps)
     t = torch.tensor([int(local_steps)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

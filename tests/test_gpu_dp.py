@@ -200,3 +200,30 @@ def test_train_loop_under_two_ranks_mixed_chromosomes(tmp_path):
         if not (r <= 2e-4 or r <= 3.0 * r32 + 1e-6 or mx <= max(2e-7, 1e-6 * gmax)):
             bad.append((k, r, r32, mx))
     assert o == z[0]["grad0"].size and not bad, bad
+
+
+def test_rccl_all_reduce_executes_at_world_size_one():
+    """The RCCL path end to end on the hardware a lease has (one GPU; RCCL refuses two ranks on one device): bench.py
+    under torch.distributed.run with ONE rank, backend nccl (= RCCL on ROCm), GNM_FORCE_COLLECTIVE=1 so that the world-size-1
+    shortcuts of dp.py / bench.py are not taken: init_process_group("nccl"), device placement from LOCAL_RANK, the
+    stream-ordered all-reduce of the flat gradient buffer (826,033 + 1 floats at H = 128 / L = 8), barriers, per_rank.
+    NCCL_DEBUG=INFO's tail is kept (gpurun_out/rccl_smoke.log -> profiles/).  The per-graph step this averages over ranks is
+    the reference's train.py:238-258."""
+    port = _free_port()
+    env = dict(os.environ, NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,COLL", GNM_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("GNM_BENCH_DEVICE", None)
+    env.pop("GNM_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--reads", "30000", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-alt-matmul", "--no-alt-orders"]
+    procs, outs = _run_group([cmd], [env], 600)
+    out = outs[0]
+    lines = out.splitlines()
+    nccl = [ln for ln in lines if ("NCCL" in ln or "RCCL" in ln) and " Channel " not in ln]
+    _log("rccl_smoke.log", "\n".join(nccl[:30] + ["..."] + nccl[-60:] + [ln for ln in lines if ln.startswith("{")]))
+    assert procs[0].returncode == 0, out[-4000:]
+    res = json.loads([ln for ln in lines if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and "RCCL grad all-reduce" in res["config"]["workload"], res["config"]["workload"]
+    assert res["per_rank"] and res["per_rank"][0]["edges"] == res["config"]["edges"]
+    assert any("Init COMPLETE" in ln or "init complete" in ln.lower() for ln in nccl), "no RCCL communicator came up"
+    assert any("AllReduce" in ln for ln in nccl) or any("opCount" in ln for ln in nccl), "no RCCL collective in the debug log"
