@@ -86,6 +86,11 @@ def op_model(op: str, N: int, E: int, H: int):
         "gnm_edge_bwd_fused": (4 * eh, 4.0 * E * H * H),                   # ge in/out, t, e_in; NN + TN
         # fused(i) chained with dst(i-1): ge'(i), t(i), e_out(i-1), t(i-1) in; ge'(i-1) out; node rows as edge_bwd_dst
         "gnm_edge_bwd_chain": (5 * eh + 9 * nh, 4.0 * E * H * H),
+        # the two-sided sweep: + Qf[dst] is on chip already; gA2h, Us, Ts out
+        "gnm_edge_bwd_chain_src": (5 * eh + 12 * nh, 4.0 * E * H * H),
+        # gate + both aggregations: t, e_in in; e_out out; A2h, A3h rows in; hf, inv_f, hb, inv_b out; then z: A1h, hf, hb in, z out
+        "gnm_edge_gate2_fwd": (3 * eh + 10 * nh, 0.0),
+        "gnm_node_bgrad": (6 * nh, 0.0),                      # Us, Ts, Ud, Td in; gB1h, gB2h out
         "gnm_node_proj_fwd": (6 * nh, 2.0 * N * H * 5 * H),                # h in, P out
         "gnm_node_proj_bwd_nn": (7 * nh, 2.0 * N * H * 5 * H),             # gP, gh_out in; gh_in out
         "gnm_node_proj_bwd_tn": (6 * nh, 2.0 * N * H * 5 * H),             # gP, h_in in
@@ -112,10 +117,11 @@ def op_model(op: str, N: int, E: int, H: int):
 # The committed PMC pass (tools/collect_traffic.sh + tools/traffic_summary.py): HBM bytes per kernel launch on
 # this workload.  PMC counters cannot be collected from inside this process, so the bench line carries the
 # number together with `traffic_source`; C-ABI op -> rocprof kernel name(s) of the op in each matmul mode.
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 OP_KERNELS = {
     "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_fused_k<MmB3>", "edge_bwd_tr_k"]},
-    "gnm_edge_bwd_chain": ["edge_bwd_chain_k"],
+    "gnm_edge_bwd_chain": ["edge_bwd_chain_k"], "gnm_edge_bwd_chain_src": ["edge_bwd_chain_k"],
+    "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true>"], "gnm_node_bgrad": ["node_bgrad_k<128>"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
     "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128, true>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
     "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3_k"]},
@@ -128,23 +134,31 @@ OP_KERNELS = {
 
 
 def load_traffic(N, E, H, mode):
-    """({op: bytes per launch}, source string) from the committed PMC pass, if it was taken on this workload
-    in this matmul mode; ({}, None) otherwise."""
+    """({op: bytes per launch}, bytes per step or None, source string) from the committed PMC pass -- if it was taken on
+    this workload, in this matmul mode AND on these sources (csrc_sha: a kernel change without a new PMC pass must not
+    report the old bytes); ({}, None, why not) otherwise."""
+    from gnnome_assembly_amd._lib import csrc_sha
     path = os.path.join(REPO, TRAFFIC_FILE)
     try:
         d = json.load(open(path))
     except (OSError, ValueError):
-        return {}, None
+        return {}, None, f"no PMC pass committed ({TRAFFIC_FILE} missing)"
     w = d.get("workload", {})
     if (w.get("edges"), w.get("nodes"), w.get("hidden")) != (E, N, H) or w.get("matmul", "f32") != mode:
-        return {}, None
+        return {}, None, f"{TRAFFIC_FILE} was taken on another workload / matmul mode"
+    sha = csrc_sha()
+    if d.get("csrc_sha") != sha:
+        return {}, None, (f"stale: {TRAFFIC_FILE} was taken on sources {d.get('csrc_sha')}, the library in use is built from "
+                          f"{sha} (re-run tools/collect_traffic.sh)")
     out = {}
     for op, ks in OP_KERNELS.items():
         ks = ks[mode] if isinstance(ks, dict) else ks
         hit = [d["per_launch"][k]["total_gb"] * 1e9 for k in ks if k in d["per_launch"]]
         if hit:
             out[op] = hit[0]
-    return out, f"{TRAFFIC_FILE} @ {d.get('commit', 'unknown commit')} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+    step = d.get("per_step_total_gb")
+    return out, (step * 1e9 if step else None), (f"{TRAFFIC_FILE} @ {d.get('commit', 'unknown commit')}, sources {sha} (rocprofv3 --pmc "
+                                                   "FETCH_SIZE/WRITE_SIZE passes over one bench step, every kernel; FETCH_SIZE x2 per MI355X_MICROARCH.md)")
 
 
 def usable_cores():
@@ -161,7 +175,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(reads, H, L, budget_s=60.0, threads=0, full_reads=750_000):
+def cpu_baseline(reads, H, L, budget_s=240.0, threads=0, full_reads=750_000):
     """fwd+bwd edges/s of the CPU oracle on this host (all cores torch gives us), on a bounded
     sample: the graph is shrunk until one step fits the time budget (edges/s is size-normalised)."""
     from gnnome_assembly_amd import synth
@@ -187,20 +201,22 @@ def cpu_baseline(reads, H, L, budget_s=60.0, threads=0, full_reads=750_000):
         return step, int(src.size), n
 
     # the same graph, or a 1/10-size one (R = 75 k) when a step exceeds 60 s, 1 warm-up + 3 timed steps.
-    # The sample grows geometrically while warm-up + 3 timed steps still fit the budget (host throughput is strongly
-    # size-dependent once the working set leaves the caches, so the next size is priced by the last one measured); the
-    # largest size measured is kept, and the default bench run still ends within minutes.
-    r = min(reads, 4000)
+    # The sample doubles from 1/8 of the requested size while warm-up + 3 timed steps at the NEXT size are predicted to fit
+    # the budget (host throughput is strongly size-dependent once the working set leaves the caches, so a size is priced by
+    # the one measured before it); the largest size measured is kept.
+    r = max(1000, reads // 8)
     while True:
         step, E, n = make(r)
         step()                                   # warm-up at this size
         t0 = time.time()
         step()
         times = [time.time() - t0]
-        elapsed = time.time() - t_start
-        if r >= reads or times[0] > budget_s / 8 or elapsed + 6 * times[0] > budget_s:
+        if r >= reads:
             break
-        r = min(reads, r * 2)
+        nxt = min(reads, 2 * r)
+        if (time.time() - t_start) + 4 * 1.15 * times[0] * nxt / r > budget_s:
+            break
+        r = nxt
     while len(times) < 3 and (time.time() - t_start) + times[0] < budget_s:
         t0 = time.time()
         step()
@@ -215,7 +231,7 @@ def cpu_baseline(reads, H, L, budget_s=60.0, threads=0, full_reads=750_000):
                       f"fwd+bwd, torch-CPU oracle fp32, median of {len(times)} steps after warm-up ({med:.2f} s/step)"}
 
 
-def cpu_baseline_subprocess(args, timeout_s=240):
+def cpu_baseline_subprocess(args, timeout_s=420):
     """Run the CPU leg in its own process with a hard wall-clock bound: the bench line must
     come out within minutes whatever the host does."""
     import subprocess
@@ -443,7 +459,9 @@ def main():
         tot = sum(t for _, t in ops.values())
         ranked = sorted(ops.items(), key=lambda kv: -kv[1][1])
         mm_peak = BF16_MFMA_PEAK / 6 if mode == "bf16x3" else F32_MFMA_PEAK   # fp32-equivalent FLOP/s of the mode
-        traffic, traffic_src = load_traffic(n, E, H, mode)
+        traffic, step_traffic, traffic_src = load_traffic(n, E, H, mode)
+        if args.inference:
+            step_traffic = None
         kernels = []
         for k, (c, tms) in ranked:
             if tms < 0.02 * tot:
@@ -465,13 +483,17 @@ def main():
         per_edge = (12 if args.inference else 32) * H * L          # algorithmic B / edge / step
         alg_bytes = per_edge * total_edges / world                  # per GPU and step
         achieved = alg_bytes / (ms / 1e3)
-        # PMC traffic of one step's modelled kernels (launches x bytes per launch), where the pass has them
-        step_traffic = sum(traffic[k] * c for k, (c, _) in ops.items() if k in traffic) if traffic else None
         roof = {"scope": "whole training step on one GPU (SURVEY.md 8d)" if not args.inference else "whole forward pass",
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "algorithmic_bytes_per_edge_step": per_edge,
                 "traffic": step_traffic, "traffic_source": traffic_src,
                 "kernels": kernels, "dominant_kernel": kernels[0] if kernels else None}
+        if kernels:     # scalars: a parser that keeps only scalar fields still has the kernel-level roofline
+            k0 = kernels[0]
+            roof.update(dominant_kernel_name=k0["op"], dominant_kernel_ms=k0["avg_launch_ms"],
+                        dominant_kernel_launches=k0["launches_per_step"], dominant_kernel_share_of_step=k0["share_of_step"],
+                        dominant_kernel_hbm_frac=k0.get("hbm", {}).get("frac"),
+                        dominant_kernel_traffic_gb=k0.get("traffic_gb"))
         res = {
             "metric": "GatedGCN edges/sec fwd+bwd, chr19 assembly graph" if not args.inference
                       else "GatedGCN edges/sec fwd only (inference)",

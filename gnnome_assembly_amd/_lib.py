@@ -146,3 +146,18 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().gnm_last_error().decode(errors="replace")
         raise GnmError(f"{what or 'libgnm'} failed (rc={rc}): {msg}")
+
+
+def csrc_sha() -> str:
+    """sha256 (16 hex digits) over the library's sources (csrc/* and include/gnm.h, sorted by name): what
+    profiles/*_traffic.json records beside the PMC bytes, so that bench.py can tell a stale pass from a current one."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "gnm.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -10,6 +10,7 @@ back to the caller's edge-id order.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import functools
 import os
@@ -34,6 +35,29 @@ LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
 #            layer's e_out).  Bit-identical results (same kernels, same inputs), about 7 GiB less per layer at the
 #            size above, for two extra kernels per layer (+3.3 ms of 25).
 ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
+
+
+_OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TWO_SIDED", "RUN_SUMS",
+                 "TWO_SIDED_FWD")
+
+
+@contextlib.contextmanager
+def options(**kw):
+    """Temporarily change schedule switches of this module (FUSED, ACTIVATIONS, CHAIN, TN_SIDE, TN_SIDE_CAP, SRC_SIDE_CAP, TN_AT,
+    TWO_SIDED, RUN_SUMS, TWO_SIDED_FWD) and restore them on exit, whatever happens inside:
+        with engine.options(TWO_SIDED=False, CHAIN=False): ...
+    The switches select between schedules that compute the same thing (tests and bench.py A/B them); they are process-wide,
+    read at call time by the thread that runs the pass -- one training loop per process, as everywhere on this path."""
+    bad = [k for k in kw if k not in _OPTION_NAMES]
+    if bad:
+        raise _lib.GnmError(f"engine.options: unknown switch {bad}; known: {_OPTION_NAMES}")
+    g = globals()
+    old = {k: g[k] for k in kw}
+    try:
+        g.update(kw)
+        yield
+    finally:
+        g.update(old)
 
 
 def set_activation_mode(mode: str) -> None:

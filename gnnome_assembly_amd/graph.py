@@ -29,7 +29,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["AssemblyGraph", "from_dgl"]
+__all__ = ["AssemblyGraph", "from_dgl", "as_assembly_graph"]
 
 _INDEX_KEYS = ("perm", "isrc", "idst", "in_ptr", "out_ptr", "out_pos", "out_dst")
 
@@ -190,7 +190,15 @@ class AssemblyGraph:
             mode = self._node_order_mode or NODE_ORDER
             info = {"mode": mode, "relabelled": False}
             order = rank = None
-            if mode == "auto":
+            if self._nrank_t is not None:
+                # born on a device with a GIVEN internal numbering (from_tensors(..., nrank): e.g. the parent's order of a
+                # mini-batch sub-graph): the host index follows it too, so that every device's copy numbers the nodes alike
+                rank = np.ascontiguousarray(self._nrank_t.cpu().numpy(), dtype=np.int32)
+                order = np.ascontiguousarray(np.argsort(rank, kind="stable").astype(np.int32))
+                src, dst = np.ascontiguousarray(rank[src]), np.ascontiguousarray(rank[dst])
+                info = {"mode": "given", "relabelled": True}
+                relabel = False
+            elif mode == "auto":
                 frac = C.c_double(1.0)
                 _lib.check(lib.gnm_graph_edge_locality(ptr(src), ptr(dst), n, e, LOCAL_WINDOW, C.byref(frac)),
                            "gnm_graph_edge_locality")
@@ -287,9 +295,48 @@ def _to_numpy(a):
 
 
 def from_dgl(g):
-    """Adapter for environments where DGL exists: copies structure and ndata/edata."""
+    """An AssemblyGraph with the structure (edge-id order kept) and the ndata / edata of a DGLGraph -- or of anything with
+    that surface: edges() -> (src, dst), num_nodes(), ndata, edata, device (train.py:245,252 / inference.py:446,453 pass
+    such an object to the model).  The result lives on the source graph's device."""
     s, d = g.edges()
     ag = AssemblyGraph(s, d, g.num_nodes())
-    ag.ndata = dict(g.ndata)
-    ag.edata = dict(g.edata)
+    ag.ndata = dict(getattr(g, "ndata", {}))
+    ag.edata = dict(getattr(g, "edata", {}))
+    dev = getattr(g, "device", None)
+    if dev is None and torch.is_tensor(s):
+        dev = s.device
+    return ag.to(dev) if dev is not None and torch.device(dev).type != "cpu" else ag
+
+
+_WRAPPED = {}      # id(foreign graph) -> AssemblyGraph, for graph objects that refuse new attributes
+
+
+def as_assembly_graph(g, device=None):
+    """What the modules call on their `graph` argument: an AssemblyGraph is returned as it is; any other object with the
+    DGLGraph surface (edges(), num_nodes()) is wrapped ONCE (from_dgl: the index is built then) and the wrapper is cached
+    on the object, so the reference's call sites -- model(g, x, e, pe) with a DGLGraph, train.py:252 -- need only the import
+    change.  `device`: where the features of this call live (a foreign graph may not carry a device)."""
+    if isinstance(g, AssemblyGraph):
+        return g
+    ag = getattr(g, "_gnm_graph", None) or _WRAPPED.get(id(g))
+    if ag is None or ag.num_edges() != int(g.num_edges()) or ag.num_nodes() != int(g.num_nodes()):
+        if not (hasattr(g, "edges") and hasattr(g, "num_nodes")):
+            raise TypeError(f"graph argument of type {type(g).__name__} has no edges() / num_nodes()")
+        ag = from_dgl(g)
+        try:
+            g._gnm_graph = ag
+        except AttributeError:
+            import weakref
+            _WRAPPED[id(g)] = ag
+            try:
+                weakref.finalize(g, _WRAPPED.pop, id(g), None)
+            except TypeError:
+                pass
+    if device is not None and torch.device(device) != ag.device:
+        moved = ag.to(device)
+        try:
+            g._gnm_graph = moved
+        except AttributeError:
+            _WRAPPED[id(g)] = moved
+        return moved
     return ag

@@ -7,9 +7,23 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import torch.nn.functional as F
+
 from . import engine
+from .graph import as_assembly_graph
 
 __all__ = ["GatedGCN_1d", "GraphGatedGCN", "ScorePredictor", "NodeEncoder", "EdgeEncoder"]
+
+
+KERNEL_WIDTHS = (32, 64, 128, 256)      # the hidden sizes the row kernels are instantiated for (GNM_DISPATCH_H)
+
+
+def padded_width(width: int) -> int:
+    """The kernel width a layer of `width` output channels runs on: itself, or the next one up with dead channels."""
+    for w in KERNEL_WIDTHS:
+        if width <= w:
+            return w
+    raise NotImplementedError(f"hidden width {width}: the HIP kernels are built for widths up to {KERNEL_WIDTHS[-1]}")
 
 
 def _params_of(module: nn.Module, prefix: str = ""):
@@ -81,8 +95,8 @@ class GatedGCN_1d(nn.Module):
         super().__init__()
         if not 0 <= dropout < 1:
             raise ValueError(f"GatedGCN_1d: dropout={dropout}")
-        if out_channels not in (32, 64, 128, 256):
-            raise NotImplementedError(f"GatedGCN_1d: out_channels={out_channels}: the HIP kernels are built for 32, 64, 128, 256")
+        padded_width(out_channels)           # any width up to 256 (gated_gcn_full.py:44-50 takes any): others run zero-padded
+        self.in_channels, self.out_channels = in_channels, out_channels
         self.dropout = dropout
         self.batch_norm = batch_norm
         # gated_gcn_full.py:41-42: a layer that changes the width silently drops the residual.  The model never builds
@@ -94,10 +108,23 @@ class GatedGCN_1d(nn.Module):
         self.bn_e = _Norm(out_channels)
 
     def forward(self, g, h, e):
+        g = as_assembly_graph(g, h.device)
         P = dict(self.named_parameters())
         flat = [P[k] for k in _LAYER_KEYS]
         need = torch.is_grad_enabled() and any(t.requires_grad for t in [h, e] + flat)
+        W, Wp = self.out_channels, padded_width(self.out_channels)
+        if Wp != W:
+            # run the next kernel width up with dead output channels (zero weight rows, bias 0, norm weight 1 / bias 0); with
+            # the residual (in == out) the inputs get the same dead channels.  autograd slices everything back.
+            d = Wp - W
+            di = d if self.residual else 0
+            flat = [F.pad(t, (0, di, 0, d)) if t.dim() == 2 else
+                    F.pad(t, (0, d), value=1.0 if k in ("bn_h.weight", "bn_e.weight") else 0.0) for k, t in zip(_LAYER_KEYS, flat)]
+            if di:
+                h, e = F.pad(h, (0, di)), F.pad(e, (0, di))
         h, e = _LayerFn.apply(g, need, bool(self.batch_norm), self.residual, h, e, *flat)
+        if Wp != W:
+            h, e = h[:, :W], e[:, :W]
         if self.dropout and self.training:
             # gated_gcn_full.py:154: dropout on the node output only, after the residual.  Never enabled by the model
             # (processor.py:12 passes no dropout), so it is not fused: the mask comes from torch's generator on h's device
@@ -115,6 +142,7 @@ class GraphGatedGCN(nn.Module):
         ])
 
     def forward(self, graph, h, e):
+        graph = as_assembly_graph(graph, h.device)
         for conv in self.convs:
             h, e = conv(graph, h, e)
         return h, e
@@ -157,7 +185,14 @@ class ScorePredictor(nn.Module):
         self.W2 = nn.Linear(hidden_edge_scores, 1)
 
     def forward(self, graph, x, e):
-        ts = (x, e, self.W1.weight, self.W1.bias, self.W2.weight, self.W2.bias)
+        graph = as_assembly_graph(graph, x.device)
+        W1 = self.W1.weight
+        H = x.shape[1]
+        Hp = padded_width(H)
+        if Hp != H:                           # dead input channels: zero columns in each of W1's three H-wide blocks
+            x, e = F.pad(x, (0, Hp - H)), F.pad(e, (0, Hp - H))
+            W1 = F.pad(W1.reshape(W1.shape[0], 3, H), (0, Hp - H)).reshape(W1.shape[0], 3 * Hp)
+        ts = (x, e, W1, self.W1.bias, self.W2.weight, self.W2.bias)
         need = torch.is_grad_enabled() and any(t.requires_grad for t in ts)
         return _PredFn.apply(graph, need, *ts)
 

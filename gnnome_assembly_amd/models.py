@@ -4,7 +4,10 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import torch.nn.functional as F
+
 from . import dp, engine, layers
+from .graph import as_assembly_graph
 
 __all__ = ["GraphGatedGCNModel", "BCEWithLogitsLoss", "flatten_parameters"]
 
@@ -91,6 +94,21 @@ class _ModelFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None) + tuple(G[k] for k in ctx.names)
 
 
+def _pad_param(name: str, v: torch.Tensor, H: int, Hp: int) -> torch.Tensor:
+    """One parameter of a width-H model as the parameter of the width-Hp model whose extra channels are dead."""
+    d = Hp - H
+    leaf = name.split(".")[-2] if "." in name else name
+    if name.startswith("predictor.W1.weight"):                     # [hs, 3H]: three H-wide blocks (x[src] | x[dst] | e)
+        return F.pad(v.reshape(v.shape[0], 3, H), (0, d)).reshape(v.shape[0], 3 * Hp)
+    if name.startswith(("predictor.", "linear1_edge.")):
+        return v
+    if name.startswith(("linear_pe.", "linear2_edge.")):           # [H, in] / [H]: new output rows
+        return F.pad(v, (0, 0, 0, d)) if v.dim() == 2 else F.pad(v, (0, d))
+    if leaf in ("bn_h", "bn_e"):
+        return F.pad(v, (0, d), value=1.0 if name.endswith("weight") else 0.0)
+    return F.pad(v, (0, d, 0, d)) if v.dim() == 2 else F.pad(v, (0, d))     # [H, H] layer weights, [H] biases
+
+
 class GraphGatedGCNModel(nn.Module):
     """models/full_graph.py:11-29.  forward(graph, x, e, pe) -> scores [E,1] (edge-id order).
 
@@ -115,6 +133,17 @@ class GraphGatedGCNModel(nn.Module):
         return flatten_parameters(self)
 
     def forward(self, graph, x, e, pe):
+        graph = as_assembly_graph(graph, pe.device)       # a DGLGraph(-like) object is wrapped once and cached on itself
+        H = self.linear_pe.out_features
+        Hp = layers.padded_width(H)
+        if Hp != H:
+            # a width the kernels are not built for (they are for 32 / 64 / 128 / 256): run the next one up with zero-padded
+            # parameters -- the extra channels stay exactly zero through every layer (t = 0 -> bn -> relu -> 0; their gates
+            # are 0.5 and gate zeros) and autograd slices the gradients back out of the padded tensors
+            names, flat = zip(*self.named_parameters())
+            padded = tuple(_pad_param(k, v, H, Hp) for k, v in zip(names, flat))
+            need = torch.is_grad_enabled() and any(p.requires_grad for p in flat)
+            return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, self.batch_norm, *padded)
         if pe.is_cuda and not _is_flat(self):
             flatten_parameters(self)          # once per device placement: stacked-parameter views instead of torch.cat
         names, flat = zip(*self.named_parameters())

@@ -167,8 +167,9 @@ def test_layer_kernels_vs_oracle(fname):
         _, _, g64, dbg = orc.manual_forward_backward(
             p64, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(z["e_raw"]).double(),
             torch.from_numpy(z["pe"]).double(), torch.from_numpy(z["y"]).double(), float(z["pos_weight"]), keep=True)
-    graph = AssemblyGraph(src, dst, n).to(dev)
+    graph = AssemblyGraph(src, dst, n, node_order="keep").to(dev)     # the engine-level calls below take node rows as they are
     idx = graph.index()
+    assert "nperm" not in idx
     perm = idx["perm"].long().cpu()
     E = src.size
     li = L - 1          # check the last layer (its incoming gradients come straight from the predictor)
@@ -419,6 +420,91 @@ def test_standalone_modules_match_oracle():
     _report(rows, "standalone.txt")
     bad = [r for r in rows if r[1] > GRAD_L2]
     assert not bad, bad
+
+
+def test_odd_hidden_width_runs_zero_padded():
+    """nn.Linear(in, out) of the reference takes any width (gated_gcn_full.py:44-50); the row kernels are instantiated for
+    32 / 64 / 128 / 256.  A width in between (96) runs on the next one up with dead channels: model logits, loss and every
+    parameter gradient against the fp64 oracle at the usual bars, state_dict shapes untouched."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    from oracle import gatedgcn_oracle as orc
+    dev = _dev()
+    H, L, seed = 96, 2, 13
+    src, dst, n = synth.make_graph(400, seed, permute_edge_ids=True)
+    inp = synth.make_inputs(src, dst, n, seed)
+    sd = synth.synth_state_dict(H, L, seed)
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.to(dev)
+    assert model.gnn.convs[0].A_1.weight.shape == (H, H)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    e, pe, y = (torch.from_numpy(inp[k]).to(dev) for k in ("e", "pe", "y"))
+    s = model(g, None, e, pe)
+    loss = G.BCEWithLogitsLoss(float(inp["pos_weight"]))(s.squeeze(-1), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    p64 = sd_to_torch(sd, torch.float64, requires_grad=True)
+    ts, td = torch.from_numpy(src), torch.from_numpy(dst)
+    r = orc.model_forward(p64, ts, td, n, torch.from_numpy(inp["e"]).double(), torch.from_numpy(inp["pe"]).double())
+    l64 = orc.bce_loss(r, torch.from_numpy(inp["y"]).double(), float(inp["pos_weight"]))
+    l64.backward()
+    assert_parity(s.detach().cpu().numpy(), r.detach().numpy(), "H=96 logits")
+    assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item()) + 1e-7
+    p32 = sd_to_torch(sd, torch.float32, requires_grad=True)
+    orc.bce_loss(orc.model_forward(p32, ts, td, n, torch.from_numpy(inp["e"]), torch.from_numpy(inp["pe"])),
+                 torch.from_numpy(inp["y"]), float(inp["pos_weight"])).backward()
+    gmax = max(float(v.grad.norm()) for v in p64.values())
+    bad = []
+    for k, prm in model.named_parameters():
+        assert prm.grad.shape == p64[k].grad.shape
+        want = p64[k].grad.numpy()
+        ro = rel_l2(prm.grad.cpu().numpy(), want)
+        rr = rel_l2(p32[k].grad.double().numpy(), want)
+        if not _grad_ok(ro, rr, float(np.abs(prm.grad.cpu().numpy() - want).max()), GRAD_ABS_FLOOR * max(gmax, 1.0)):
+            bad.append((k, ro, rr))
+    assert not bad, bad
+    # the stand-alone layer at an odd width, residual on (in == out == 48 -> padded to 64)
+    lay = G.layers.GatedGCN_1d(48, 48, True).to(dev)
+    rng = np.random.default_rng(4)
+    h0 = torch.from_numpy(rng.standard_normal((n, 48)).astype(np.float32))
+    e0 = torch.from_numpy(rng.standard_normal((src.size, 48)).astype(np.float32))
+    h1, e1 = lay(g, h0.to(dev), e0.to(dev))
+    lsd = {"gnn.convs.0." + k: v.detach().cpu().double() for k, v in lay.state_dict().items()}
+    rh, re = orc.layer_forward(lsd, 0, ts.long(), td.long(), n, h0.double(), e0.double())
+    assert h1.shape == (n, 48) and e1.shape == (src.size, 48)
+    assert_parity(h1.detach().cpu().numpy(), rh.numpy(), "H=48 layer h", l2=2e-5)
+    assert_parity(e1.detach().cpu().numpy(), re.numpy(), "H=48 layer e", l2=2e-5)
+
+
+@pytest.mark.mode_independent
+def test_model_accepts_a_dgl_graph_object():
+    """train.py:252 calls model(g, x, e, pe) with the DGLGraph itself: any object with edges() / num_nodes() is wrapped once
+    (graph.as_assembly_graph) -- here the DGL stand-in the golden vectors were generated with; logits bit-equal to the
+    AssemblyGraph built directly, the wrapper (and its index) is reused by the second call."""
+    import sys
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dgl_standin"))
+    try:
+        import dgl
+    finally:
+        sys.path.pop(0)
+    dev = _dev()
+    src, dst, n = synth.make_graph(300, 2, permute_edge_ids=True)
+    inp = synth.make_inputs(src, dst, n, 2)
+    model = G.GraphGatedGCNModel(1, 2, 64, 16, 2, 64, True, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(64, 2, 2).items()})
+    model.to(dev).eval()
+    e, pe = torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(inp["pe"]).to(dev)
+    dg = dgl.DGLGraph(src, dst, n)
+    with torch.no_grad():
+        s_ref = model(G.AssemblyGraph(src, dst, n).to(dev), None, e, pe)
+        s_dgl = model(dg, None, e, pe)
+        w = dg._gnm_graph
+        s_dgl2 = model(dg, None, e, pe)
+    assert torch.equal(s_ref, s_dgl) and torch.equal(s_dgl, s_dgl2) and dg._gnm_graph is w
+    assert w.device == dev and dev in w._dev_index
 
 
 # -----------------------------------------------------------------------------------------
@@ -971,16 +1057,13 @@ def test_chained_backward_matches_the_layer_by_layer_backward():
     crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
 
     def run(chain):
-        old, engine.CHAIN = engine.CHAIN, chain
-        try:
+        with engine.options(CHAIN=chain):
             model.zero_grad(set_to_none=True)
             s = model(g, None, e, pe)
             loss = crit(s.squeeze(-1), y)
             loss.backward()
             torch.cuda.synchronize()
             return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
-        finally:
-            engine.CHAIN = old
     s0, l0, g0 = run(False)
     s1, l1, g1 = run(True)
     assert torch.equal(s0, s1) and l0 == l1
@@ -1021,16 +1104,13 @@ def test_two_sided_sweep_matches_the_separate_by_source_pass(ids):
     print(f"sweep plan [{ids}]: {plan['nfix']} of {n} nodes left to the fix-up pass, peak live slots {plan['peak_live']}")
 
     def run(two_sided):
-        old, engine.TWO_SIDED = engine.TWO_SIDED, two_sided
-        try:
+        with engine.options(TWO_SIDED=two_sided):
             model.zero_grad(set_to_none=True)
             s = model(g, None, e, pe)
             loss = crit(s.squeeze(-1), y)
             loss.backward()
             torch.cuda.synchronize()
             return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
-        finally:
-            engine.TWO_SIDED = old
     s0, l0, g0 = run(False)
     s1, l1, g1 = run(True)
     s2, l2, g2 = run(True)
@@ -1072,16 +1152,13 @@ def test_two_sided_forward_sweep_matches_the_separate_passes(ids):
     print(f"forward sweep plan [{ids}]: {plan['nfix']} of {n} nodes left to the fix-up pass, peak live slots {plan['peak_live']}")
 
     def run(two_sided):
-        old, engine.TWO_SIDED_FWD = engine.TWO_SIDED_FWD, two_sided
-        try:
+        with engine.options(TWO_SIDED_FWD=two_sided):
             model.zero_grad(set_to_none=True)
             s = model(g, None, e, pe)
             loss = crit(s.squeeze(-1), y)
             loss.backward()
             torch.cuda.synchronize()
             return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
-        finally:
-            engine.TWO_SIDED_FWD = old
     s0, l0, g0 = run(False)
     s1, l1, g1 = run(True)
     s2, l2, g2 = run(True)
@@ -1205,17 +1282,13 @@ def test_side_stream_schedule_and_per_call_caps_change_nothing_but_rounding():
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in model.named_parameters()}
     base = run()
-    keep = (engine.TN_SIDE, engine.TN_SIDE_CAP, engine.SRC_SIDE_CAP)
-    try:
-        for setting in ((False, 0, 0), (True, 1, 2), (True, 2, 8)):
-            engine.TN_SIDE, engine.TN_SIDE_CAP, engine.SRC_SIDE_CAP = setting
+    for setting in ((False, 0, 0, "next"), (True, 1, 2, "next"), (True, 2, 8, "now"), (True, 0, 4, "now")):
+        with engine.options(TN_SIDE=setting[0], TN_SIDE_CAP=setting[1], SRC_SIDE_CAP=setting[2], TN_AT=setting[3]):
             co, co2 = run(), run()
-            for k in base:
-                assert torch.equal(co[k], co2[k]), (setting, k)                    # still deterministic
-                d = float((co[k] - base[k]).abs().max())
-                assert d <= 1e-5 * float(base[k].abs().max()) + 1e-9, (setting, k, d)
-    finally:
-        engine.TN_SIDE, engine.TN_SIDE_CAP, engine.SRC_SIDE_CAP = keep
+        for k in base:
+            assert torch.equal(co[k], co2[k]), (setting, k)                    # still deterministic
+            d = float((co[k] - base[k]).abs().max())
+            assert d <= 1e-5 * float(base[k].abs().max()) + 1e-9, (setting, k, d)
 
 
 @pytest.mark.mode_independent

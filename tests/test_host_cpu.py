@@ -95,8 +95,10 @@ def test_module_surface_and_state_dict_schema():
     wide = G.layers.GatedGCN_1d(32, 64, True)                         # in != out: the residual is dropped (gated_gcn_full.py:41-42)
     assert wide.residual is False and wide.B_3.weight.shape == (64, 32)
     assert G.layers.GatedGCN_1d(32, 32, True, residual=False).residual is False
+    assert G.layers.GatedGCN_1d(32, 48, True).B_3.weight.shape == (48, 32)     # any width up to 256 (run zero-padded to 64)
+    assert G.layers.padded_width(96) == 128 and G.layers.padded_width(128) == 128
     with pytest.raises(NotImplementedError):
-        G.layers.GatedGCN_1d(32, 48, True)                             # output widths the kernels are not built for
+        G.layers.GatedGCN_1d(32, 300, True)                            # wider than the widest kernel instantiation
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -153,6 +155,17 @@ def test_tensor_index_equals_host_index():
         for k, v in want.items():
             assert np.array_equal(g.index()[k].numpy(), v), k
         assert np.array_equal(g._src, np.asarray(src, np.int32))        # lazy host copy
+        # a GIVEN internal numbering (mini-batch sub-graphs inherit the parent's): the host index follows it as the
+        # device-side index does, whichever of the two is built first
+        rank = torch.from_numpy(np.random.default_rng(3).permutation(int(n)).astype(np.int32))
+        s_t, d_t = torch.from_numpy(np.asarray(src, np.int32)), torch.from_numpy(np.asarray(dst, np.int32))
+        dev_first = AssemblyGraph.from_tensors(s_t, d_t, int(n), nrank=rank).index()
+        host_first = AssemblyGraph.from_tensors(s_t, d_t, int(n), nrank=rank)
+        hidx = host_first.host_index()
+        assert set(hidx) == set(dev_first)
+        for k, v in hidx.items():
+            assert np.array_equal(dev_first[k].numpy(), v), k
+        assert all(np.array_equal(host_first.index()[k].numpy(), v) for k, v in hidx.items())
 
 
 def test_graph_file_round_trip(tmp_path):
@@ -179,3 +192,34 @@ def test_graph_file_round_trip(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         io.load_graph(str(tmp_path / "bad.npz"))
+
+
+def test_from_dgl_and_foreign_graph_wrapping():
+    """from_dgl / as_assembly_graph against the committed DGL stand-in (tests/golden/dgl_standin: the graph type the golden
+    vectors were generated with): structure in edge-id order, ndata / edata carried over, the wrapper is built once and
+    cached on the foreign object (train.py:252 passes the DGLGraph itself to the model)."""
+    import sys
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import synth
+    from gnnome_assembly_amd.graph import as_assembly_graph
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dgl_standin"))
+    try:
+        import dgl
+    finally:
+        sys.path.pop(0)
+    s, d, n = synth.tiny_edge_case_graph(1)
+    dg = dgl.DGLGraph(s, d, n)
+    dg.ndata["x"] = torch.ones(n, 1)
+    dg.edata["y"] = torch.arange(s.size, dtype=torch.float32)
+    ag = G.from_dgl(dg)
+    ss, dd = ag.edges()
+    assert ag.num_nodes() == n and ag.num_edges() == s.size
+    assert np.array_equal(ss.numpy(), s) and np.array_equal(dd.numpy(), d)
+    assert torch.equal(ag.ndata["x"], dg.ndata["x"]) and torch.equal(ag.edata["y"], dg.edata["y"])
+    ref = G.AssemblyGraph(s, d, n).host_index()
+    got = ag.host_index()
+    assert all(np.array_equal(ref[k], got[k]) for k in ref)
+    w1 = as_assembly_graph(dg)
+    assert as_assembly_graph(dg) is w1 and as_assembly_graph(w1) is w1
+    with pytest.raises(TypeError):
+        as_assembly_graph(object())

@@ -27,7 +27,7 @@ def main():
     H = a.hidden
     src, dst, n = synth.make_graph(a.reads, 0)
     E = src.size
-    g = G.AssemblyGraph(src, dst, n).to(dev)
+    g = G.AssemblyGraph(src, dst, n, node_order="keep").to(dev)     # engine-level calls: node rows as they are
     idx = g.index()
     sd = {k: torch.from_numpy(v).to(dev) for k, v in synth.synth_state_dict(H, 1, 0).items()}
     prm = engine.layer_params(sd, 0)
