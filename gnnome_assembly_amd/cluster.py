@@ -12,7 +12,8 @@ values, train.py:301-305).
 
 METIS lives inside DGL and is not available here, so the PARTITIONER is this module's own (parity
 with METIS's particular cut is unpinned and not attempted): overlap graphs of a chromosome are
-nearly one-dimensional, so a reverse Cuthill-McKee ordering of the symmetrised graph (scipy) cut
+nearly one-dimensional, so a breadth-first (Cuthill-McKee) ordering of the symmetrised graph -- the one
+the graph index numbers its nodes by, gnm_graph_locality_order -- cut
 into equal contiguous blocks gives balanced parts whose edge cut is the band width per boundary.
 Repeat-induced long-range edges would fold that ordering; they are recognised by having no common
 neighbour and left out of the ordering (not out of the graph).
@@ -33,7 +34,7 @@ NID = "_ID"     # dgl.NID / dgl.EID: original ids of a subgraph's nodes / edges
 EID = "_ID"
 
 
-def node_order(graph: AssemblyGraph, method: str = "rcm") -> np.ndarray:
+def node_order(graph: AssemblyGraph, method: str = "locality") -> np.ndarray:
     """The 1-D node ordering the parts are cut from (cached on the graph: only the number of parts
     changes between epochs, train.py:291)."""
     cache = graph.__dict__.setdefault("_node_order", {})
@@ -41,6 +42,22 @@ def node_order(graph: AssemblyGraph, method: str = "rcm") -> np.ndarray:
         n = graph.num_nodes()
         if method == "order":
             cache[method] = np.arange(n, dtype=np.int64)
+        elif method == "locality":
+            # the same order the graph index numbers its nodes by (gnm_graph_locality_order, host C++, linear in E:
+            # breadth-first over the triangle-supported overlaps from a pseudo-peripheral node of every component)
+            idx = graph.host_index() if graph._host_index is not None or graph._src_t is None else None
+            if idx is not None and "nperm" in idx:
+                cache[method] = idx["nperm"].astype(np.int64)           # the index has it already
+            else:
+                import ctypes as C
+                from . import _lib
+                lib = _lib.load()
+                src, dst = np.ascontiguousarray(graph._src, np.int32), np.ascontiguousarray(graph._dst, np.int32)
+                order, rank = np.empty(n, np.int32), np.empty(n, np.int32)
+                ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+                _lib.check(lib.gnm_graph_locality_order(ptr(src), ptr(dst), n, src.size, ptr(order), ptr(rank), None),
+                           "gnm_graph_locality_order")
+                cache[method] = order.astype(np.int64)
         elif method == "rcm":
             import scipy.sparse as sp
             from scipy.sparse.csgraph import reverse_cuthill_mckee
@@ -63,9 +80,11 @@ def node_order(graph: AssemblyGraph, method: str = "rcm") -> np.ndarray:
     return cache[method]
 
 
-def partition_graph(graph: AssemblyGraph, num_parts: int, method: str = "rcm") -> np.ndarray:
+def partition_graph(graph: AssemblyGraph, num_parts: int, method: str = "locality") -> np.ndarray:
     """part[v] in [0, num_parts) for every node; parts are balanced to within one node.
-    method 'rcm': contiguous blocks of a reverse Cuthill-McKee ordering (default);
+    method 'locality': contiguous blocks of the index's own breadth-first order (default; host C++, linear in E);
+           'rcm': contiguous blocks of scipy's reverse Cuthill-McKee ordering (the round-1 partitioner: E-sized sparse
+                  products, kept for comparison);
            'order': contiguous blocks of the node ids themselves (reads already position-sorted)."""
     n = graph.num_nodes()
     if num_parts < 1:

@@ -40,7 +40,7 @@ def get_hyperparameters() -> Dict:
         "hidden_edge_features": 16, "hidden_edge_scores": 64, "num_gnn_layers": 16, "nb_pos_enc": 16,
         "batch_size_train": 1, "batch_size_eval": 1, "patience": 2, "decay": 0.95, "batch_norm": True,
         # only read when batch_size_* > 1 (hyperparameters.py:15-18 has 500 / 500 / 50 / 50)
-        "num_parts_metis_train": 500, "num_parts_metis_eval": 500, "partition_method": "rcm",
+        "num_parts_metis_train": 500, "num_parts_metis_eval": 500, "partition_method": "locality",
     }
 
 

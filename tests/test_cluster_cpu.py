@@ -15,7 +15,7 @@ def _graph(reads=400, seed=3, shuffle_nodes=False):
     return AssemblyGraph(src, dst, n), src, dst, n
 
 
-@pytest.mark.parametrize("method", ["rcm", "order"])
+@pytest.mark.parametrize("method", ["locality", "rcm", "order"])
 @pytest.mark.parametrize("parts", [1, 7, 50])
 def test_partition_is_balanced_total_and_deterministic(method, parts):
     g, src, dst, n = _graph()
@@ -31,10 +31,12 @@ def test_rcm_recovers_the_band_when_node_ids_are_shuffled():
     g, src, dst, n = _graph(reads=1500, shuffle_nodes=True)
     e = src.size
     cut_rcm = cluster.edge_cut(g, cluster.partition_graph(g, 20, "rcm"))
+    cut_loc = cluster.edge_cut(g, cluster.partition_graph(g, 20, "locality"))
     cut_ids = cluster.edge_cut(g, cluster.partition_graph(g, 20, "order"))
-    print(f"edge cut: rcm {cut_rcm}/{e}  node-id blocks {cut_ids}/{e}")
+    print(f"edge cut: locality {cut_loc}/{e}  rcm {cut_rcm}/{e}  node-id blocks {cut_ids}/{e}")
     assert cut_ids > 0.8 * e          # shuffled ids: almost every edge is cut
     assert cut_rcm < 0.12 * e         # the ordering finds the 1-D structure again
+    assert cut_loc < 0.12 * e         # ... and so does the index's own breadth-first order (the default: host C++, linear in E)
     g2, *_ = _graph(reads=1500)
     assert cluster.edge_cut(g2, cluster.partition_graph(g2, 20, "order")) < 0.08 * e
 
