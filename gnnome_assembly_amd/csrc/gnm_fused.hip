@@ -1673,6 +1673,37 @@ static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, flo
   return gnm_reduce_partials(partials_hi, grid, 1, FH, gb3_hi, stream) ? -3 : 0;
 }
 
+// the top of the stack: gnm_edge_bwd_dst (+ the by-source sums through the sweep plan) on the chained kernel's sweep
+extern "C" int gnm_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const float* e_out, const float* t,
+                                const float* stat_e, const float* P, const float* Q, const float* hf, const float* hb,
+                                const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, float* gP, float* Ud,
+                                float* Td, double* partials, const uint32_t* sinfo, int64_t plan_nodes_per_block,
+                                float* UT, int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "edge_bwd_top: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(N > 0 && E > 0 && ge && e_out && t && stat_e && P && Q && hf && hb && isrc && idst && in_ptr && gP && Ud &&
+                    Td && partials && nblk_out && (!sinfo || UT), "edge_bwd_top: null argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "edge_bwd_top: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  ChainArgs a{};
+  a.E = E; a.N = N;
+  a.ge = ge; a.ge_out = ge; a.e_mid = e_out;                     // t_hi == NULL selects the sweep without a layer above
+  a.slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  a.t_lo = t; a.stat_lo = stat_e; a.P_lo = P; a.Q_lo = Q; a.hf_lo = hf; a.hb_lo = hb;
+  a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
+  a.gP_lo = gP; a.Ud_lo = Ud; a.Td_lo = Td; a.partials_lo = partials;
+  a.sinfo = sinfo; a.UT_lo = UT; a.margin = kSweepMargin;
+  a.ud_pitch = Td == Ud + FH ? 2 * FH : FH;
+  int64_t npb = 0;
+  gnm_sweep_partition(N, 1, &npb, nullptr);
+  GNM_CHECK_ARG((npb + 2 * kSweepMargin) * 5 * FH * 4 < (int64_t)INT32_MAX, "edge_bwd_top: %lld nodes per workgroup exceed the 32-bit buffer offsets",
+                (long long)npb);
+  GNM_CHECK_ARG(!sinfo || plan_nodes_per_block == npb, "edge_bwd_top: the sweep plan was built for %lld nodes per workgroup, the kernel uses %lld",
+                (long long)plan_nodes_per_block, (long long)npb);
+  *nblk_out = edge_bwd_chain_launch(a, nullptr, nullptr, (hipStream_t)stream);
+  GNM_LAUNCH_CHECK("edge_bwd_top");
+  return 0;
+}
+
 extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
                                   const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
                                   const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,

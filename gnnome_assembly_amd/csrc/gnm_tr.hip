@@ -443,7 +443,9 @@ struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][
 // contiguous, two slots alternate for the run that crosses a tile boundary) by the half-wave of the run's first row: the
 // sequential column walk -- 16 dependent steps per tile on three waves while the other five wait at the next barrier --
 // is gone; all sixteen half-waves serve their own row's destination and source.
-template <int ABL, int SRC, bool WSKIP = true>
+// HI = false: no layer i above (the TOP layer of the stack: ge is d loss / d e_out of layer i-1 as the predictor's backward
+// left it): phase 0 only parks the rows, no gt, no MFMAs, no gW3 -- the sweep is edge_bwd_dst_k (+ the by-source sums).
+template <int ABL, int SRC, bool WSKIP = true, bool HI = true>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   constexpr bool RUN = SRC == 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds[RUN ? CH_LDS_RUN : SRC ? CH_LDS_SRC : CH_LDS];
@@ -474,20 +476,22 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   const int64_t ntile = (re - rb + ER - 1) / ER;
   const int row = tid >> 5, lc4 = (tid & 31) * 4;                        // this thread's row of every tile
   for (int c = tid; c < SW; c += CT) {
-    cs[c] = a.stat_hi[c];
-    cs[SW + c] = a.stat_hi[SW + c];
-    cs[2 * SW + c] = a.stat_hi[2 * SW + c];
-    cs[3 * SW + c] = a.stat_hi[3 * SW + c];
-    cs[4 * SW + c] = a.bstat_hi[c];
-    cs[5 * SW + c] = a.bstat_hi[SW + c];
-    cs[6 * SW + c] = a.gamma_hi[c] * a.stat_hi[SW + c];
+    if constexpr (HI) {
+      cs[c] = a.stat_hi[c];
+      cs[SW + c] = a.stat_hi[SW + c];
+      cs[2 * SW + c] = a.stat_hi[2 * SW + c];
+      cs[3 * SW + c] = a.stat_hi[3 * SW + c];
+      cs[4 * SW + c] = a.bstat_hi[c];
+      cs[5 * SW + c] = a.bstat_hi[SW + c];
+      cs[6 * SW + c] = a.gamma_hi[c] * a.stat_hi[SW + c];
+    }
     cl[c] = a.stat_lo[c];
     cl[SW + c] = a.stat_lo[SW + c];
     cl[2 * SW + c] = a.stat_lo[2 * SW + c];
     cl[3 * SW + c] = a.stat_lo[3 * SW + c];
   }
   W3Frag16 wf;
-  {
+  if constexpr (HI) {
     const bf16x8* p = a.Wp + ((int64_t)wave * (SW / 32) * 3) * 64 + lane;
 #pragma unroll
     for (int kc = 0; kc < SW / 32; ++kc)
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     const int64_t r0 = rb + k * ER;
     const int o = clamp_row(k) * SW + lc4;
     pg = ld4(a.ge + r0 * SW + o);
-    pt = ld4(a.t_hi + r0 * SW + o);
+    if constexpr (HI) pt = ld4(a.t_hi + r0 * SW + o);
     pe_ = ld4(a.e_mid + r0 * SW + o);
     pl = ld4_nt(a.t_lo + r0 * SW + o);
   };
@@ -622,12 +626,14 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       st4(og + row * EOP + lc4, pg);
       st4(tl + row * SW + lc4, pl);
       st4(ef + row * SW + lc4, pe_);                  // for the sigmoid of the by-destination pass (cheaper than re-joining the split images)
-      const float4 gu = gate4(fma4(pt, sc, sh), pg);
-      float4 gt = cc * (gu - m1 - ((pt - mu) * rs) * m2);
-      if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
-      cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
-      simg_stage(ig, EIMG, row, lc4, gt);
-      simg_stage(ie, EIMG, row, lc4, pe_);
+      if constexpr (HI) {
+        const float4 gu = gate4(fma4(pt, sc, sh), pg);
+        float4 gt = cc * (gu - m1 - ((pt - mu) * rs) * m2);
+        if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
+        cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
+        simg_stage(ig, EIMG, row, lc4, gt);
+        simg_stage(ie, EIMG, row, lc4, pe_);
+      }
       if ((tid & 31) == 0) {                        // indices of tile k+1 (requested a tile ago) -> ring
         int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
         sdn[row] = fs;
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     prefetch_rows(k + 1 < klast ? k + 1 : klast);
     __builtin_amdgcn_sched_barrier(0);
     // ---- TN: gW3[n][c] += sum_rows gt[row][n] e[row][c], this wave's 64 x 32 block (transpose reads) ----
-    if (!(ABL & 4)) {
+    if (HI && !(ABL & 4)) {
       int tr0 = trq0, tr1 = trq1;
       asm volatile("" : "+v"(tr0), "+v"(tr1));
       bf16x8 fa[2][3];
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       }
     }
     // ---- NN: acc = gt W3 (16 rows x this wave's 16 columns), joined with the residual rows in og ----
-    if (!(ABL & 4)) {
+    if (HI && !(ABL & 4)) {
       floatx4_acc acc;
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] = 0.f;
@@ -833,14 +839,16 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     // read by the SAME thread (same row / column mapping) or before this tile's second barrier (gt images)
   }
 
-  float* sl = a.slab + (size_t)chunk * SW * SW;
+  if constexpr (HI) {
+    float* sl = a.slab + (size_t)chunk * SW * SW;
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = (2 * wn + x) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-      sl[m * SW + wc * 32 + li] = tn[x][e];
-    }
+      for (int e = 0; e < 16; ++e) {
+        const int m = (2 * wn + x) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+        sl[m * SW + wc * 32 + li] = tn[x][e];
+      }
+  }
   __syncthreads();
   {   // BatchNorm column sums of layer i-1: eight row-pair groups (waves 2, 3, 6, 7) -> one row of partials_lo
     double* bnr = reinterpret_cast<double*>(lds);      // [8 groups][2][128] doubles = 16 KB (the images are dead)
@@ -861,6 +869,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     }
     __syncthreads();
   }
+  if constexpr (!HI) return;
   double* red = reinterpret_cast<double*>(lds);          // 16 row slots x 128 columns = 16 KB (the images are dead)
   red[row * SW + lc4 + 0] = cg0;
   red[row * SW + lc4 + 1] = cg1;
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const in
 
 // returns the grid size (= number of gW3 slabs / partial rows of both kinds)
 int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st) {
-  hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
+  if (W3) hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   ChainArgs a = in;
   a.Wp = (const bf16x8*)wpack;
   int grid = 0;
@@ -920,6 +929,11 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
     default: break;
   }
 #endif
+  if (!a.t_hi) {                                     // top of the stack: the sweep without a layer above
+    if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, 1, true, false>), dim3(grid), dim3(CT), 0, st, a);
+    else hipLaunchKernelGGL((edge_bwd_chain_k<0, 0, true, false>), dim3(grid), dim3(CT), 0, st, a);
+    return grid;
+  }
   if (a.sinfo && a.dinfo && chain_variant() == 0) hipLaunchKernelGGL((edge_bwd_chain_k<0, 2>), dim3(grid), dim3(CT), 0, st, a);   // run sums both ways
   else if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, 1>), dim3(grid), dim3(CT), 0, st, a);     // column walk + by-source run sums
   else hipLaunchKernelGGL((edge_bwd_chain_k<0, 0>), dim3(grid), dim3(CT), 0, st, a);

@@ -592,11 +592,24 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     i = L - 1
     prm, s = ensure(i)
     gP, Q = node(i, gh)
-    Ud, Td = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
     nblk = C.c_int(0)
-    _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
-          _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
-          _ptr(sc.partials), C.byref(nblk), st)
+    UT = None                   # two-sided sweep: the raw by-source sums [Us | Ts] of the current layer (None: src(i) forms them)
+    if plan is None:
+        Ud, Td = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
+        _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
+              _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+              _ptr(sc.partials), C.byref(nblk), st)
+    else:                       # the top layer on the same two-sided sweep as the chained kernel (no layer above)
+        UT = torch.empty(N, 2 * H, **f32)
+        DT = torch.empty(N, 2 * H, **f32)
+        Ud, Td = DT[:, :H], DT[:, H:]
+        ws = sc.ws(max(need_p, need_f))
+        _call("gnm_edge_bwd_top", N, E, H, _ptr(ge), _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(s.P), _ptr(Q), _ptr(s.hf),
+              _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+              _ptr(sc.partials), _ptr(plan["sinfo"]), plan["nodes_per_block"], _ptr(UT), C.byref(nblk), _ptr(ws), need_f, st)
+        _call("gnm_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s.e_out), _ptr(s.t),
+              _ptr(s.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
+              _ptr(gP), _ptr(UT), st)
     if ACTIVATIONS == "lean":
         s.P = None              # as below: only the by-destination pass reads the rebuilt P
     # not in the lean mode: the deferred kernel keeps its gP (one [E,H]-sized tensor) alive one layer longer
@@ -604,7 +617,6 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     main = torch.cuda.current_stream()
     pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
     held: List[torch.Tensor] = []   # what the side stream is reading; dropped only after the main stream has waited for it
-    UT = None                   # two-sided sweep: the raw by-source sums [Us | Ts] of the current layer (None: src(i) forms them)
     while True:
         prm, s = prms[i], saved[i]
         o = outs[i] or {}

@@ -309,6 +309,14 @@ int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* 
                            const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
                            const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block, float* UT_lo,
                            int* nblk_out, void* ws, size_t ws_bytes, void* stream);
+/* edge_bwd_top: the top layer of the stack (no layer above to chain with): gnm_edge_bwd_dst on the chained kernel's sweep
+ * (ge updated in place to ge + gsigma*sigma', gP[:,2H:3H], Ud, Td, BatchNorm_e backward partials) plus, with sinfo, the
+ * by-source sums exactly as gnm_edge_bwd_chain_src leaves them (then gnm_edge_bwd_src_fix, gnm_node_bgrad).          */
+int gnm_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const float* e_out, const float* t, const float* stat_e,
+                     const float* P, const float* Q, const float* hf, const float* hb, const int32_t* isrc,
+                     const int32_t* idst, const int32_t* in_ptr, float* gP, float* Ud, float* Td, double* partials,
+                     const uint32_t* sinfo, int64_t plan_nodes_per_block, float* UT, int* nblk_out, void* ws,
+                     size_t ws_bytes, void* stream);
 int gnm_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int64_t N, int64_t E, int H, const float* e_out,
                          const float* t, const float* stat_e, const float* ge, const float* Q, const int32_t* out_ptr,
                          const int32_t* out_pos, const int32_t* out_dst, float* gP, float* UT, void* stream);
