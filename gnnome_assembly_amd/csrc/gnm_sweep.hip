@@ -71,7 +71,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   __syncthreads();
   if (ntile == 0) return;
 
-  float4 pt, pe_ = f4(0.f);                  // the next tile's rows of t, e_in
+  float4 ptA, peA = f4(0.f), ptB, peB = f4(0.f);   // rows of t, e_in: two tiles in flight (even / odd tiles)
   float4 ga2, ga3;                           // A2h[src], A3h[dst] of this thread's edge
   int fs = 0, fd = 0;                        // indices / plan words of this thread's row two tiles ahead
   unsigned fi = 0, fj = 0;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     fi = cr == row ? w1 : 0u;
     fj = cr == row ? w2 : 0u;
   };
-  auto prefetch_rows = [&](int64_t k) __attribute__((always_inline)) {
+  auto prefetch_rows = [&](int64_t k, float4& pt, float4& pe_) __attribute__((always_inline)) {
     const int64_t o = (rb + k * GR + clamp_row(k)) * SW + c4;
     pt = ld4_nt(a.t + o);
     if constexpr (RES) pe_ = ld4_nt(a.e_in + o);
@@ -136,10 +136,13 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   ring_put(0);
   const int s0 = fs, d0 = fd;
   prefetch_idx(klast < 1 ? klast : 1);
-  prefetch_rows(0);
+  prefetch_rows(0, ptA, peA);
+  prefetch_rows(klast < 1 ? klast : 1, ptB, peB);
   gather(s0, d0);
   const float4 sc = ld4(cs + c4), sh = ld4(cs + SW + c4);
-  for (int64_t k = 0; k < ntile; ++k) {
+  // one tile; its rows are in (pt, pe_), which are refilled with the rows of tile k + 2 behind the first barrier: the row
+  // streams are requested TWO tiles ahead (one tile's run sums + barriers are shorter than the HBM latency under load)
+  auto tile = [&](int64_t k, float4& pt, float4& pe_) __attribute__((always_inline)) {
     const int64_t r0 = rb + k * GR;
     const int nvalid = re - r0 < GR ? (int)(re - r0) : GR;
     const int* rk = ring + (int)(k % 3) * 4 * GR;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     }
     __syncthreads();
     prefetch_idx(k + 2 < klast ? k + 2 : klast);
-    prefetch_rows(k + 1 < klast ? k + 1 : klast);
+    prefetch_rows(k + 2 < klast ? k + 2 : klast, pt, pe_);
     // ---- run sums: this half-wave's row as the leader of its destination, then of its source ----
     {
       float4 num, den;
@@ -182,6 +185,10 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
       gather(rn[row], rn[GR + row]);
     }
     __syncthreads();                               // the images are free again
+  };
+  for (int64_t k = 0; k < ntile; k += 2) {
+    tile(k, ptA, peA);
+    if (k + 1 < ntile) tile(k + 1, ptB, peB);
   }
 }
 

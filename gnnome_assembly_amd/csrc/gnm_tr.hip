@@ -754,10 +754,6 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         s_gut[2] += (double)x.z * (double)th.z; s_gut[3] += (double)x.w * (double)th.w;
       }
     }
-    if constexpr (SRC == 1) {                      // issued BEFORE the run sums: the next tile's per-edge phase waits on these
-      const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
-      gather(sdn[row], sdn[ER + row]);
-    }
     if constexpr (SRC) {
       // one run sum: the rows `m` of the three images, joined with / parked in the slot, or (last tile) handed back for the store
       auto run3 = [&](unsigned w, const float* i1, const float* i2, const float* i3, float* sl, int nsl, float4& s1, float4& s2,
@@ -799,7 +795,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         const int sn = sdk[rr] - (int)vbase;
         const int og_ = out ? (sn * (5 * SW) + wc4) * 4 : (int)0x80000000;
         const int ou_ = out ? (sn * (2 * SW) + wc4) * 4 : (int)0x80000000;
-        if (__builtin_amdgcn_ballot_w64(out) != 0) {
+        if (!(ABL & 16) && __builtin_amdgcn_ballot_w64(out) != 0) {
           __builtin_amdgcn_raw_buffer_store_b128(bits4(s1), srs_g, og_, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(bits4(s2), srs_u, ou_, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(bits4(s3), srs_u, ou_, SW * 4, 0);
@@ -820,17 +816,64 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
           }
           by_source(row, si[(int)(k % 3) * ER + row]);
         }
-      } else if (!(ABL & 1) && wave >= 3) {           // beside the column walk: half-wave q serves the tile rows q and q + 10
+      } else if (!(ABL & 1) && !(ABL & 8) && wave >= 3) {   // beside the column walk: half-wave q serves the tile rows q and q + 10
+        // The two rows of a half-wave are served TOGETHER, every LDS read issued unconditionally and up front -- the plan
+        // words, then the leader's own row of the three images and the slot contents for both rows (12 + 12 independent
+        // reads), a loop only for the rare further rows of a run -- so that the phase is three LDS round trips long instead
+        // of ten: served one after the other through data-dependent loops it was 0.68 ms of the kernel (ablation, r04).
         const int q = (tid - 192) >> 5;                // 0 .. 9
         const unsigned* sik = si + (int)(k % 3) * ER;
+        const int rr[2] = {q, (q + 10) & (ER - 1)};
+        unsigned w[2] = {sik[rr[0]], q + 10 < ER ? sik[rr[1]] : 0u};
+        float4 s1[2], s2[2], s3[2], p1[2], p2[2], p3[2];
+        unsigned m[2];
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const int rr = q + 10 * pass;
-          by_source(rr & (ER - 1), rr < ER ? sik[rr & (ER - 1)] : 0u);
+        for (int u = 0; u < 2; ++u) {
+          m[u] = w[u] & 0xffffu;
+          const int b = rr[u];                         // a leader's first row is its own
+          s1[u] = ld4(v5 + b * SW + wc4);
+          s2[u] = ld4(v2 + b * SW + wc4);
+          s3[u] = ld4(v3 + b * SW + wc4);
+          const float* p = slots + ((w[u] >> 16) & (kSweepSlots - 1)) * SW + wc4;
+          p1[u] = ld4(p);
+          p2[u] = ld4(p + kSweepSlots * SW);
+          p3[u] = ld4(p + 2 * kSweepSlots * SW);
+          m[u] &= m[u] - 1;                            // (0 stays 0)
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          while (m[u]) {                               // further rows of the run (a source with several edges into this tile)
+            const int b = __builtin_ctz(m[u]);
+            m[u] &= m[u] - 1;
+            s1[u] += ld4(v5 + b * SW + wc4);
+            s2[u] += ld4(v2 + b * SW + wc4);
+            s3[u] += ld4(v3 + b * SW + wc4);
+          }
+          const bool lead = (w[u] & 0xffffu) != 0;
+          if (lead && !(w[u] & kSweepOpen)) {
+            s1[u] += p1[u];
+            s2[u] += p2[u];
+            s3[u] += p3[u];
+          }
+          float* p = slots + ((w[u] >> 16) & (kSweepSlots - 1)) * SW + wc4;
+          if (lead && !(w[u] & kSweepClose)) {
+            st4(p, s1[u]);
+            st4(p + kSweepSlots * SW, s2[u]);
+            st4(p + 2 * kSweepSlots * SW, s3[u]);
+          }
+          const bool out = lead && (w[u] & kSweepClose);
+          const int sn = sdk[rr[u]] - (int)vbase;
+          const int og_ = out ? (sn * (5 * SW) + wc4) * 4 : (int)0x80000000;
+          const int ou_ = out ? (sn * (2 * SW) + wc4) * 4 : (int)0x80000000;
+          if (!(ABL & 16) && __builtin_amdgcn_ballot_w64(out) != 0) {
+            __builtin_amdgcn_raw_buffer_store_b128(bits4(s1[u]), srs_g, og_, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(bits4(s2[u]), srs_u, ou_, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(bits4(s3[u]), srs_u, ou_, SW * 4, 0);
+          }
         }
       }
     }
-    if constexpr (SRC != 1) {                      // the next tile's node rows, through the ring (written before this tile's first barrier)
+    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
     }
@@ -926,6 +969,9 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
     case 2: hipLaunchKernelGGL((edge_bwd_chain_k<2, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
     case 4: hipLaunchKernelGGL((edge_bwd_chain_k<4, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
     case 7: hipLaunchKernelGGL((edge_bwd_chain_k<7, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 8: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<8, 1>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
+    case 16: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<16, 1>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
+    case 9: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<9, 1>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
     default: break;
   }
 #endif
