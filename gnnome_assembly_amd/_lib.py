@@ -63,7 +63,7 @@ SIGNATURES = {
     "gnm_node_proj_bwd_nn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_tn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _i32, _p]),
     "gnm_edge_bwd_chain": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_pi, _p, _sz, _p]),
-    "gnm_edge_bwd_chain_src": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_p, _p, _i64, _p] + [_pi, _p, _sz, _p]),
+    "gnm_edge_bwd_chain_src": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_p, _i64, _p] + [_pi, _p, _sz, _p]),
     "gnm_edge_bwd_top": (_i32, [_i64, _i64, _i32] + [_p] * 15 + [_p, _i64, _p, _pi, _p, _sz, _p]),
     "gnm_edge_bwd_src_fix": (_i32, [_i64, _p, _i64, _i64, _i32] + [_p] * 10 + [_p]),
     "gnm_node_bgrad": (_i32, [_i64, _i32] + [_p] * 9 + [_p]),

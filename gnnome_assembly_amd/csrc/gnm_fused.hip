@@ -1632,7 +1632,7 @@ static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, flo
                                const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
                                const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
                                const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
-                               const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block, float* UT_lo,
+                               const uint32_t* sinfo, int64_t plan_nodes_per_block, float* UT_lo,
                                int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(H == FH, "edge_bwd_chain: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(g_matmul_mode == 1, "edge_bwd_chain: only built for the bf16x3 matmul mode");
@@ -1652,9 +1652,8 @@ static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, flo
   a.t_lo = t_lo; a.stat_lo = stat_lo; a.P_lo = P_lo; a.Q_lo = Q_lo; a.hf_lo = hf_lo; a.hb_lo = hb_lo;
   a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
   a.gP_lo = gP_lo; a.Ud_lo = Ud_lo; a.Td_lo = Td_lo; a.partials_lo = partials_lo;
-  a.sinfo = sinfo; a.UT_lo = UT_lo; a.margin = kSweepMargin; a.dinfo = dinfo;
+  a.sinfo = sinfo; a.UT_lo = UT_lo; a.margin = kSweepMargin;
   a.ud_pitch = Td_lo == Ud_lo + FH ? 2 * FH : FH;       // [Ud | Td] as one [N,2H] array, or two [N,H] arrays
-  GNM_CHECK_ARG(!dinfo || a.ud_pitch == 2 * FH, "edge_bwd_chain_src: with dinfo, Ud_lo / Td_lo must be the halves of one [N,2H] array");
   int64_t npb = 0;
   gnm_sweep_partition(N, 1, &npb, nullptr);      // one 512-thread workgroup per CU
   // the walkers' / run sums' rows are addressed through 32-bit buffer offsets over the workgroup's node range
@@ -1713,7 +1712,7 @@ extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, 
                                   int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
   return edge_bwd_chain_impl(N, E, H, ge, ge_out, t_hi, e_mid, stat_hi, bstat_hi, gamma_hi, W3_hi, gW3_hi, gb3_hi, partials_hi,
                              t_lo, stat_lo, P_lo, Q_lo, hf_lo, hb_lo, isrc, idst, in_ptr, gP_lo, Ud_lo, Td_lo, partials_lo,
-                             nullptr, nullptr, 0, nullptr, nblk_out, ws, ws_bytes, stream);
+                             nullptr, 0, nullptr, nblk_out, ws, ws_bytes, stream);
 }
 
 extern "C" int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
@@ -1722,12 +1721,12 @@ extern "C" int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* 
                                       const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
                                       const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
                                       const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
-                                      const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
+                                      const uint32_t* sinfo, int64_t plan_nodes_per_block,
                                       float* UT_lo, int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(sinfo, "edge_bwd_chain_src: sinfo is null");
   return edge_bwd_chain_impl(N, E, H, ge, ge_out, t_hi, e_mid, stat_hi, bstat_hi, gamma_hi, W3_hi, gW3_hi, gb3_hi, partials_hi,
                              t_lo, stat_lo, P_lo, Q_lo, hf_lo, hb_lo, isrc, idst, in_ptr, gP_lo, Ud_lo, Td_lo, partials_lo,
-                             sinfo, dinfo, plan_nodes_per_block, UT_lo, nblk_out, ws, ws_bytes, stream);
+                             sinfo, plan_nodes_per_block, UT_lo, nblk_out, ws, ws_bytes, stream);
 }
 
 extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void) {

@@ -153,9 +153,8 @@ struct ChainArgs {
   int64_t nodes_per_block;
   // two-sided sweep (edge_bwd_chain_k<., true>): the by-SOURCE sums of layer i-1 through the sweep plan
   // (gnm_graph_build_sweep_plan over THIS partition): gA2h -> gP_lo[:,H:2H], Us | Ts -> UT_lo [N,2H]
-  // RUN variant: the by-destination sums through dinfo as well (no column walk); Ud_lo / Td_lo are then the two halves of
-  // ONE [N,2H] array (ud_pitch = 2H; H for two separate arrays)
-  const uint32_t* sinfo; float* UT_lo; int64_t margin; const uint32_t* dinfo; int ud_pitch;
+  // Ud_lo / Td_lo may be the two halves of ONE [N,2H] array (ud_pitch = 2H) or two [N,H] arrays (ud_pitch = H)
+  const uint32_t* sinfo; float* UT_lo; int64_t margin; int ud_pitch;
 };
 
 constexpr int kSweepTileRows = 16;      // rows per tile of the sweep kernels (= ER of gnm_tr.hip)

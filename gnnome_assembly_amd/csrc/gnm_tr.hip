@@ -424,10 +424,8 @@ typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 constexpr int CH_LDS = 6 * EIMG + ER * EOP * 4 + 7 * SW * 4 + 4 * SW * 4 + 5 * ER * SW * 4 + 3 * 2 * ER * 4;
 // two-sided sweep: + ring of the plan words, the sigma * Qf[dst] image, three accumulator slot arrays (gA2h, Us, Ts)
 constexpr int CH_LDS_SRC = CH_LDS + 3 * ER * 4 + ER * SW * 4 + 3 * kSweepSlots * SW * 4;
-// ... + ring of the destination plan words, two x three accumulator slots of the by-destination sums
-constexpr int CH_LDS_RUN = CH_LDS_SRC + 3 * ER * 4 + 3 * 2 * SW * 4 + 64;
 static_assert(ER == kSweepTileRows, "the sweep plan is built for the chained kernel's tile");
-static_assert(CH_LDS % 16 == 0 && CH_LDS_SRC % 16 == 0 && CH_LDS_RUN <= 160 * 1024, "LDS layout");
+static_assert(CH_LDS % 16 == 0 && CH_LDS_SRC <= 160 * 1024, "LDS layout");
 
 struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][hi/mid/lo] = 48 VGPRs
 
@@ -439,16 +437,15 @@ struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][
 // the sum carried in the source's accumulator slot and either parks it there again or, in the source's last tile, stores
 // it.  One owner per source and tile, fixed order: deterministic, no atomics.  The stores are unconditional buffer stores
 // (offset out of range unless the leader closes its source), like the walkers'.
-// SRC = 2: the by-DESTINATION sums (gA3h, Ud, Td) are taken the same way (dinfo of the plan; a destination's rows are
-// contiguous, two slots alternate for the run that crosses a tile boundary) by the half-wave of the run's first row: the
-// sequential column walk -- 16 dependent steps per tile on three waves while the other five wait at the next barrier --
-// is gone; all sixteen half-waves serve their own row's destination and source.
+// (Taking the by-DESTINATION sums the same way -- run sums on all sixteen half-waves instead of the column walk on three waves --
+// was built and measured twice this round, with data-dependent loops and with up-front predicated reads: 7.58 / 7.55 ms per
+// launch against 7.15 with the walk.  The walk's three waves overlap the other five's next phase 0; run sums on every wave do
+// not.  Not shipped.)
 // HI = false: no layer i above (the TOP layer of the stack: ge is d loss / d e_out of layer i-1 as the predictor's backward
 // left it): phase 0 only parks the rows, no gt, no MFMAs, no gW3 -- the sweep is edge_bwd_dst_k (+ the by-source sums).
-template <int ABL, int SRC, bool WSKIP = true, bool HI = true>
+template <int ABL, bool SRC, bool WSKIP = true, bool HI = true>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
-  constexpr bool RUN = SRC == 2;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[RUN ? CH_LDS_RUN : SRC ? CH_LDS_SRC : CH_LDS];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SRC ? CH_LDS_SRC : CH_LDS];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
   float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // residual ge rows, then ge + gt W3 (row layout)
@@ -463,8 +460,6 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   unsigned* si = reinterpret_cast<unsigned*>(sd + 3 * 2 * ER);           // SRC: ring of 3 tiles x [plan word 16]
   float* v5 = reinterpret_cast<float*>(si + 3 * ER);                     // SRC: sigma * Qf[dst]
   float* slots = v5 + ER * SW;                                           // SRC: [3 sums][kSweepSlots][128]
-  float* dslots = slots + 3 * kSweepSlots * SW;                          // RUN: [3 sums][2][128]
-  unsigned* di = reinterpret_cast<unsigned*>(dslots + 3 * 2 * SW);       // RUN: ring of 3 tiles x [destination plan word 16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -514,7 +509,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
   // (round 3: one role per WAVE -- lanes 0-31 of waves 0, 1, 2 -- so that the walkers' output is a wave-uniform buffer
   //  resource; the BatchNorm sums moved to waves 4-7)
-  const bool walker = !RUN && wave < 3 && lane < 32, bnsum = tid >= 256;   // BatchNorm sums: waves 4-7, two rows of a tile each
+  const bool walker = wave < 3 && lane < 32, bnsum = tid >= 256;   // BatchNorm sums: waves 4-7, two rows of a tile each
   const int role = wave, wc4 = (tid & 31) * 4;
   const int brow = 2 * ((tid - 256) >> 5);                         // first of this thread's two rows (0, 2, .. 14)
   int cur = -1;                             // node whose segment is being summed (wave-uniform)
@@ -538,18 +533,12 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       SRC ? a.gP_lo + vbase * (5 * SW) + SW : a.gP_lo, 0, SRC ? nspan * 5 * SW * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t srs_u = __builtin_amdgcn_make_buffer_rsrc(
       SRC ? a.UT_lo + vbase * (2 * SW) : a.gP_lo, 0, SRC ? nspan * 2 * SW * 4 : 0, 0x00020000);
-  // RUN: the by-destination sums' rows over this workgroup's own node range: gP_lo[:,2H:3H] and [Ud | Td] (one [N,2H] array)
-  const __amdgpu_buffer_rsrc_t drs_g = __builtin_amdgcn_make_buffer_rsrc(
-      a.gP_lo + v0 * (5 * SW) + 2 * SW, 0, RUN ? (int)(v1n - v0) * 5 * SW * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t drs_u = __builtin_amdgcn_make_buffer_rsrc(
-      a.Ud_lo + v0 * (2 * SW), 0, RUN ? (int)(v1n - v0) * 2 * SW * 4 : 0, 0x00020000);
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
   float4 ga2, gqb, ghb, gqf, ghf, ga3;       // the node rows of this thread's edge: A2h[s] Qb[s] hb[s] | Qf[d] hf[d] A3h[d]
   int fs = 0, fd = 0;                        // source / destination node of this thread's row TWO tiles ahead (in flight)
   unsigned fi = 0;                           // SRC: its plan word (0 for the clamped rows past the chunk)
-  unsigned fj = 0;                           // RUN: its destination plan word
   // Software pipeline (every request is issued a full tile before its first use; sd is a ring of three tiles):
   //   after the first barrier of tile k:   indices of tile k+2 (registers), row streams of tile k+1 (registers)
   //   phase 0 of tile k+1:                 indices of tile k+2 -> sd ring;  rows of tile k+1 -> images
@@ -569,10 +558,6 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     if constexpr (SRC) {
       const unsigned w = a.sinfo[r];
       fi = cr == row ? w : 0u;
-    }
-    if constexpr (RUN) {
-      const unsigned w = a.dinfo[r];
-      fj = cr == row ? w : 0u;
     }
   };
   auto prefetch_rows = [&](int64_t k) __attribute__((always_inline)) {
@@ -599,7 +584,6 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       sd[row] = s0;
       sd[ER + row] = d0;
       if constexpr (SRC) si[row] = fi;
-      if constexpr (RUN) di[row] = fj;
     }
     prefetch_idx(klast < 1 ? klast : 1);            // written to the ring in phase 0 of tile 0
     prefetch_rows(0);
@@ -639,7 +623,6 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         sdn[row] = fs;
         sdn[ER + row] = fd;
         if constexpr (SRC) si[(int)((k + 1) % 3) * ER + row] = fi;
-        if constexpr (RUN) di[(int)((k + 1) % 3) * ER + row] = fj;
       }
     }
     __syncthreads();   // images, residual rows, the next tile's indices ready
@@ -755,68 +738,12 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       }
     }
     if constexpr (SRC) {
-      // one run sum: the rows `m` of the three images, joined with / parked in the slot, or (last tile) handed back for the store
-      auto run3 = [&](unsigned w, const float* i1, const float* i2, const float* i3, float* sl, int nsl, float4& s1, float4& s2,
-                      float4& s3) __attribute__((always_inline)) {
-        unsigned m = w & 0xffffu;
-        s1 = f4(0.f); s2 = f4(0.f); s3 = f4(0.f);
-        while (m) {                                  // the tile's rows of this node, in row order (LDS only)
-          const int b = __builtin_ctz(m);
-          m &= m - 1;
-          s1 += ld4(i1 + b * SW + wc4);
-          s2 += ld4(i2 + b * SW + wc4);
-          s3 += ld4(i3 + b * SW + wc4);
-        }
-        const bool lead = (w & 0xffffu) != 0;
-        float* p = sl + ((w >> 16) & 63u) * SW + wc4;
-        if (lead && !(w & kSweepOpen)) {
-          s1 += ld4(p);
-          s2 += ld4(p + nsl * SW);
-          s3 += ld4(p + 2 * nsl * SW);
-        }
-        if (lead && !(w & kSweepClose)) {
-          st4(p, s1);
-          st4(p + nsl * SW, s2);
-          st4(p + 2 * nsl * SW, s3);
-        }
-        return lead && (w & kSweepClose);
-      };
       auto bits4 = [](const float4& v) __attribute__((always_inline)) {
         const u32x4_ b = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
                           __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
         return b;
       };
-      // ~3 of a tile's 16 rows close a source (a destination): a wave whose rows do not skips the three store instructions
-      // (each costs the CU's vector-memory path 16 cycles whether its lanes are in range or not); the branch is wave-uniform
-      // and holds stores only -- it leaves the counted vmcnt waits of the row pipeline alone (checked in the ISA)
-      auto by_source = [&](int rr, unsigned w) __attribute__((always_inline)) {
-        float4 s1, s2, s3;
-        const bool out = run3(w, v5, v2, v3, slots, kSweepSlots, s1, s2, s3);
-        const int sn = sdk[rr] - (int)vbase;
-        const int og_ = out ? (sn * (5 * SW) + wc4) * 4 : (int)0x80000000;
-        const int ou_ = out ? (sn * (2 * SW) + wc4) * 4 : (int)0x80000000;
-        if (!(ABL & 16) && __builtin_amdgcn_ballot_w64(out) != 0) {
-          __builtin_amdgcn_raw_buffer_store_b128(bits4(s1), srs_g, og_, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(bits4(s2), srs_u, ou_, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(bits4(s3), srs_u, ou_, SW * 4, 0);
-        }
-      };
-      if constexpr (RUN) {
-        if (!(ABL & 1)) {                              // every half-wave serves its own row: destination, then source
-          float4 s1, s2, s3;
-          const unsigned w = di[(int)(k % 3) * ER + row];
-          const bool out = run3(w, v1, v2, v3, dslots, 2, s1, s2, s3);
-          const int dn_ = sdk[ER + row] - (int)v0;
-          const int og_ = out ? (dn_ * (5 * SW) + wc4) * 4 : (int)0x80000000;
-          const int ou_ = out ? (dn_ * (2 * SW) + wc4) * 4 : (int)0x80000000;
-          if (__builtin_amdgcn_ballot_w64(out) != 0) {
-            __builtin_amdgcn_raw_buffer_store_b128(bits4(s1), drs_g, og_, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(bits4(s2), drs_u, ou_, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(bits4(s3), drs_u, ou_, SW * 4, 0);
-          }
-          by_source(row, si[(int)(k % 3) * ER + row]);
-        }
-      } else if (!(ABL & 1) && !(ABL & 8) && wave >= 3) {   // beside the column walk: half-wave q serves the tile rows q and q + 10
+      if (!(ABL & 1) && !(ABL & 8) && wave >= 3) {   // beside the column walk: half-wave q serves the tile rows q and q + 10
         // The two rows of a half-wave are served TOGETHER, every LDS read issued unconditionally and up front -- the plan
         // words, then the leader's own row of the three images and the slot contents for both rows (12 + 12 independent
         // reads), a loop only for the rare further rows of a run -- so that the phase is three LDS round trips long instead
@@ -965,24 +892,23 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
 #ifdef GNM_TIMING_ABLATIONS      // builds for timing experiments only: the ablated kernels give wrong results
   static const int abl = getenv("GNM_CHAIN_ABL") ? atoi(getenv("GNM_CHAIN_ABL")) : 0;
   switch (abl) {
-    case 1: hipLaunchKernelGGL((edge_bwd_chain_k<1, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
-    case 2: hipLaunchKernelGGL((edge_bwd_chain_k<2, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
-    case 4: hipLaunchKernelGGL((edge_bwd_chain_k<4, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
-    case 7: hipLaunchKernelGGL((edge_bwd_chain_k<7, 0>), dim3(grid), dim3(CT), 0, st, a); return grid;
-    case 8: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<8, 1>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
-    case 16: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<16, 1>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
-    case 9: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<9, 1>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
+    case 1: hipLaunchKernelGGL((edge_bwd_chain_k<1, false>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 2: hipLaunchKernelGGL((edge_bwd_chain_k<2, false>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 4: hipLaunchKernelGGL((edge_bwd_chain_k<4, false>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 7: hipLaunchKernelGGL((edge_bwd_chain_k<7, false>), dim3(grid), dim3(CT), 0, st, a); return grid;
+    case 8: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<8, true>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
+    case 16: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<16, true>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
+    case 9: if (a.sinfo && a.t_hi) { hipLaunchKernelGGL((edge_bwd_chain_k<9, true>), dim3(grid), dim3(CT), 0, st, a); return grid; } break;
     default: break;
   }
 #endif
   if (!a.t_hi) {                                     // top of the stack: the sweep without a layer above
-    if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, 1, true, false>), dim3(grid), dim3(CT), 0, st, a);
-    else hipLaunchKernelGGL((edge_bwd_chain_k<0, 0, true, false>), dim3(grid), dim3(CT), 0, st, a);
+    if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, false>), dim3(grid), dim3(CT), 0, st, a);
+    else hipLaunchKernelGGL((edge_bwd_chain_k<0, false, true, false>), dim3(grid), dim3(CT), 0, st, a);
     return grid;
   }
-  if (a.sinfo && a.dinfo && chain_variant() == 0) hipLaunchKernelGGL((edge_bwd_chain_k<0, 2>), dim3(grid), dim3(CT), 0, st, a);   // run sums both ways
-  else if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, 1>), dim3(grid), dim3(CT), 0, st, a);     // column walk + by-source run sums
-  else hipLaunchKernelGGL((edge_bwd_chain_k<0, 0>), dim3(grid), dim3(CT), 0, st, a);
+  if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, true>), dim3(grid), dim3(CT), 0, st, a);     // column walk + by-source run sums
+  else hipLaunchKernelGGL((edge_bwd_chain_k<0, false>), dim3(grid), dim3(CT), 0, st, a);
   return grid;
 }
 

@@ -37,14 +37,13 @@ LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
 ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
 
 
-_OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TWO_SIDED", "RUN_SUMS",
-                 "TWO_SIDED_FWD")
+_OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TWO_SIDED", "TWO_SIDED_FWD")
 
 
 @contextlib.contextmanager
 def options(**kw):
     """Temporarily change schedule switches of this module (FUSED, ACTIVATIONS, CHAIN, TN_SIDE, TN_SIDE_CAP, SRC_SIDE_CAP, TN_AT,
-    TWO_SIDED, RUN_SUMS, TWO_SIDED_FWD) and restore them on exit, whatever happens inside:
+    TWO_SIDED, TWO_SIDED_FWD) and restore them on exit, whatever happens inside:
         with engine.options(TWO_SIDED=False, CHAIN=False): ...
     The switches select between schedules that compute the same thing (tests and bench.py A/B them); they are process-wide,
     read at call time by the thread that runs the pass -- one training loop per process, as everywhere on this path."""
@@ -530,10 +529,6 @@ SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 # layer -- shrinks to a gather over the few per cent of the nodes the plan does not serve plus an [N,H]-sized conversion
 # once the BatchNorm-backward means are known.  GNM_TWO_SIDED=0 / engine.TWO_SIDED = False keeps the separate pass.
 TWO_SIDED = os.environ.get("GNM_TWO_SIDED", "1") != "0"
-# ... with the by-destination sums as run sums too (no sequential column walk): GNM_RUN_SUMS=1.  Measured SLOWER (chained
-# kernel 7.58 vs 7.22 ms per launch, same box): the walk on three waves overlaps the other waves' next phase 0, run sums
-# on all sixteen half-waves do not.  Kept as an opt-in variant of the kernel.
-RUN_SUMS = os.environ.get("GNM_RUN_SUMS", "0") != "0"
 # the forward twin (gnm_edge_gate2_fwd): gate + by-destination AND by-source aggregation in one sweep; GNM_TWO_SIDED_FWD=0
 # keeps edge_gate_fwd + node_agg_src_fwd
 TWO_SIDED_FWD = os.environ.get("GNM_TWO_SIDED_FWD", "1") != "0"
@@ -697,8 +692,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                   _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc2.partials),
                   _ptr(s_j.t), _ptr(s_j.stat_e), _ptr(s_j.P), _ptr(Q), _ptr(s_j.hf), _ptr(s_j.hb),
                   _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td), _ptr(sc.partials),
-                  _ptr(plan["sinfo"]), _ptr(plan["dinfo"]) if RUN_SUMS else C.c_void_p(0), plan["nodes_per_block"], _ptr(UT),
-                  C.byref(nblk), _ptr(ws), need_f, st)
+                  _ptr(plan["sinfo"]), plan["nodes_per_block"], _ptr(UT), C.byref(nblk), _ptr(ws), need_f, st)
             # the sources the plan does not serve (chunk boundaries, repeat edges, no out-edges): ge holds ge_tot(j) now
             _call("gnm_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s_j.e_out), _ptr(s_j.t),
                   _ptr(s_j.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),

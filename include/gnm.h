@@ -297,9 +297,8 @@ int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_o
  * gnm_edge_bwd_src_fix then writes the same three sums for the plan's fix_nodes (gathers; needs layer i-1's
  * e_out, t, stat_e, Q and ge = this call's ge_out), and once layer i-1's BatchNorm-backward means are known
  * gnm_node_bgrad turns the raw sums into gP[:,3H:4H] = gB1h = c (Us - outdeg m1 - m2 Ts) and gP[:,4H:5H] = gB2h =
- * c (Ud - indeg m1 - m2 Td).  Together = gnm_edge_bwd_src.  dinfo (optional, the plan's destination words): the
- * by-destination sums gA3h / Ud / Td are run sums too (no sequential column walk); Ud_lo / Td_lo must then be the
- * two halves of one [N,2H] array (Td_lo == Ud_lo + H, row pitch 2H; gnm_node_bgrad accepts either layout).
+ * c (Ud - indeg m1 - m2 Td).  Together = gnm_edge_bwd_src.  Ud_lo / Td_lo: two [N,H] arrays or the halves of one [N,2H]
+ * array (Td_lo == Ud_lo + H); gnm_node_bgrad accepts either layout.
  *                                                                     autograd of gated_gcn_full.py:133-143 */
 int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
                            const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
@@ -307,7 +306,7 @@ int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* 
                            const float* t_lo, const float* stat_lo, const float* P_lo, const float* Q_lo,
                            const float* hf_lo, const float* hb_lo, const int32_t* isrc, const int32_t* idst,
                            const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
-                           const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block, float* UT_lo,
+                           const uint32_t* sinfo, int64_t plan_nodes_per_block, float* UT_lo,
                            int* nblk_out, void* ws, size_t ws_bytes, void* stream);
 /* edge_bwd_top: the top layer of the stack (no layer above to chain with): gnm_edge_bwd_dst on the chained kernel's sweep
  * (ge updated in place to ge + gsigma*sigma', gP[:,2H:3H], Ud, Td, BatchNorm_e backward partials) plus, with sinfo, the
