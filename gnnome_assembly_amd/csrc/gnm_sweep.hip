@@ -71,7 +71,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   __syncthreads();
   if (ntile == 0) return;
 
-  float4 ptA, peA = f4(0.f), ptB, peB = f4(0.f);   // rows of t, e_in: two tiles in flight (even / odd tiles)
+  float4 ptA, peA = f4(0.f), ptB, peB = f4(0.f), ptC, peC = f4(0.f);   // rows of t, e_in: three tiles in flight
   float4 ga2, ga3;                           // A2h[src], A3h[dst] of this thread's edge
   int fs = 0, fd = 0;                        // indices / plan words of this thread's row two tiles ahead
   unsigned fi = 0, fj = 0;
@@ -138,10 +138,11 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   prefetch_idx(klast < 1 ? klast : 1);
   prefetch_rows(0, ptA, peA);
   prefetch_rows(klast < 1 ? klast : 1, ptB, peB);
+  prefetch_rows(klast < 2 ? klast : 2, ptC, peC);
   gather(s0, d0);
   const float4 sc = ld4(cs + c4), sh = ld4(cs + SW + c4);
-  // one tile; its rows are in (pt, pe_), which are refilled with the rows of tile k + 2 behind the first barrier: the row
-  // streams are requested TWO tiles ahead (one tile's run sums + barriers are shorter than the HBM latency under load)
+  // one tile; its rows are in (pt, pe_), which are refilled with the rows of tile k + 3 behind the first barrier: the row
+  // streams are requested THREE tiles ahead (one tile's run sums + barriers are shorter than the HBM latency under load)
   auto tile = [&](int64_t k, float4& pt, float4& pe_) __attribute__((always_inline)) {
     const int64_t r0 = rb + k * GR;
     const int nvalid = re - r0 < GR ? (int)(re - r0) : GR;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     }
     __syncthreads();
     prefetch_idx(k + 2 < klast ? k + 2 : klast);
-    prefetch_rows(k + 2 < klast ? k + 2 : klast, pt, pe_);
+    prefetch_rows(k + 3 < klast ? k + 3 : klast, pt, pe_);
     // ---- run sums: this half-wave's row as the leader of its destination, then of its source ----
     {
       float4 num, den;
@@ -186,9 +187,10 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     }
     __syncthreads();                               // the images are free again
   };
-  for (int64_t k = 0; k < ntile; k += 2) {
+  for (int64_t k = 0; k < ntile; k += 3) {
     tile(k, ptA, peA);
     if (k + 1 < ntile) tile(k + 1, ptB, peB);
+    if (k + 2 < ntile) tile(k + 2, ptC, peC);
   }
 }
 
