@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNM_LIBRARY") or os.path.join(_HERE, "libgnm.so")   # GNM_LIBRARY: A/B against another build (tools)
 
 _lib = None
-ABI_VERSION = 2     # GNM_ABI_VERSION of include/gnm.h
+ABI_VERSION = 3     # GNM_ABI_VERSION of include/gnm.h
 
 _p = C.c_void_p
 _i64 = C.c_int64

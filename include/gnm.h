@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 2   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order */
+#define GNM_ABI_VERSION 3   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
