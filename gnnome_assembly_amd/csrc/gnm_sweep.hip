@@ -39,7 +39,8 @@ __device__ __forceinline__ u32x4g_ bits4g(const float4& v) {
   return b;
 }
 
-template <bool RES>
+// INV = false (a forward under no_grad): inv_f / inv_b -- which only the backward reads -- are not stored
+template <bool RES, bool INV>
 __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[G2_LDS];
   float* i1 = reinterpret_cast<float*>(lds);          // sigma * A2h[src]
@@ -65,9 +66,9 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   const int nspan = (int)(v1 - v0 + 2 * a.margin);
   const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(a.e_out + rb * SW, 0, (int)(re - rb) * SW * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hf = __builtin_amdgcn_make_buffer_rsrc(a.hf + v0 * SW, 0, (int)(v1 - v0) * SW * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_if = __builtin_amdgcn_make_buffer_rsrc(a.inv_f + v0 * SW, 0, (int)(v1 - v0) * SW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_if = __builtin_amdgcn_make_buffer_rsrc(INV ? a.inv_f + v0 * SW : a.hf, 0, INV ? (int)(v1 - v0) * SW * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hb = __builtin_amdgcn_make_buffer_rsrc(a.hb + vbase * SW, 0, nspan * SW * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ib = __builtin_amdgcn_make_buffer_rsrc(a.inv_b + vbase * SW, 0, nspan * SW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ib = __builtin_amdgcn_make_buffer_rsrc(INV ? a.inv_b + vbase * SW : a.hb, 0, INV ? nspan * SW * 4 : 0, 0x00020000);
   __syncthreads();
   if (ntile == 0) return;
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
                                        1.f / (den.w + kEpsDen));
         const int o = out ? ((rk[GR + row] - (int)v0) * SW + c4) * 4 : (int)0x80000000;
         __builtin_amdgcn_raw_buffer_store_b128(bits4g(num * inv), rs_hf, o, 0, 2);
-        __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_if, o, 0, 2);
+        if constexpr (INV) __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_if, o, 0, 2);
       }
       out = run2((unsigned)rk[2 * GR + row], i3, i2, sslots, kSweepSlots, num, den);
       if (__builtin_amdgcn_ballot_w64(out) != 0) {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
                                        1.f / (den.w + kEpsDen));
         const int o = out ? ((rk[row] - (int)vbase) * SW + c4) * 4 : (int)0x80000000;
         __builtin_amdgcn_raw_buffer_store_b128(bits4g(num * inv), rs_hb, o, 0, 2);
-        __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_ib, o, 0, 2);
+        if constexpr (INV) __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_ib, o, 0, 2);
       }
     }
     {                                              // the next tile's node rows (its indices went to the ring before the barrier)
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void gate2_empty_segments_k(int64_t N, const i
       const int64_t u = base + b;
       const int c4 = (lane & 31) * 4;
       if (lane < 32) st4(hf + u * SW + c4, f4(0.f));
-      else st4(inv_f + u * SW + c4, f4(1.f / kEpsDen));
+      else if (inv_f) st4(inv_f + u * SW + c4, f4(1.f / kEpsDen));
     }
   }
 }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kBlock, 8) void node_agg_src_fix_k(int64_t nfix, co
       const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen), 1.f / (den.z + kEpsDen),
                                      1.f / (den.w + kEpsDen));
       st4_nt(hb + v * H + c4, num * inv);
-      st4_nt(inv_b + v * H + c4, inv);
+      if (inv_b) st4_nt(inv_b + v * H + c4, inv);
     }
   }
 }
@@ -291,8 +292,9 @@ extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, c
                                   float* z, double* partials, int* nblk_out, void* stream) {
   GNM_CHECK_ARG(H == SW, "edge_gate2_fwd: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(N > 0 && E > 0 && t && stat_e && P && isrc && idst && in_ptr && sinfo && dinfo && (nfix == 0 || fix_nodes) &&
-                    nfix >= 0 && out_ptr && out_pos && out_dst && e_out && hf && inv_f && hb && inv_b && z && partials &&
-                    nblk_out, "edge_gate2_fwd: null/neg argument");      // e_in == NULL: no residual
+                    nfix >= 0 && out_ptr && out_pos && out_dst && e_out && hf && hb && z && partials && nblk_out &&
+                    (inv_f != nullptr) == (inv_b != nullptr),
+                "edge_gate2_fwd: null/neg argument");      // e_in == NULL: no residual; inv_f == inv_b == NULL: not wanted (no backward)
   hipStream_t st = (hipStream_t)stream;
   Gate2Args a{};
   a.N = N; a.E = E; a.t = t; a.e_in = e_in; a.stat = stat_e; a.P = P; a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
@@ -306,8 +308,10 @@ extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, c
   GNM_CHECK_ARG((a.nodes_per_block + 2 * kSweepMargin) * SW * 4 < (int64_t)INT32_MAX && E / grid < (1 << 21),
                 "edge_gate2_fwd: a workgroup's share exceeds the 32-bit buffer offsets");
   hipLaunchKernelGGL(gate2_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, N, in_ptr, hf, inv_f);
-  if (e_in) hipLaunchKernelGGL(edge_gate2_fwd_k<true>, dim3(grid), dim3(GT), 0, st, a);
-  else hipLaunchKernelGGL(edge_gate2_fwd_k<false>, dim3(grid), dim3(GT), 0, st, a);
+  if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true>), dim3(grid), dim3(GT), 0, st, a);
+  else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false>), dim3(grid), dim3(GT), 0, st, a);
+  else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true>), dim3(grid), dim3(GT), 0, st, a);
+  else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false>), dim3(grid), dim3(GT), 0, st, a);
   GNM_LAUNCH_CHECK("edge_gate2_fwd");
   if (nfix > 0) {
     int64_t g2 = (nfix + kWavesPerBlock - 1) / kWavesPerBlock;

@@ -367,11 +367,11 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
-    inv_f = torch.empty(N, H, **f32)
     two_sided = plan is not None and batch_norm and H == 128 and TWO_SIDED_FWD
+    inv_f = torch.empty(N, H, **f32) if (save or not two_sided) else None      # inv_f / inv_b: only the backward reads them
     if two_sided:
         hb = torch.empty(N, H, **f32)
-        inv_b = torch.empty(N, H, **f32)
+        inv_b = torch.empty(N, H, **f32) if save else None
         z = torch.empty(N, H, **f32)
         stat_e = bn_finalize(sc.partials, nblk.value, E, H, prm.gamma_e, prm.beta_e)
         _call("gnm_edge_gate2_fwd", N, E, H, _ptr(t), res_e, _ptr(stat_e), _ptr(P), _ptr(idx["isrc"]), _ptr(idx["idst"]),

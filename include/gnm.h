@@ -176,7 +176,8 @@ int gnm_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* 
 /* edge_gate2 (H = 128): gnm_edge_gate_fwd AND gnm_node_agg_src_fwd as ONE two-sided sweep over the destination-sorted
  *   rows (same outputs: e_out, hf, inv_f, hb, inv_b, z, BatchNorm_h partials; e_out is not re-read): the by-source
  *   sums through the sweep plan (sinfo / dinfo / fix_nodes of gnm_graph_build_sweep_plan over
- *   gnm_sweep_partition(N, 2)); the plan's fix_nodes are covered by gathers.                         (:122-147) */
+ *   gnm_sweep_partition(N, 2)); the plan's fix_nodes are covered by gathers.  inv_f == inv_b == NULL: a forward
+ *   without a backward (torch.no_grad: inference.py:444) does not store what only the backward reads.  (:122-147) */
 int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* stat_e,
                        const float* P, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr,
                        const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block, int64_t nfix,
