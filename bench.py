@@ -91,6 +91,7 @@ def op_model(op: str, N: int, E: int, H: int):
         # gate + both aggregations: t, e_in in; e_out out; A2h, A3h rows in; hf, inv_f, hb, inv_b out; then z: A1h, hf, hb in, z out
         "gnm_edge_gate2_fwd": (3 * eh + 10 * nh, 0.0),
         "gnm_node_bgrad": (6 * nh, 0.0),                      # Us, Ts, Ud, Td in; gB1h, gB2h out
+        "gnm_edge_bwd_top": (4 * eh + 12 * nh, 0.0),          # the top layer on the same sweep: e_out, t, ge in; ge out
         "gnm_node_proj_fwd": (6 * nh, 2.0 * N * H * 5 * H),                # h in, P out
         "gnm_node_proj_bwd_nn": (7 * nh, 2.0 * N * H * 5 * H),             # gP, gh_out in; gh_in out
         "gnm_node_proj_bwd_tn": (6 * nh, 2.0 * N * H * 5 * H),             # gP, h_in in
@@ -121,7 +122,7 @@ TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 OP_KERNELS = {
     "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_fused_k<MmB3>", "edge_bwd_tr_k"]},
     "gnm_edge_bwd_chain": ["edge_bwd_chain_k"], "gnm_edge_bwd_chain_src": ["edge_bwd_chain_k"],
-    "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true>"], "gnm_node_bgrad": ["node_bgrad_k<128>"],
+    "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true, true>"], "gnm_node_bgrad": ["node_bgrad_k<128>"], "gnm_edge_bwd_top": ["edge_bwd_chain_k"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
     "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128, true>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
     "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3_k"]},
