@@ -1,16 +1,16 @@
 import sys
 p=sys.argv[1]; full=open(p).read()
 # only edge_bwd_chain_k (the shipped kernel) is patched: everything before the role-specialised variant
-cut = full.index("// The column walk of one 16-row tile by the gather role of edge_bwd_chain2_k") if "edge_bwd_chain2_k" in full else len(full)
+cut = len(full)
 s, rest = full[:cut], full[cut:]
 def rep(old, new, cnt=1):
     global s
     assert s.count(old) == cnt, (old, s.count(old))
     s = s.replace(old, new)
-rep("template <int ABL>\n__global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {",
+rep("template <int ABL, bool SRC, bool WSKIP = true, bool HI = true>\n__global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {",
 """__device__ long long g_chain_dbg[256 * 8 * 12];
 #define TS(n) { const long long t_ = clock64(); tacc[n] += t_ - tlast; tlast = t_; }
-template <int ABL>
+template <int ABL, bool SRC, bool WSKIP = true, bool HI = true>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = clock64();""")
@@ -37,23 +37,28 @@ rep("""    __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
     TS(6)
 """)
+rep("""    if constexpr (SRC) {
+      auto bits4 = [](const float4& v) __attribute__((always_inline)) {""","""    TS(7)
+    if constexpr (SRC) {
+      auto bits4 = [](const float4& v) __attribute__((always_inline)) {""")
 rep("""    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
     }
-""","""    TS(7)
-    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
+""","""    {                                              // the next tile's node rows, through the ring (written before this tile's first barrier)
       const int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
       gather(sdn[row], sdn[ER + row]);
     }
     TS(8)
 """)
-rep("""  float* sl = a.slab + (size_t)chunk * SW * SW;
-""","""  if ((tid & 63) == 0 && blockIdx.x < 256) {
+rep("""  if constexpr (HI) {
+    float* sl = a.slab + (size_t)chunk * SW * SW;
+""","""  if (HI && SRC && (tid & 63) == 0 && blockIdx.x < 256) {
     for (int q = 0; q < 10; ++q) g_chain_dbg[(blockIdx.x * 8 + wave) * 12 + q] = tacc[q];
     g_chain_dbg[(blockIdx.x * 8 + wave) * 12 + 10] = ntile;
   }
-  float* sl = a.slab + (size_t)chunk * SW * SW;
+  if constexpr (HI) {
+    float* sl = a.slab + (size_t)chunk * SW * SW;
 """)
 s = s + rest
 s=s.rstrip('\n')+"""

@@ -32,7 +32,7 @@ if os.environ.get("CHAIN2"):
         print(f"{names2[q]:32s}", " ".join(f"{per[:, w, q].mean():8.1f}" for w in range(8)))
     print("sum", " ".join(f"{per[:, w, :7].sum(-1).mean():8.1f}" for w in range(8)))
     sys.exit(0)
-names = ["loop-top(gather issue->)", "phase0 after the rows arrived", "barrier1", "prefetch+MFMA TN+NN", "barrier2", "dst arithmetic", "barrier3", "walk / segment sums", "gather issue", "phase0: wait for the rows"]
+names = ["loop-top(gather issue->)", "phase0 after the rows arrived", "barrier1", "prefetch+MFMA TN+NN", "barrier2", "dst arithmetic", "barrier3", "walk / bn sums (waves 0-2 / 4-7)", "by-source run sums + gather issue", "phase0: wait for the rows"]
 print("tiles per WG:", nt[:4, 0])
 print("ticks per tile (s_memtime ticks = 100 MHz? reported raw), mean over WGs, per wave:")
 for q in (0, 9, 1, 2, 3, 4, 5, 6, 7, 8):
