@@ -109,30 +109,6 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
       rk[3 * GR + row] = (int)fj;
     }
   };
-  // sum of the rows `w & 0xffff` of two images, joined with / parked in the node's slot; true: last tile of the node
-  auto run2 = [&](unsigned w, const float* ia, const float* ib, float* sl, int nsl, float4& s1, float4& s2) __attribute__((always_inline)) {
-    unsigned m = w & 0xffffu;
-    s1 = f4(0.f);
-    s2 = f4(0.f);
-    while (m) {
-      const int b = __builtin_ctz(m);
-      m &= m - 1;
-      s1 += ld4(ia + b * SW + c4);
-      s2 += ld4(ib + b * SW + c4);
-    }
-    const bool lead = (w & 0xffffu) != 0;
-    float* p = sl + ((w >> 16) & 63u) * SW + c4;
-    if (lead && !(w & kSweepOpen)) {
-      s1 += ld4(p);
-      s2 += ld4(p + nsl * SW);
-    }
-    if (lead && !(w & kSweepClose)) {
-      st4(p, s1);
-      st4(p + nsl * SW, s2);
-    }
-    return lead && (w & kSweepClose);
-  };
-
   prefetch_idx(0);
   ring_put(0);
   const int s0 = fs, d0 = fd;
@@ -162,29 +138,67 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     __syncthreads();
     prefetch_idx(k + 2 < klast ? k + 2 : klast);
     prefetch_rows(k + 3 < klast ? k + 3 : klast, pt, pe_);
-    // ---- run sums: this half-wave's row as the leader of its destination, then of its source ----
+    {                                              // the next tile's node rows (its indices went to the ring before the barrier): a whole
+      const int* rn = ring + (int)((k + 1) % 3) * 4 * GR;      // run-sum phase ahead of their use
+      gather(rn[row], rn[GR + row]);
+    }
+    // ---- run sums: this half-wave's row as the leader of its destination AND of its source.  Every LDS read both need is
+    // issued up front -- the leader's own row (unconditional), the slots (unconditional), the next three rows of the
+    // destination run (a destination has ~5 contiguous rows; predicated on the run length) -- so that the phase is two LDS
+    // round trips long; loops only for what is left ----
     {
-      float4 num, den;
-      bool out = run2((unsigned)rk[3 * GR + row], i1, i2, dslots, 2, num, den);
-      if (__builtin_amdgcn_ballot_w64(out) != 0) {
-        const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen), 1.f / (den.z + kEpsDen),
-                                       1.f / (den.w + kEpsDen));
-        const int o = out ? ((rk[GR + row] - (int)v0) * SW + c4) * 4 : (int)0x80000000;
-        __builtin_amdgcn_raw_buffer_store_b128(bits4g(num * inv), rs_hf, o, 0, 2);
+      const unsigned wd = (unsigned)rk[3 * GR + row], ws_ = (unsigned)rk[2 * GR + row];
+      const unsigned md = wd & 0xffffu;
+      unsigned ms = ws_ & 0xffffu;
+      const int nd = __builtin_popcount(md);                   // rows row .. row + nd - 1
+      float4 dn_ = ld4(i1 + row * SW + c4), dd = ld4(i2 + row * SW + c4);
+      float4 sn_ = ld4(i3 + row * SW + c4), sdn = dd;
+      float* pd = dslots + ((wd >> 16) & 1u) * SW + c4;
+      float* ps = sslots + ((ws_ >> 16) & (kSweepSlots - 1)) * SW + c4;
+      const float4 e1 = ld4(pd), e2 = ld4(pd + 2 * SW);
+      const float4 q1 = ld4(ps), q2 = ld4(ps + kSweepSlots * SW);
+      float4 x1[3] = {f4(0.f), f4(0.f), f4(0.f)}, x2[3] = {f4(0.f), f4(0.f), f4(0.f)};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (j + 1 < nd) {                                        // only the leader of a run reads its rows
+          x1[j] = ld4(i1 + (row + 1 + j) * SW + c4);
+          x2[j] = ld4(i2 + (row + 1 + j) * SW + c4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        dn_ += x1[j];
+        dd += x2[j];
+      }
+      for (int j = 4; j < nd; ++j) {                             // a destination with more than four rows in this tile
+        dn_ += ld4(i1 + (row + j) * SW + c4);
+        dd += ld4(i2 + (row + j) * SW + c4);
+      }
+      ms &= ms - 1;
+      while (ms) {                                               // a source with several edges into this tile
+        const int b = __builtin_ctz(ms);
+        ms &= ms - 1;
+        sn_ += ld4(i3 + b * SW + c4);
+        sdn += ld4(i2 + b * SW + c4);
+      }
+      const bool ld_ = md != 0, ls_ = (ws_ & 0xffffu) != 0;
+      if (ld_ && !(wd & kSweepOpen)) { dn_ += e1; dd += e2; }
+      if (ls_ && !(ws_ & kSweepOpen)) { sn_ += q1; sdn += q2; }
+      if (ld_ && !(wd & kSweepClose)) { st4(pd, dn_); st4(pd + 2 * SW, dd); }
+      if (ls_ && !(ws_ & kSweepClose)) { st4(ps, sn_); st4(ps + kSweepSlots * SW, sdn); }
+      const bool outd = ld_ && (wd & kSweepClose), outs = ls_ && (ws_ & kSweepClose);
+      if (__builtin_amdgcn_ballot_w64(outd) != 0) {
+        const float4 inv = make_float4(1.f / (dd.x + kEpsDen), 1.f / (dd.y + kEpsDen), 1.f / (dd.z + kEpsDen), 1.f / (dd.w + kEpsDen));
+        const int o = outd ? ((rk[GR + row] - (int)v0) * SW + c4) * 4 : (int)0x80000000;
+        __builtin_amdgcn_raw_buffer_store_b128(bits4g(dn_ * inv), rs_hf, o, 0, 2);
         if constexpr (INV) __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_if, o, 0, 2);
       }
-      out = run2((unsigned)rk[2 * GR + row], i3, i2, sslots, kSweepSlots, num, den);
-      if (__builtin_amdgcn_ballot_w64(out) != 0) {
-        const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen), 1.f / (den.z + kEpsDen),
-                                       1.f / (den.w + kEpsDen));
-        const int o = out ? ((rk[row] - (int)vbase) * SW + c4) * 4 : (int)0x80000000;
-        __builtin_amdgcn_raw_buffer_store_b128(bits4g(num * inv), rs_hb, o, 0, 2);
+      if (__builtin_amdgcn_ballot_w64(outs) != 0) {
+        const float4 inv = make_float4(1.f / (sdn.x + kEpsDen), 1.f / (sdn.y + kEpsDen), 1.f / (sdn.z + kEpsDen), 1.f / (sdn.w + kEpsDen));
+        const int o = outs ? ((rk[row] - (int)vbase) * SW + c4) * 4 : (int)0x80000000;
+        __builtin_amdgcn_raw_buffer_store_b128(bits4g(sn_ * inv), rs_hb, o, 0, 2);
         if constexpr (INV) __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_ib, o, 0, 2);
       }
-    }
-    {                                              // the next tile's node rows (its indices went to the ring before the barrier)
-      const int* rn = ring + (int)((k + 1) % 3) * 4 * GR;
-      gather(rn[row], rn[GR + row]);
     }
     __syncthreads();                               // the images are free again
   };
