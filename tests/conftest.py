@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 def golden_files(pattern=""):
     return sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz") and pattern in f
-                  and not f.startswith(("pe_", "decode_", "train_loop", "layer_variants")))
+                  and not f.startswith(("pe_", "decode_", "train_loop", "layer_variants", "fullsize_")))
 
 
 @pytest.fixture(scope="session")

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import golden_files
-from helpers import load_case, sd_to_torch, rel_l2, assert_parity, tally_clause, RTOL, ATOL
+from helpers import GOLDEN, load_case, sd_to_torch, rel_l2, assert_parity, tally_clause, RTOL, ATOL
 
 pytestmark = pytest.mark.gpu
 
@@ -602,20 +602,21 @@ def test_chr19_scale_step_is_finite_and_self_consistent():
 
 @pytest.mark.default_mode_only
 def test_full_size_logits_match_the_oracle():
-    """Parity AT THE METRIC'S SIZE (BASELINE config 2: R = 750 k, N = 1.5 M, E = 7.54 M, H = 128, L = 8): all E logits of
-    the HIP forward against oracle.model_forward on the host (no_grad; fp64 when the host has the memory for it, else fp32),
-    bar = assert_parity (rtol 1e-4, atol 1e-5, rel-L2 <= 1e-4).  The 1 k-read fixtures cannot exercise BatchNorm sums over
-    7.5 M rows, the int32 / int64 offset arithmetic or the sweep plans at one workgroup per CU; this does.  Run twice on the
-    device: node ids as the generator gives them, and shuffled (the internal renumbering: the same oracle logits apply,
-    logits belong to edges)."""
+    """Parity AT THE METRIC'S SIZE (BASELINE config 2: R = 750 k, N = 1.5 M, E = 7.54 M, H = 128, L = 8): the logits of the
+    HIP forward against oracle.model_forward in fp64, bar = assert_parity (rtol 1e-4, atol 1e-5, rel-L2 <= 1e-4).  The 1 k-read
+    fixtures cannot exercise BatchNorm sums over 7.5 M rows, the int32 / int64 offset arithmetic or the sweep plans at one
+    workgroup per CU; this does.  Run twice on the device: node ids as the generator gives them, and shuffled (the internal
+    renumbering: the same oracle logits apply, logits belong to edges).
+    The oracle's fp64 forward takes ~5 min of a 128-thread host, so by default the comparison is with its logits at every 97th
+    edge, stored in tests/golden/fullsize_logits_r750k.npz (tests/golden/make_golden_fullsize.py; 77,735 of the 7,540,278, plus the
+    norm of all of them); GNM_FULL_ORACLE=1 runs the oracle live and compares ALL E logits (profiles/r04_gputest.log has such a
+    run: rel-L2 5.7e-7)."""
     import time
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import synth
-    from oracle import gatedgcn_oracle as orc
     dev = _dev()
     R, H, L, seed = 750000, 128, 8, 0
     model, src, dst, n, inp = _model_and_inputs(R, H, L, seed, dev)
-    sd = synth.synth_state_dict(H, L, seed)
     E = int(src.size)
     model.eval()
 
@@ -633,26 +634,36 @@ def test_full_size_logits_match_the_oracle():
     pe_s = np.empty_like(inp["pe"])
     pe_s[p] = inp["pe"]
     s_shuf = hip(p[src], p[dst], pe_s)
-    try:
-        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
-    except (ValueError, OSError):
-        avail = 0.0
-    dt = torch.float64 if avail > 220 else torch.float32          # ~22 [E,H] tensors alive at the oracle's peak
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ref = orc.model_forward(sd_to_torch(sd, dt), torch.from_numpy(src), torch.from_numpy(dst), n,
-                                torch.from_numpy(inp["e"]).to(dt), torch.from_numpy(inp["pe"]).to(dt)).squeeze(-1).double().numpy()
-    secs = time.perf_counter() - t0
-    r1, r2 = rel_l2(s_sorted, ref), rel_l2(s_shuf, ref)
-    line = (f"full size E={E} N={n} H={H} L={L}: logits rel_l2 vs the {str(dt).split('.')[-1]} oracle = {r1:.3e} (generator ids), "
-            f"{r2:.3e} (shuffled ids, renumbered); max_abs {np.abs(s_sorted - ref).max():.3e} / {np.abs(s_shuf - ref).max():.3e}; "
-            f"oracle forward {secs:.0f} s on {torch.get_num_threads()} threads, host memory available {avail:.0f} GiB")
+    assert np.isfinite(s_sorted).all() and np.isfinite(s_shuf).all()
+    if os.environ.get("GNM_FULL_ORACLE") == "1":
+        from oracle import gatedgcn_oracle as orc
+        sd = synth.synth_state_dict(H, L, seed)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref = orc.model_forward(sd_to_torch(sd, torch.float64), torch.from_numpy(src), torch.from_numpy(dst), n,
+                                    torch.from_numpy(inp["e"]).double(), torch.from_numpy(inp["pe"]).double()).squeeze(-1).numpy()
+        what = f"all {E} logits, live fp64 oracle ({time.perf_counter() - t0:.0f} s on {torch.get_num_threads()} threads)"
+        idx = np.arange(E)
+    else:
+        z = np.load(os.path.join(GOLDEN, "fullsize_logits_r750k.npz"))
+        assert (int(z["reads"]), int(z["H"]), int(z["L"]), int(z["seed"]), int(z["edges"])) == (R, H, L, seed, E)
+        idx = np.arange(0, E, int(z["stride"]))
+        ref = z["logits"]
+        assert ref.dtype == np.float64 and ref.size == idx.size
+        # the stored norm of ALL the oracle's logits: the edges between the samples are covered in aggregate
+        for s in (s_sorted, s_shuf):
+            assert abs(np.linalg.norm(s.astype(np.float64)) / float(z["norm2"]) - 1.0) < 1e-5
+        what = f"every {int(z['stride'])}th logit ({idx.size}), fp64 oracle fixture"
+    a, b = s_sorted[idx], s_shuf[idx]
+    r1, r2 = rel_l2(a, ref), rel_l2(b, ref)
+    line = (f"full size E={E} N={n} H={H} L={L}: logits rel_l2 vs the oracle = {r1:.3e} (generator ids), {r2:.3e} (shuffled ids, "
+            f"renumbered); max_abs {np.abs(a - ref).max():.3e} / {np.abs(b - ref).max():.3e}; {what}")
     print(line)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "logit_parity_fullsize.txt"), "w") as f:
         f.write(line + "\n")
-    assert_parity(s_sorted, ref, "full-size logits, generator ids")
-    assert_parity(s_shuf, ref, "full-size logits, shuffled ids")
+    assert_parity(a, ref, "full-size logits, generator ids")
+    assert_parity(b, ref, "full-size logits, shuffled ids")
 
 
 def test_no_grad_forward_keeps_no_activations():
