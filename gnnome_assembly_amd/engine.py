@@ -37,7 +37,7 @@ LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
 ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
 
 
-_OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TWO_SIDED", "TWO_SIDED_FWD")
+_OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TN_SPLIT", "TWO_SIDED", "TWO_SIDED_FWD")
 
 
 @contextlib.contextmanager
@@ -521,6 +521,10 @@ TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
 # when the deferred weight-gradient kernel of layer i is launched: "next" = at the head of layer i-1's iteration (beside its
 # by-source pass / conversion), "now" = right after layer i's own by-source pass or conversion (beside nn(i), node(i-1))
 TN_AT = os.environ.get("GNM_TN_AT", "next")
+# "next" only: the deferred kernel in TWO launches sized to the two HBM-bound windows of an iteration -- the gB1h | gB2h column groups
+# beside this layer's conversion (node_bgrad), the gA1h | gA2h | gA3h groups AFTER this layer's nn (both matrix bound: side by side
+# they only take turns) beside the next layer's BatchNorm_h backward.  GNM_TN_SPLIT=0: one launch at the head of the iteration.
+TN_SPLIT = os.environ.get("GNM_TN_SPLIT", "1") != "0"
 SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 
 
@@ -611,6 +615,8 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     side = _side_stream(dev) if (TN_SIDE and _prof is None and ACTIVATIONS != "lean") else None
     main = torch.cuda.current_stream()
     pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
+    pending2 = None             # the same, when only its first launch (TN_SPLIT) has been issued
+    need_t = lib.gnm_tn128_workspace_bytes()
     held: List[torch.Tensor] = []   # what the side stream is reading; dropped only after the main stream has waited for it
     while True:
         prm, s = prms[i], saved[i]
@@ -626,10 +632,16 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             held.clear()                # (no record_stream: blocks parked on a side-stream event made the allocator
             side.wait_stream(main)      #  fall back to hipMalloc / hipFree in the lean mode: 3x the step time)
             sc3 = scratch(dev, "tn")
-            ws3 = sc3.ws(need_p)
-            _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(pgP), _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials),
-                                                _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
-                       "gnm_node_proj_bwd_tn")
+            if TN_SPLIT and UT is not None:
+                ws3 = sc3.ws(need_t)
+                _lib.check(lib.gnm_tn128(N, _ptr(pgP[:, 3 * H:]), 5 * H, 2, _ptr(ph), _ptr(pW[3 * H:]), _ptr(pb[3 * H:]),
+                                         _ptr(sc3.partials), _ptr(ws3), need_t, C.c_void_p(side.cuda_stream)), "gnm_tn128")
+                pending2 = pending
+            else:
+                ws3 = sc3.ws(need_p)
+                _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(pgP), _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials),
+                                                    _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
+                           "gnm_node_proj_bwd_tn")
             held.extend((pgP, ph))
             pending = None
             src_cap = SRC_SIDE_CAP
@@ -647,6 +659,14 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
         ws = sc.ws(max(need_p, need_f))
         if not (side is not None and TN_AT == "now"):
             _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
+        if pending2 is not None:        # the other three column groups of the layer above, behind this layer's nn
+            pgP, ph, pW, pb = pending2
+            side.wait_stream(main)
+            sc3 = scratch(dev, "tn")
+            ws3 = sc3.ws(need_t)
+            _lib.check(lib.gnm_tn128(N, _ptr(pgP), 5 * H, 3, _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials), _ptr(ws3),
+                                     need_t, C.c_void_p(side.cuda_stream)), "gnm_tn128")
+            pending2 = None
         if side is not None and TN_AT == "now":
             main.wait_stream(side)
             held.clear()

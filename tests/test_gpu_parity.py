@@ -1347,8 +1347,8 @@ def test_bench_line_contract(tmp_path):
 
 def test_side_stream_schedule_and_per_call_caps_change_nothing_but_rounding():
     """The chained backward launches the node weight-gradient kernel on a side stream beside the by-source pass
-    (engine.TN_SIDE); the workgroups-per-CU caps of the two kernels are ARGUMENTS of their launches (gnm.h
-    max_blocks_per_cu), no process-wide state.  Same kernels: another cap only changes the number of per-workgroup
+    (engine.TN_SIDE), in one launch or in two sized to the HBM-bound windows of an iteration (engine.TN_SPLIT); the
+    workgroups-per-CU caps of the two kernels are ARGUMENTS of their launches (gnm.h max_blocks_per_cu), no process-wide state.  Same kernels: another cap only changes the number of per-workgroup
     partial slabs, i.e. the summation order -> gradients equal to fp32 round-off, and every setting is deterministic."""
     from gnnome_assembly_amd import engine
     dev = _dev()
@@ -1363,8 +1363,10 @@ def test_side_stream_schedule_and_per_call_caps_change_nothing_but_rounding():
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in model.named_parameters()}
     base = run()
-    for setting in ((False, 0, 0, "next"), (True, 1, 2, "next"), (True, 2, 8, "now"), (True, 0, 4, "now")):
-        with engine.options(TN_SIDE=setting[0], TN_SIDE_CAP=setting[1], SRC_SIDE_CAP=setting[2], TN_AT=setting[3]):
+    for setting in ((False, 0, 0, "next", True), (True, 1, 2, "next", False), (True, 0, 4, "next", True), (True, 2, 8, "now", True),
+                    (True, 0, 4, "now", False)):
+        with engine.options(TN_SIDE=setting[0], TN_SIDE_CAP=setting[1], SRC_SIDE_CAP=setting[2], TN_AT=setting[3],
+                            TN_SPLIT=setting[4]):
             co, co2 = run(), run()
         for k in base:
             assert torch.equal(co[k], co2[k]), (setting, k)                    # still deterministic
