@@ -47,6 +47,21 @@ def main():
             if q2 != q and s2 < e and e2 > s and e2 - s2 >= 20000:
                 ov.append(f"{n2[:28]} {(min(e, e2) - max(s, s2)) / 1e3:.0f}")
         out.append(f"{(s - t0) / 1e6:9.3f} {(e - s) / 1e3:8.1f} {q:>5s}  {n}" + (f"    [beside: {'; '.join(ov)}]" if ov else ""))
+    out.append("")
+    out.append("idle gaps of more than 30 us (no kernel running on any queue), with the kernels on either side:")
+    cur_end, last = step[0][1], step[0][2]
+    nxt = ks[b:b + 40]
+    for s, e, n, q, st in step[1:] + nxt:
+        if s - cur_end > 30000:
+            out.append(f"  {(cur_end - t0) / 1e6:9.3f} ms: {(s - cur_end) / 1e3:7.1f} us between {last} and {n}")
+        if e > cur_end:
+            cur_end, last = e, n
+    out.append("")
+    out.append("every kernel from 1.2 ms before the step's last kernel ends to 1 ms into the next step:")
+    tend = step[-1][1]
+    for s, e, n, q, st in step + nxt:
+        if s > tend - 1200000 and s < tend + 1000000:
+            out.append(f"{(s - t0) / 1e6:9.3f} {(e - s) / 1e3:8.1f} {q:>5s}  {n}")
     txt = "\n".join(out)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(txt + "\n")
