@@ -627,6 +627,128 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3_k(
 }
 
 // ------------------------------------------------------------------------------------------
+// H = 256 (the reference's default dim_latent, hyperparameters.py:8): t = e W3^T + b3 + B1h[src] + B2h[dst] and the
+// BatchNorm sums in ONE pass over e (gated_gcn_full.py:113,120-122), split mode.  The three bf16 images of the
+// 256 x 256 weight are 384 KB -- no workgroup can keep them -- so a workgroup keeps ONE output half J (128 columns)
+// stationary in the registers of EIGHT waves = 4 column blocks of 32 x 2 contraction halves of 128 (96 VGPRs per wave,
+// as in edge_t32_b3_k), and the two workgroups of a row chunk (J = 0, 1) sit on one XCD and read the same e rows through
+// its L2.  Per 32-row tile: 512 threads stage the 32 x 256 tile into two image sets (one per contraction half), every
+// wave runs its 48 MFMAs, the two halves of the contraction meet in two fp32 LDS images that the epilogue adds.
+// 130 KB of LDS, one workgroup per CU.  Replaces gemm NT [E,256,256] + edge_t_stats_fwd (t written and re-read once).
+// ------------------------------------------------------------------------------------------
+constexpr int WH = 2 * FH;          // the wide hidden size
+constexpr int kBlockW = 512;
+__global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256_k(
+    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
+    const int32_t* __restrict__ idst, double* __restrict__ partials, int nchunk, int64_t tiles_per_chunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MmB3::kImgBytes];   // [contraction half][hi|mid|lo][2 x 32 rows]
+  __shared__ float os[2 * ER3 * FP];                                                  // [contraction half][32 rows] partial results
+  __shared__ int sd[2][2 * ER3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int cb = wave & 3, kh = wave >> 2;
+  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;
+  const int J = jj & 1, chunk = xcd * (nchunk / kXcds) + (jj >> 1);
+  const int64_t ntiles = (M + ER3 - 1) / ER3;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_chunk;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_chunk);
+  const int64_t nfull = min(tb1, M / ER3);
+  const int srow = tid >> 6, sc = (tid & 63) * 4;            // staging: 8 rows x 64 float4 per pass, 4 passes
+  unsigned char* const simg = xraw + (sc >> 7) * MmB3::kImgBytes;
+  const int slc4 = sc & (FH - 1);
+  const int erow = tid >> 5, ec4 = (tid & 31) * 4;           // epilogue: 16 rows x 32 float4 (this class's 128 columns), 2 passes
+  const int64_t Mlast = M - 1;
+  const int32_t* const ibase = (lane & 32) ? idst : isrc;    // lanes 0-31: src of row lane, 32-63: dst of row lane - 32
+
+  MmB3::Frag wf;
+  MmB3::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
+  const float4 b4 = ld4(bias + J * FH + ec4);
+  float4 pre[2][4];
+  int pidx[2] = {0, 0};
+  auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4(X + clampi(r0 + srow + 8 * it, Mlast) * WH + sc);   // shared with class 1 - J through L2
+    idx = ibase[clampi(r0 + (lane & 31), Mlast)];
+  };
+  Stat4 st;
+  st.zero();
+  auto body = [&](auto tag, float4 (&buf)[4], int& idx, int64_t tile, int hb) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) MmB3::stage(simg, 32 * hb + srow + 8 * it, slc4, buf[it]);
+    if (wave == 0) sd[hb][lane] = idx;
+    __syncthreads();
+    float4 g1[2], g2[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = erow + 16 * it;
+      const int64_t s_ = sd[hb][row], d_ = sd[hb][ER3 + row];
+      g1[it] = ld4(P + s_ * (5 * WH) + 3 * WH + J * FH + ec4);
+      g2[it] = ld4(P + d_ * (5 * WH) + 4 * WH + J * FH + ec4);
+    }
+    prefetch(buf, idx, tile + 2);
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    mma32_b3(xraw + kh * MmB3::kImgBytes, 32 * hb, wf, acc, li, lg);
+    float* const oh = os + kh * (ER3 * FP);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oh[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + cb * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = erow + 16 * it;
+      const int64_t grow = r0 + row;
+      const float4 v = (ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4)) + b4 + g1[it] + g2[it];
+      if (FULL || grow < M) {
+        st4_nt(Y + grow * WH + J * FH + ec4, v);
+        st.add_prod(v, v);
+      }
+    }
+  };
+  if (tb0 < tb1) {
+    prefetch(pre[0], pidx[0], tb0);
+    prefetch(pre[1], pidx[1], tb0 + 1);
+  }
+  int64_t tile = tb0;
+  for (; tile + 2 <= nfull; tile += 2) {
+    body(full_t{}, pre[0], pidx[0], tile, 0);
+    body(full_t{}, pre[1], pidx[1], tile + 1, 1);
+  }
+  int hb = 0;
+  for (; tile < tb1; ++tile, hb ^= 1) {
+    if (hb == 0) body(ragged_t{}, pre[0], pidx[0], tile, 0);
+    else body(ragged_t{}, pre[1], pidx[1], tile, 1);
+  }
+  // BatchNorm partial sums of this workgroup's 128 columns: lanes l and l ^ 32 hold the same columns, then 8 waves through LDS
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st.a[i] += __shfl_xor(st.a[i], 32, 64);
+    st.b[i] += __shfl_xor(st.b[i], 32, 64);
+  }
+  double* red = reinterpret_cast<double*>(xraw);             // [8 waves][2][128]
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[(wave * 2 + 0) * FH + lane * 4 + i] = st.a[i];
+      red[(wave * 2 + 1) * FH + lane * 4 + i] = st.b[i];
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * FH) {
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlockW / 64; ++w) acc += red[w * 2 * FH + tid];
+    partials[((size_t)chunk * 2 + (tid >> 7)) * WH + J * FH + (tid & (FH - 1))] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // fused edge backward: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
 // ------------------------------------------------------------------------------------------
 template <class MM>
@@ -1578,8 +1700,23 @@ static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, cons
 extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
                                     const float* P, const int32_t* isrc, const int32_t* idst, float* t,
                                     double* partials, int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(H == FH, "edge_t_fused_fwd: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(H == FH || (H == WH && g_matmul_mode), "edge_t_fused_fwd: H=%d (128, and 256 in the bf16x3 matmul mode, are built)", H);
   GNM_CHECK_ARG(E > 0 && e_in && W3 && b3 && P && isrc && idst && t && partials && nblk_out, "edge_t_fused_fwd: null/neg argument");
+  if (H == WH) {
+    GNM_CHECK_ARG(ws && ws_bytes >= (size_t)16 * MmB3::kPackBytes, "edge_t_fused_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pack_w3_gen_k, dim3(64), dim3(256), 0, st, W3, (int64_t)WH, 2, 2, 0, (bf16x8*)ws);
+    GNM_LAUNCH_CHECK("pack_w3_gen (NT 256)");
+    const int64_t ntiles = cdiv_(E, ER3);
+    int nchunk = num_cus() / 2 / kXcds * kXcds;            // one 8-wave workgroup per CU, two classes per chunk
+    if (nchunk < kXcds) nchunk = kXcds;
+    if (nchunk > kMaxPartialBlocks) nchunk = kMaxPartialBlocks / kXcds * kXcds;
+    hipLaunchKernelGGL(edge_t32_h256_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                       partials, nchunk, cdiv_(ntiles, nchunk));
+    GNM_LAUNCH_CHECK("edge_t_fused_fwd (256)");
+    *nblk_out = nchunk;
+    return 0;
+  }
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(FH), "edge_t_fused_fwd: workspace too small");
   return g_matmul_mode ? edge_t_fused_impl<MmB3>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream)
                        : edge_t_fused_impl<MmF32>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream);

@@ -37,7 +37,7 @@ LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
 ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
 
 
-_OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TN_SPLIT", "TWO_SIDED", "TWO_SIDED_FWD")
+_OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TN_SPLIT", "TWO_SIDED", "TWO_SIDED_FWD", "WIDE_FUSED")
 
 
 @contextlib.contextmanager
@@ -336,6 +336,14 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
         _call("gnm_node_proj_fwd", N, H, 5 * H, _ptr(h_in), _ptr(prm.W5), _ptr(prm.b5), _ptr(P), _ptr(ws), need, st)
         _call("gnm_edge_t_fused_fwd", E, H, _ptr(e_in), _ptr(prm.W3), _ptr(prm.b3), _ptr(P), _ptr(idx["isrc"]),
               _ptr(idx["idst"]), _ptr(t), _ptr(sc.partials), C.byref(nblk), _ptr(ws), need, st)
+    elif H == 256 and FUSED and WIDE_FUSED and e_in.shape[1] == H and _lib.get_matmul_mode() == "bf16x3":
+        # the reference's default width: projections through the split-mode GEMM, t + BatchNorm partials in one pass
+        # (a workgroup keeps one 128-column half of W3 stationary in eight waves)
+        gemm(NT, h_in, prm.W5, P, bias=prm.b5)
+        need = lib.gnm_rowtile_workspace_bytes(5 * H)
+        ws = sc.ws(need)
+        _call("gnm_edge_t_fused_fwd", E, H, _ptr(e_in), _ptr(prm.W3), _ptr(prm.b3), _ptr(P), _ptr(idx["isrc"]),
+              _ptr(idx["idst"]), _ptr(t), _ptr(sc.partials), C.byref(nblk), _ptr(ws), need, st, tag="gnm_edge_t_fused_fwd[256]")
     else:
         # dense projections                                                    (:107-113)
         gemm(NT, h_in, prm.W5, P, bias=prm.b5)
@@ -536,6 +544,9 @@ TWO_SIDED = os.environ.get("GNM_TWO_SIDED", "1") != "0"
 # the forward twin (gnm_edge_gate2_fwd): gate + by-destination AND by-source aggregation in one sweep; GNM_TWO_SIDED_FWD=0
 # keeps edge_gate_fwd + node_agg_src_fwd
 TWO_SIDED_FWD = os.environ.get("GNM_TWO_SIDED_FWD", "1") != "0"
+# H = 256 (the reference's default width): the fused forward kernel for t (gnm_edge_t_fused_fwd at H = 256);
+# GNM_WIDE_FUSED=0 keeps gemm NT + edge_t_stats_fwd
+WIDE_FUSED = os.environ.get("GNM_WIDE_FUSED", "1") != "0"
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
