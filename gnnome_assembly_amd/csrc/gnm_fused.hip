@@ -749,6 +749,90 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256_k(
 }
 
 // ------------------------------------------------------------------------------------------
+// H = 256 backward twin: gt = gamma*rstd*(gu - m1 - that*m2), gu = ge*[t*scale+shift > 0] (autograd of
+// gated_gcn_full.py:122) formed while the tile is staged, written ONCE for the weight-gradient GEMM, and
+// ge_out = ge + gt W3 (autograd of :113) in the same pass; organisation of edge_t32_h256_k (class J = output half of
+// ge_out, eight waves = 4 column blocks x 2 contraction halves of gt).  Both classes read all 256 columns of ge / t
+// (the second through L2), each writes its own half of gt and of ge_out: ge_out must NOT alias ge.
+// Replaces edge_bwd_gt + gemm NN [E,256,256] (gt re-read, ge read twice).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
+    int64_t M, const float* __restrict__ ge, const float* __restrict__ t, const float* __restrict__ stat,
+    const float* __restrict__ bstat, const float* __restrict__ gamma, const void* __restrict__ Wp,
+    float* __restrict__ gt, float* __restrict__ ge_out, int nchunk, int64_t tiles_per_chunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MmB3::kImgBytes];   // [contraction half][hi|mid|lo] (rows 0-31 used)
+  __shared__ float os[2 * ER3 * FP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int cb = wave & 3, kh = wave >> 2;
+  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;
+  const int J = jj & 1, chunk = xcd * (nchunk / kXcds) + (jj >> 1);
+  const int64_t ntiles = (M + ER3 - 1) / ER3;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_chunk;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_chunk);
+  const int64_t nfull = min(tb1, M / ER3);
+  const int srow = tid >> 6, sc = (tid & 63) * 4;
+  unsigned char* const simg = xraw + (sc >> 7) * MmB3::kImgBytes;
+  const int slc4 = sc & (FH - 1);
+  const bool mine = (sc >> 7) == J;                          // this thread's gt columns belong to this class's half
+  const int erow = tid >> 5, ec4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+
+  const float4 mu = ld4(stat + sc), rs = ld4(stat + WH + sc), scl = ld4(stat + 2 * WH + sc), sh = ld4(stat + 3 * WH + sc);
+  const float4 m1 = ld4(bstat + sc), m2 = ld4(bstat + WH + sc), cc = ld4(gamma + sc) * rs;
+  MmB3::Frag wf;
+  MmB3::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
+  float4 pg[4], pt[4];
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t o = clampi(r0 + srow + 8 * it, Mlast) * WH + sc;
+      pg[it] = ld4(ge + o);
+      pt[it] = ld4(t + o);
+    }
+  };
+  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t grow = r0 + srow + 8 * it;
+      const float4 gu = gate4(fma4(pt[it], scl, sh), pg[it]);
+      float4 g = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
+      if (!FULL && grow >= M) g = f4(0.f);
+      if (mine && (FULL || grow < M)) st4_nt(gt + grow * WH + sc, g);
+      MmB3::stage(simg, srow + 8 * it, slc4, g);
+    }
+    __syncthreads();
+    float4 rr[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) rr[it] = ld4(ge + clampi(r0 + erow + 16 * it, Mlast) * WH + J * FH + ec4);   // L2: staged a moment ago
+    prefetch(tile + 1);
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    mma32_b3(xraw + kh * MmB3::kImgBytes, 0, wf, acc, li, lg);
+    float* const oh = os + kh * (ER3 * FP);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oh[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + cb * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = erow + 16 * it;
+      const int64_t grow = r0 + row;
+      const float4 v = (ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4)) + rr[it];
+      if (FULL || grow < M) st4_nt(ge_out + grow * WH + J * FH + ec4, v);
+    }
+  };
+  if (tb0 < tb1) prefetch(tb0);
+  int64_t tile = tb0;
+  for (; tile < nfull; ++tile) body(full_t{}, tile);
+  for (; tile < tb1; ++tile) body(ragged_t{}, tile);
+}
+
+// ------------------------------------------------------------------------------------------
 // fused edge backward: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
 // ------------------------------------------------------------------------------------------
 template <class MM>
@@ -1720,6 +1804,26 @@ extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const f
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(FH), "edge_t_fused_fwd: workspace too small");
   return g_matmul_mode ? edge_t_fused_impl<MmB3>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream)
                        : edge_t_fused_impl<MmF32>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream);
+}
+
+// edge_bwd_gt + ge_out = ge + gt W3 at H = 256 (bf16x3 matmul mode), see edge_gt_nn_h256_k; ge_out != ge
+extern "C" int gnm_edge_bwd_gt_nn(int64_t E, int H, const float* ge, const float* t, const float* stat_e, const float* bstat_e,
+                                  const float* gamma_e, const float* W3, float* gt, float* ge_out, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  GNM_CHECK_ARG(H == WH && g_matmul_mode, "edge_bwd_gt_nn: H=%d (256 in the bf16x3 matmul mode is what is built)", H);
+  GNM_CHECK_ARG(E > 0 && ge && t && stat_e && bstat_e && gamma_e && W3 && gt && ge_out && ge_out != ge && gt != ge,
+                "edge_bwd_gt_nn: null / aliased argument (ge_out and gt must not be ge)");
+  GNM_CHECK_ARG(ws && ws_bytes >= (size_t)16 * MmB3::kPackBytes, "edge_bwd_gt_nn: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pack_w3_gen_k, dim3(64), dim3(256), 0, st, W3, (int64_t)WH, 2, 2, 1, (bf16x8*)ws);
+  GNM_LAUNCH_CHECK("pack_w3_gen (NN 256)");
+  const int64_t ntiles = cdiv_(E, ER3);
+  int nchunk = num_cus() / 2 / kXcds * kXcds;
+  if (nchunk < kXcds) nchunk = kXcds;
+  hipLaunchKernelGGL(edge_gt_nn_h256_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, ge, t, stat_e, bstat_e, gamma_e, (const void*)ws,
+                     gt, ge_out, nchunk, cdiv_(ntiles, nchunk));
+  GNM_LAUNCH_CHECK("edge_bwd_gt_nn");
+  return 0;
 }
 
 template <class MM>

@@ -486,6 +486,17 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             ws = sc.ws(need)
             _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need, st)
+        elif H == 256 and FUSED and WIDE_FUSED and residual and Hin == H and _lib.get_matmul_mode() == "bf16x3":
+            # the reference's default width: gt and ge_in = ge_tot + gt W3 from one pass, gt kept for the weight-gradient GEMM
+            gt = torch.empty(E, H, **f32)
+            ge_in = torch.empty(E, H, **f32)
+            need = lib.gnm_rowtile_workspace_bytes(5 * H)
+            ws = sc.ws(need)
+            _call("gnm_edge_bwd_gt_nn", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e),
+                  _ptr(prm.W3), _ptr(gt), _ptr(ge_in), _ptr(ws), need, st)
+            ge = ge_in
+            g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
+            del gt
         else:
             gt = torch.empty(E, H, **f32)
             _call("gnm_edge_bwd_gt", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 3   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps */
+#define GNM_ABI_VERSION 4   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -273,9 +273,18 @@ size_t gnm_rowtile_workspace_bytes(int ncols);
 int gnm_debug_set_variant(const char* what, int v);   /* A/B switches between kernel generations (tests, tools) */
 int gnm_set_matmul_mode(int mode);
 int gnm_get_matmul_mode(void);
+/* H = 128 in both matmul modes; H = 256 (the reference's default dim_latent, hyperparameters.py:8) in the bf16x3 mode: a
+ * workgroup of eight waves keeps one 128-column half of W3 stationary, the two halves of the contraction meet in LDS
+ * (ws >= gnm_rowtile_workspace_bytes(5 * H)).                                    gated_gcn_full.py:113,120-122 */
 int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
                          const float* P, const int32_t* isrc, const int32_t* idst, float* t,
                          double* partials, int* nblk_out, void* ws, size_t ws_bytes, void* stream);
+/* H = 256, bf16x3 mode: gt = gamma*rstd*(gu - m1 - that*m2) (what gnm_edge_bwd_gt writes) AND ge_out = ge + gt W3 in one
+ * pass over ge and t; gt is kept for the weight-gradient GEMM (gW3 = gt^T e_in).  ge_out and gt must not alias ge.
+ * ws >= gnm_rowtile_workspace_bytes(5 * H).                                 autograd of gated_gcn_full.py:113,122 */
+int gnm_edge_bwd_gt_nn(int64_t E, int H, const float* ge, const float* t, const float* stat_e, const float* bstat_e,
+                       const float* gamma_e, const float* W3, float* gt, float* ge_out, void* ws, size_t ws_bytes,
+                       void* stream);
 int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, const float* W, const float* b,
                       float* Pout, void* ws, size_t ws_bytes, void* stream);
 /* edge_bwd_chain (bf16x3 mode, H = 128): gnm_edge_bwd_fused of layer i ("hi": ge, t_hi, e_mid = e_in(i) = e_out(i-1),
