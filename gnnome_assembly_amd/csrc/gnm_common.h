@@ -166,7 +166,9 @@ struct Stat4 {
 // Reduce Stat4 over the sub-groups of a wave (lanes with equal lane % G), then over the
 // block's 4 waves through LDS, and write partials[chunk][2][H] (fp64).  G = H/4 lanes per
 // row.  `lds` must hold kWavesPerBlock*2*H doubles.
-template <int H>
+// HF > H: the partial rows are HF wide and this call fills columns [0, H) of them (`partials` already points at the
+// first of those columns): a 256-wide layer run as two 128-column problems.
+template <int H, int HF = H>
 __device__ __forceinline__ void block_stat_store(Stat4& s, double* lds, double* partials, int chunk) {
   constexpr int G = H / 4;
   const int lane = threadIdx.x & 63;
@@ -191,7 +193,7 @@ __device__ __forceinline__ void block_stat_store(Stat4& s, double* lds, double* 
     double acc = 0.0;
 #pragma unroll
     for (int w = 0; w < kWavesPerBlock; ++w) acc += lds[w * 2 * H + idx];
-    partials[(size_t)chunk * 2 * H + idx] = acc;
+    partials[(size_t)chunk * 2 * HF + (idx / H) * HF + (idx % H)] = acc;
   }
 }
 

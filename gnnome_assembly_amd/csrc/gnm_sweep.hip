@@ -14,6 +14,8 @@
 // additions: deterministic, no atomics.  Nodes the plan does not serve (out-edges in more than one workgroup: chunk
 // boundaries, repeat edges; no out-edges) are covered by node_agg_src_fix_k (gathers, a few per cent of the rows);
 // z = A1h + hf + hb and the BatchNorm_h column sums by node_z_stats_k.                                 :145-147
+#include <type_traits>
+
 #include "gnm_tr.h"
 
 namespace gnm {
@@ -40,7 +42,9 @@ __device__ __forceinline__ u32x4g_ bits4g(const float4& v) {
 }
 
 // INV = false (a forward under no_grad): inv_f / inv_b -- which only the backward reads -- are not stored
-template <bool RES, bool INV>
+// HF = the row pitch of every tensor (floats) = the layer's full width: 128, or 256 with the kernel run once per 128-column
+// half (the sweep is column-separable; the caller offsets every pointer by the half's first column)
+template <bool RES, bool INV, int HF>
 __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[G2_LDS];
   float* i1 = reinterpret_cast<float*>(lds);          // sigma * A2h[src]
@@ -58,17 +62,17 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   const int64_t rb = a.in_ptr[v0], re = a.in_ptr[v1];
   const int64_t ntile = (re - rb + GR - 1) / GR;
   for (int c = tid; c < SW; c += GT) {
-    cs[c] = a.stat[2 * SW + c];
-    cs[SW + c] = a.stat[3 * SW + c];
+    cs[c] = a.stat[2 * HF + c];
+    cs[SW + c] = a.stat[3 * HF + c];
   }
   // outputs as buffers: rows outside the range (a lane that has nothing to store carries offset 0x80000000) are dropped
   const int64_t vbase = v0 - a.margin;
   const int nspan = (int)(v1 - v0 + 2 * a.margin);
-  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(a.e_out + rb * SW, 0, (int)(re - rb) * SW * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_hf = __builtin_amdgcn_make_buffer_rsrc(a.hf + v0 * SW, 0, (int)(v1 - v0) * SW * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_if = __builtin_amdgcn_make_buffer_rsrc(INV ? a.inv_f + v0 * SW : a.hf, 0, INV ? (int)(v1 - v0) * SW * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_hb = __builtin_amdgcn_make_buffer_rsrc(a.hb + vbase * SW, 0, nspan * SW * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ib = __builtin_amdgcn_make_buffer_rsrc(INV ? a.inv_b + vbase * SW : a.hb, 0, INV ? nspan * SW * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(a.e_out + rb * HF, 0, (int)(re - rb) * HF * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hf = __builtin_amdgcn_make_buffer_rsrc(a.hf + v0 * HF, 0, (int)(v1 - v0) * HF * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_if = __builtin_amdgcn_make_buffer_rsrc(INV ? a.inv_f + v0 * HF : a.hf, 0, INV ? (int)(v1 - v0) * HF * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hb = __builtin_amdgcn_make_buffer_rsrc(a.hb + vbase * HF, 0, nspan * HF * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ib = __builtin_amdgcn_make_buffer_rsrc(INV ? a.inv_b + vbase * HF : a.hb, 0, INV ? nspan * HF * 4 : 0, 0x00020000);
   __syncthreads();
   if (ntile == 0) return;
 
@@ -92,13 +96,13 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     fj = cr == row ? w2 : 0u;
   };
   auto prefetch_rows = [&](int64_t k, float4& pt, float4& pe_) __attribute__((always_inline)) {
-    const int64_t o = (rb + k * GR + clamp_row(k)) * SW + c4;
+    const int64_t o = (rb + k * GR + clamp_row(k)) * HF + c4;
     pt = ld4_nt(a.t + o);
     if constexpr (RES) pe_ = ld4_nt(a.e_in + o);
   };
   auto gather = [&](int64_t s, int64_t d) __attribute__((always_inline)) {
-    ga2 = ld4(a.P + s * (5 * SW) + SW + c4);
-    ga3 = ld4(a.P + d * (5 * SW) + 2 * SW + c4);
+    ga2 = ld4(a.P + s * (5 * HF) + HF + c4);
+    ga3 = ld4(a.P + d * (5 * HF) + 2 * HF + c4);
   };
   auto ring_put = [&](int64_t k) __attribute__((always_inline)) {
     if ((tid & 31) == 0) {
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     {
       const bool live = row < nvalid;
       const float4 eo = relu4(fma4(pt, sc, sh)) + pe_;
-      __builtin_amdgcn_raw_buffer_store_b128(bits4g(eo), rs_e, live ? (int)(((k * GR + row) * SW + c4) * 4) : (int)0x80000000, 0, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(bits4g(eo), rs_e, live ? (int)(((k * GR + row) * HF + c4) * 4) : (int)0x80000000, 0, 2);
       const float4 sg = live ? sigmoid4(eo) : f4(0.f);
       st4(i1 + row * SW + c4, sg * ga2);
       st4(i2 + row * SW + c4, sg);
@@ -189,13 +193,13 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
       const bool outd = ld_ && (wd & kSweepClose), outs = ls_ && (ws_ & kSweepClose);
       if (__builtin_amdgcn_ballot_w64(outd) != 0) {
         const float4 inv = make_float4(1.f / (dd.x + kEpsDen), 1.f / (dd.y + kEpsDen), 1.f / (dd.z + kEpsDen), 1.f / (dd.w + kEpsDen));
-        const int o = outd ? ((rk[GR + row] - (int)v0) * SW + c4) * 4 : (int)0x80000000;
+        const int o = outd ? ((rk[GR + row] - (int)v0) * HF + c4) * 4 : (int)0x80000000;
         __builtin_amdgcn_raw_buffer_store_b128(bits4g(dn_ * inv), rs_hf, o, 0, 2);
         if constexpr (INV) __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_if, o, 0, 2);
       }
       if (__builtin_amdgcn_ballot_w64(outs) != 0) {
         const float4 inv = make_float4(1.f / (sdn.x + kEpsDen), 1.f / (sdn.y + kEpsDen), 1.f / (sdn.z + kEpsDen), 1.f / (sdn.w + kEpsDen));
-        const int o = outs ? ((rk[row] - (int)vbase) * SW + c4) * 4 : (int)0x80000000;
+        const int o = outs ? ((rk[row] - (int)vbase) * HF + c4) * 4 : (int)0x80000000;
         __builtin_amdgcn_raw_buffer_store_b128(bits4g(sn_ * inv), rs_hb, o, 0, 2);
         if constexpr (INV) __builtin_amdgcn_raw_buffer_store_b128(bits4g(inv), rs_ib, o, 0, 2);
       }
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
 }
 
 // hf / inv_f of the nodes WITHOUT in-edges (the sweep only ever stores to nodes that own rows): 0 and 1 / 1e-6
+template <int HF>
 __global__ __launch_bounds__(256) void gate2_empty_segments_k(int64_t N, const int32_t* __restrict__ in_ptr,
                                                               float* __restrict__ hf, float* __restrict__ inv_f) {
   const int lane = threadIdx.x & 63;
@@ -224,13 +229,14 @@ __global__ __launch_bounds__(256) void gate2_empty_segments_k(int64_t N, const i
       m &= m - 1;
       const int64_t u = base + b;
       const int c4 = (lane & 31) * 4;
-      if (lane < 32) st4(hf + u * SW + c4, f4(0.f));
-      else if (inv_f) st4(inv_f + u * SW + c4, f4(1.f / kEpsDen));
+      if (lane < 32) st4(hf + u * HF + c4, f4(0.f));
+      else if (inv_f) st4(inv_f + u * HF + c4, f4(1.f / kEpsDen));
     }
   }
 }
 
 // hb / inv_b of the nodes the sweep plan does not serve: node_agg_src_fwd_k's gathers over a node list
+template <int HF>
 __global__ __launch_bounds__(kBlock, 8) void node_agg_src_fix_k(int64_t nfix, const int32_t* __restrict__ fix_nodes,
                                                                 const float* __restrict__ e_out, const float* __restrict__ P,
                                                                 const int32_t* __restrict__ out_ptr,
@@ -247,8 +253,8 @@ __global__ __launch_bounds__(kBlock, 8) void node_agg_src_fix_k(int64_t nfix, co
     float4 num = f4(0.f), den = f4(0.f);
     for (int64_t m = a + sub; m < b; m += RPW) {
       const int64_t j = out_pos[m], d = out_dst[m];
-      const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
-      num = fma4(sg, ld4(P + d * (5 * H) + 2 * H + c4), num);
+      const float4 sg = sigmoid4(ld4_nt(e_out + j * HF + c4));
+      num = fma4(sg, ld4(P + d * (5 * HF) + 2 * HF + c4), num);
       den += sg;
     }
 #pragma unroll
@@ -259,13 +265,14 @@ __global__ __launch_bounds__(kBlock, 8) void node_agg_src_fix_k(int64_t nfix, co
     if (sub == 0) {
       const float4 inv = make_float4(1.f / (den.x + kEpsDen), 1.f / (den.y + kEpsDen), 1.f / (den.z + kEpsDen),
                                      1.f / (den.w + kEpsDen));
-      st4_nt(hb + v * H + c4, num * inv);
-      if (inv_b) st4_nt(inv_b + v * H + c4, inv);
+      st4_nt(hb + v * HF + c4, num * inv);
+      if (inv_b) st4_nt(inv_b + v * HF + c4, inv);
     }
   }
 }
 
 // z = A1h + hf + hb, partial (sum z, sum z^2)                                     gated_gcn_full.py:145-147
+template <int HF>
 __global__ __launch_bounds__(kBlock) void node_z_stats_k(int64_t N, const float* __restrict__ P, const float* __restrict__ hf,
                                                          const float* __restrict__ hb, float* __restrict__ z,
                                                          double* __restrict__ partials, int64_t rows_per_block) {
@@ -279,11 +286,11 @@ __global__ __launch_bounds__(kBlock) void node_z_stats_k(int64_t N, const float*
   Stat4 st;
   st.zero();
   for (int64_t v = r0 + wave * RPW + sub; v < r1; v += kWavesPerBlock * RPW) {
-    const float4 zz = ld4_nt(P + v * (5 * H) + c4) + ld4_nt(hf + v * H + c4) + ld4_nt(hb + v * H + c4);
-    st4_nt(z + v * H + c4, zz);
+    const float4 zz = ld4_nt(P + v * (5 * HF) + c4) + ld4_nt(hf + v * HF + c4) + ld4_nt(hb + v * HF + c4);
+    st4_nt(z + v * HF + c4, zz);
     st.add_prod(zz, zz);
   }
-  block_stat_store<H>(st, lds, partials, chunk);
+  block_stat_store<H, HF>(st, lds, partials, chunk);
 }
 
 }  // namespace gnm
@@ -304,7 +311,7 @@ extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, c
                                   int64_t nfix, const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos,
                                   const int32_t* out_dst, float* e_out, float* hf, float* inv_f, float* hb, float* inv_b,
                                   float* z, double* partials, int* nblk_out, void* stream) {
-  GNM_CHECK_ARG(H == SW, "edge_gate2_fwd: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(H == SW || H == 2 * SW, "edge_gate2_fwd: H=%d (128 and 256 are built)", H);
   GNM_CHECK_ARG(N > 0 && E > 0 && t && stat_e && P && isrc && idst && in_ptr && sinfo && dinfo && (nfix == 0 || fix_nodes) &&
                     nfix >= 0 && out_ptr && out_pos && out_dst && e_out && hf && hb && z && partials && nblk_out &&
                     (inv_f != nullptr) == (inv_b != nullptr),
@@ -318,26 +325,39 @@ extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, c
   gnm_sweep_partition(N, 2, &a.nodes_per_block, &grid);
   GNM_CHECK_ARG(plan_nodes_per_block == a.nodes_per_block, "edge_gate2_fwd: the sweep plan was built for %lld nodes per workgroup, the "
                 "kernel uses %lld (gnm_sweep_partition(N, 2))", (long long)plan_nodes_per_block, (long long)a.nodes_per_block);
-  // 32-bit buffer offsets: the rows of one workgroup (x 512 B) and its node range + margins (x 512 B)
-  GNM_CHECK_ARG((a.nodes_per_block + 2 * kSweepMargin) * SW * 4 < (int64_t)INT32_MAX && E / grid < (1 << 21),
+  // 32-bit buffer offsets: the rows of one workgroup (x 4 H bytes) and its node range + margins (x 4 H bytes)
+  GNM_CHECK_ARG((a.nodes_per_block + 2 * kSweepMargin) * H * 4 < (int64_t)INT32_MAX && (E / grid + 64) * H * 4 < (int64_t)INT32_MAX,
                 "edge_gate2_fwd: a workgroup's share exceeds the 32-bit buffer offsets");
-  hipLaunchKernelGGL(gate2_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, N, in_ptr, hf, inv_f);
-  if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true>), dim3(grid), dim3(GT), 0, st, a);
-  else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false>), dim3(grid), dim3(GT), 0, st, a);
-  else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true>), dim3(grid), dim3(GT), 0, st, a);
-  else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false>), dim3(grid), dim3(GT), 0, st, a);
-  GNM_LAUNCH_CHECK("edge_gate2_fwd");
-  if (nfix > 0) {
-    int64_t g2 = (nfix + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t cap = (int64_t)num_cus() * 8;
-    if (g2 > cap) g2 = cap;
-    hipLaunchKernelGGL(node_agg_src_fix_k, dim3((int)g2), dim3(kBlock), 0, st, nfix, fix_nodes, e_out, P, out_ptr, out_pos,
-                       out_dst, hb, inv_b);
-    GNM_LAUNCH_CHECK("edge_gate2_fwd fix");
+  const int gz = H == SW ? persistent_grid(N, 256, occ_blocks<node_z_stats_k<SW>>()) : persistent_grid(N, 256, occ_blocks<node_z_stats_k<2 * SW>>());
+  auto run = [&](auto hf_tag, int c0) -> int {
+    constexpr int HF = decltype(hf_tag)::value;
+    Gate2Args b = a;              // this 128-column problem: every pointer starts at the half's first column
+    b.t = t + c0; b.e_in = e_in ? e_in + c0 : nullptr; b.stat = stat_e + c0; b.P = P + c0; b.e_out = e_out + c0; b.hf = hf + c0;
+    b.inv_f = inv_f ? inv_f + c0 : nullptr; b.hb = hb + c0; b.inv_b = inv_b ? inv_b + c0 : nullptr;
+    hipLaunchKernelGGL(gate2_empty_segments_k<HF>, dim3(num_cus() * 2), dim3(256), 0, st, N, in_ptr, b.hf, b.inv_f);
+    if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true, HF>), dim3(grid), dim3(GT), 0, st, b);
+    else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false, HF>), dim3(grid), dim3(GT), 0, st, b);
+    else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true, HF>), dim3(grid), dim3(GT), 0, st, b);
+    else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false, HF>), dim3(grid), dim3(GT), 0, st, b);
+    GNM_LAUNCH_CHECK("edge_gate2_fwd");
+    if (nfix > 0) {
+      int64_t g2 = (nfix + kWavesPerBlock - 1) / kWavesPerBlock;
+      const int64_t cap = (int64_t)num_cus() * 8;
+      if (g2 > cap) g2 = cap;
+      hipLaunchKernelGGL(node_agg_src_fix_k<HF>, dim3((int)g2), dim3(kBlock), 0, st, nfix, fix_nodes, b.e_out, b.P, out_ptr, out_pos,
+                         out_dst, b.hb, b.inv_b);
+      GNM_LAUNCH_CHECK("edge_gate2_fwd fix");
+    }
+    hipLaunchKernelGGL(node_z_stats_k<HF>, dim3(gz), dim3(kBlock), 0, st, N, b.P, b.hf, b.hb, z + c0, partials + c0, (N + gz - 1) / gz);
+    GNM_LAUNCH_CHECK("edge_gate2_fwd z");
+    return 0;
+  };
+  if (H == SW) {
+    if (run(std::integral_constant<int, SW>{}, 0)) return -2;
+  } else {
+    for (int c0 = 0; c0 < H; c0 += SW)
+      if (run(std::integral_constant<int, 2 * SW>{}, c0)) return -2;
   }
-  const int gz = persistent_grid(N, 256, occ_blocks<node_z_stats_k>());
-  hipLaunchKernelGGL(node_z_stats_k, dim3(gz), dim3(kBlock), 0, st, N, P, hf, hb, z, partials, (N + gz - 1) / gz);
-  GNM_LAUNCH_CHECK("edge_gate2_fwd z");
   *nblk_out = gz;
   return 0;
 }

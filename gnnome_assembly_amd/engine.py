@@ -360,7 +360,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
     Returns (h_out, e_out, LayerSaved or None).  H = out_channels; h_in [N,Hin], e_in [E,Hin] with Hin != H only
     when residual is False (the reference drops the residual then: gated_gcn_full.py:41-42).
-    plan (graph.sweep_plan(device, 2), BatchNorm, H = 128): gate + by-source aggregation as ONE two-sided sweep."""
+    plan (graph.sweep_plan(device, 2), BatchNorm, H = 128 or 256): gate + by-source aggregation as ONE two-sided sweep."""
     if residual and h_in.shape[1] != H:
         raise _lib.GnmError("layer_forward: a residual layer needs in_channels == out_channels")
     res_e = _ptr(e_in) if residual else C.c_void_p(0)
@@ -375,7 +375,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
-    two_sided = plan is not None and batch_norm and H == 128 and TWO_SIDED_FWD
+    two_sided = plan is not None and batch_norm and H in (128, 256) and TWO_SIDED_FWD      # 256: one sweep per 128-column half
     inv_f = torch.empty(N, H, **f32) if (save or not two_sided) else None      # inv_f / inv_b: only the backward reads them
     if two_sided:
         hb = torch.empty(N, H, **f32)
@@ -926,7 +926,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw) if save else None
-    plan2 = graph.sweep_plan(dev, 2) if (TWO_SIDED_FWD and batch_norm and H == 128 and hasattr(graph, "sweep_plan")) else None
+    plan2 = graph.sweep_plan(dev, 2) if (TWO_SIDED_FWD and batch_norm and H in (128, 256) and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
         h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2)
         if save:
