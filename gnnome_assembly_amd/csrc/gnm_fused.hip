@@ -1919,28 +1919,32 @@ extern "C" int gnm_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const fl
                                 const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, float* gP, float* Ud,
                                 float* Td, double* partials, const uint32_t* sinfo, int64_t plan_nodes_per_block,
                                 float* UT, int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(H == FH, "edge_bwd_top: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(H == FH || (H == 2 * FH && sinfo), "edge_bwd_top: H=%d (128; 256 with a sweep plan, one sweep per 128-column half)", H);
   GNM_CHECK_ARG(N > 0 && E > 0 && ge && e_out && t && stat_e && P && Q && hf && hb && isrc && idst && in_ptr && gP && Ud &&
                     Td && partials && nblk_out && (!sinfo || UT), "edge_bwd_top: null argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "edge_bwd_top: workspace %zu < %zu", ws_bytes,
                 gnm_edge_bwd_fused_workspace_bytes());
-  ChainArgs a{};
-  a.E = E; a.N = N;
-  a.ge = ge; a.ge_out = ge; a.e_mid = e_out;                     // t_hi == NULL selects the sweep without a layer above
-  a.slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
-  a.t_lo = t; a.stat_lo = stat_e; a.P_lo = P; a.Q_lo = Q; a.hf_lo = hf; a.hb_lo = hb;
-  a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
-  a.gP_lo = gP; a.Ud_lo = Ud; a.Td_lo = Td; a.partials_lo = partials;
-  a.sinfo = sinfo; a.UT_lo = UT; a.margin = kSweepMargin;
-  a.ud_pitch = Td == Ud + FH ? 2 * FH : FH;
   int64_t npb = 0;
   gnm_sweep_partition(N, 1, &npb, nullptr);
-  GNM_CHECK_ARG((npb + 2 * kSweepMargin) * 5 * FH * 4 < (int64_t)INT32_MAX, "edge_bwd_top: %lld nodes per workgroup exceed the 32-bit buffer offsets",
+  GNM_CHECK_ARG((npb + 2 * kSweepMargin) * 5 * H * 4 < (int64_t)INT32_MAX, "edge_bwd_top: %lld nodes per workgroup exceed the 32-bit buffer offsets",
                 (long long)npb);
   GNM_CHECK_ARG(!sinfo || plan_nodes_per_block == npb, "edge_bwd_top: the sweep plan was built for %lld nodes per workgroup, the kernel uses %lld",
                 (long long)plan_nodes_per_block, (long long)npb);
-  *nblk_out = edge_bwd_chain_launch(a, nullptr, nullptr, (hipStream_t)stream);
-  GNM_LAUNCH_CHECK("edge_bwd_top");
+  for (int c0 = 0; c0 < H; c0 += FH) {                             // a 256-wide layer = two 128-column problems with row pitch 256
+    ChainArgs a{};
+    a.E = E; a.N = N; a.hfull = H;
+    a.ge = ge + c0; a.ge_out = ge + c0; a.e_mid = e_out + c0;      // t_hi == NULL selects the sweep without a layer above
+    a.slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+    a.t_lo = t + c0; a.stat_lo = stat_e + c0; a.P_lo = P + c0; a.Q_lo = Q + c0; a.hf_lo = hf + c0; a.hb_lo = hb + c0;
+    a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
+    a.gP_lo = gP + c0; a.Ud_lo = Ud + c0; a.Td_lo = Td + c0; a.partials_lo = partials + c0;
+    a.sinfo = sinfo; a.UT_lo = UT ? UT + c0 : nullptr; a.margin = kSweepMargin;
+    a.ud_pitch = Td == Ud + H ? 2 * H : H;
+    const int g = edge_bwd_chain_launch(a, nullptr, nullptr, (hipStream_t)stream);
+    GNM_CHECK_ARG(g > 0, "edge_bwd_top: no kernel for this configuration");
+    *nblk_out = g;
+    GNM_LAUNCH_CHECK("edge_bwd_top");
+  }
   return 0;
 }
 

@@ -155,6 +155,7 @@ struct ChainArgs {
   // (gnm_graph_build_sweep_plan over THIS partition): gA2h -> gP_lo[:,H:2H], Us | Ts -> UT_lo [N,2H]
   // Ud_lo / Td_lo may be the two halves of ONE [N,2H] array (ud_pitch = 2H) or two [N,H] arrays (ud_pitch = H)
   const uint32_t* sinfo; float* UT_lo; int64_t margin; int ud_pitch;
+  int hfull;       // row pitch of the layer-(i-1) tensors (0 / 128: 128; 256: the top sweep of a 256-wide layer, one half per launch)
 };
 
 constexpr int kSweepTileRows = 16;      // rows per tile of the sweep kernels (= ER of gnm_tr.hip)

@@ -443,8 +443,11 @@ struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][
 // not.  Not shipped.)
 // HI = false: no layer i above (the TOP layer of the stack: ge is d loss / d e_out of layer i-1 as the predictor's backward
 // left it): phase 0 only parks the rows, no gt, no MFMAs, no gW3 -- the sweep is edge_bwd_dst_k (+ the by-source sums).
-template <int ABL, bool SRC, bool WSKIP = true, bool HI = true>
+// HF = the row pitch (floats) of every layer-(i-1) tensor = that layer's full width: 128, or 256 with the HI = false sweep run
+// once per 128-column half (column-separable; the caller offsets every pointer by the half's first column)
+template <int ABL, bool SRC, bool WSKIP = true, bool HI = true, int HF = SW>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
+  static_assert(HF == SW || !HI, "the chained (matrix) half of the kernel is built for 128-wide layers only");
   __shared__ __attribute__((aligned(16))) unsigned char lds[SRC ? CH_LDS_SRC : CH_LDS];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
@@ -481,9 +484,9 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       cs[6 * SW + c] = a.gamma_hi[c] * a.stat_hi[SW + c];
     }
     cl[c] = a.stat_lo[c];
-    cl[SW + c] = a.stat_lo[SW + c];
-    cl[2 * SW + c] = a.stat_lo[2 * SW + c];
-    cl[3 * SW + c] = a.stat_lo[3 * SW + c];
+    cl[SW + c] = a.stat_lo[HF + c];
+    cl[2 * SW + c] = a.stat_lo[2 * HF + c];
+    cl[3 * SW + c] = a.stat_lo[3 * HF + c];
   }
   W3Frag16 wf;
   if constexpr (HI) {
@@ -519,8 +522,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // whole sum; a node's ~5 stores meet in L2): no data-dependent branch around a memory operation, so hipcc keeps
   // COUNTED vmcnt waits for the prefetched rows (a store under such a branch costs vmcnt(0) = a full drain of the
   // software pipeline on every tile).  Nodes without in-edges are zeroed by zero_empty_segments_k beforehand.
-  float* const wout = role == 0 ? a.gP_lo + 2 * SW : role == 1 ? a.Td_lo : a.Ud_lo;      // (wave-uniform)
-  const int wpitch32 = role == 0 ? 5 * SW : a.ud_pitch;
+  float* const wout = role == 0 ? a.gP_lo + 2 * HF : role == 1 ? a.Td_lo : a.Ud_lo;      // (wave-uniform)
+  const int wpitch32 = role == 0 ? 5 * HF : a.ud_pitch;
   // the walkers' output rows as a buffer over THIS workgroup's node range (32-bit offsets whatever N; rows outside are dropped)
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(wout + v0 * wpitch32, 0, (int)(v1n - v0) * wpitch32 * 4, 0x00020000);
   // target of the throw-away stores (rows past the chunk, scoreboard equalisation): a slab of its own BEHIND the
@@ -530,9 +533,9 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   const int64_t vbase = v0 - a.margin;
   const int nspan = (int)(v1n - v0 + 2 * a.margin);
   const __amdgpu_buffer_rsrc_t srs_g = __builtin_amdgcn_make_buffer_rsrc(
-      SRC ? a.gP_lo + vbase * (5 * SW) + SW : a.gP_lo, 0, SRC ? nspan * 5 * SW * 4 : 0, 0x00020000);
+      SRC ? a.gP_lo + vbase * (5 * HF) + HF : a.gP_lo, 0, SRC ? nspan * 5 * HF * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t srs_u = __builtin_amdgcn_make_buffer_rsrc(
-      SRC ? a.UT_lo + vbase * (2 * SW) : a.gP_lo, 0, SRC ? nspan * 2 * SW * 4 : 0, 0x00020000);
+      SRC ? a.UT_lo + vbase * (2 * HF) : a.gP_lo, 0, SRC ? nspan * 2 * HF * 4 : 0, 0x00020000);
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
@@ -562,19 +565,19 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   };
   auto prefetch_rows = [&](int64_t k) __attribute__((always_inline)) {
     const int64_t r0 = rb + k * ER;
-    const int o = clamp_row(k) * SW + lc4;
-    pg = ld4(a.ge + r0 * SW + o);
-    if constexpr (HI) pt = ld4(a.t_hi + r0 * SW + o);
-    pe_ = ld4(a.e_mid + r0 * SW + o);
-    pl = ld4_nt(a.t_lo + r0 * SW + o);
+    const int o = clamp_row(k) * HF + lc4;
+    pg = ld4(a.ge + r0 * HF + o);
+    if constexpr (HI) pt = ld4(a.t_hi + r0 * HF + o);
+    pe_ = ld4(a.e_mid + r0 * HF + o);
+    pl = ld4_nt(a.t_lo + r0 * HF + o);
   };
   auto gather = [&](int64_t s, int64_t d) __attribute__((always_inline)) {   // node rows of the edge s -> d
-    ga2 = ld4(a.P_lo + s * (5 * SW) + SW + lc4);
-    gqb = ld4(a.Q_lo + s * (2 * SW) + SW + lc4);
-    ghb = ld4(a.hb_lo + s * SW + lc4);
-    gqf = ld4(a.Q_lo + d * (2 * SW) + lc4);
-    ghf = ld4(a.hf_lo + d * SW + lc4);
-    ga3 = ld4(a.P_lo + d * (5 * SW) + 2 * SW + lc4);
+    ga2 = ld4(a.P_lo + s * (5 * HF) + HF + lc4);
+    gqb = ld4(a.Q_lo + s * (2 * HF) + HF + lc4);
+    ghb = ld4(a.hb_lo + s * HF + lc4);
+    gqf = ld4(a.Q_lo + d * (2 * HF) + lc4);
+    ghf = ld4(a.hf_lo + d * HF + lc4);
+    ga3 = ld4(a.P_lo + d * (5 * HF) + 2 * HF + lc4);
   };
 
   if (ntile > 0) {
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       const float4 gsig = fma4(gqf, ga2, fma4(gqb, ga3, f4(0.f) - gqf * ghf - gqb * ghb));
       const float4 g = fma4(gsig, dsg, ge4);
       const bool live = row < nvalid;        // rows past the chunk repeat its last row's indices: their terms are zeroed HERE
-      st4_nt(live ? a.ge_out + (r0 + row) * SW + lc4 : dummy_row, g);
+      st4_nt(live ? a.ge_out + (r0 + row) * HF + lc4 : dummy_row, g);
       st4(v1 + row * SW + lc4, live ? sg * gqb : f4(0.f));
       st4(v2 + row * SW + lc4, live ? gate4(fma4(tt, sc, sh), g) : f4(0.f));
       st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
@@ -790,12 +793,12 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
           }
           const bool out = lead && (w[u] & kSweepClose);
           const int sn = sdk[rr[u]] - (int)vbase;
-          const int og_ = out ? (sn * (5 * SW) + wc4) * 4 : (int)0x80000000;
-          const int ou_ = out ? (sn * (2 * SW) + wc4) * 4 : (int)0x80000000;
+          const int og_ = out ? (sn * (5 * HF) + wc4) * 4 : (int)0x80000000;
+          const int ou_ = out ? (sn * (2 * HF) + wc4) * 4 : (int)0x80000000;
           if (!(ABL & 16) && __builtin_amdgcn_ballot_w64(out) != 0) {
             __builtin_amdgcn_raw_buffer_store_b128(bits4(s1[u]), srs_g, og_, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(bits4(s2[u]), srs_u, ou_, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(bits4(s3[u]), srs_u, ou_, SW * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(bits4(s3[u]), srs_u, ou_, HF * 4, 0);
           }
         }
       }
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       double s_ = 0.0;
 #pragma unroll
       for (int g8 = 0; g8 < 8; ++g8) s_ += bnr[g8 * 2 * SW + tid];
-      a.partials_lo[(size_t)chunk * 2 * SW + tid] = s_;
+      a.partials_lo[(size_t)chunk * 2 * HF + (tid / SW) * HF + (tid % SW)] = s_;
     }
     __syncthreads();
   }
@@ -856,6 +859,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
 
 
 // gA3h / Ud / Td rows of the nodes WITHOUT in-edges (the column walkers only ever store to nodes that own rows)
+template <int HF>
 __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const int32_t* __restrict__ in_ptr,
                                                              float* __restrict__ gP, float* __restrict__ Ud,
                                                              float* __restrict__ Td, int ud_pitch) {
@@ -872,7 +876,7 @@ __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const in
       const int64_t u = base + b;
       const int c4 = (lane & 31) * 4;
       if (lane < 32) {
-        st4(gP + u * (5 * SW) + 2 * SW + c4, f4(0.f));
+        st4(gP + u * (5 * HF) + 2 * HF + c4, f4(0.f));
         st4(Td + u * ud_pitch + c4, f4(0.f));
       } else {
         st4(Ud + u * ud_pitch + c4, f4(0.f));
@@ -888,7 +892,13 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   a.Wp = (const bf16x8*)wpack;
   int grid = 0;
   gnm_sweep_partition(a.N, 1, &a.nodes_per_block, &grid);  // one 512-thread workgroup per CU
-  hipLaunchKernelGGL(zero_empty_segments_k, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo, a.ud_pitch);
+  if (a.hfull == 2 * SW) {                           // a 256-wide layer's sweep, one 128-column half: top of the stack only
+    hipLaunchKernelGGL(zero_empty_segments_k<2 * SW>, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo, a.ud_pitch);
+    if (a.t_hi || !a.sinfo) return -1;
+    hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, false, 2 * SW>), dim3(grid), dim3(CT), 0, st, a);
+    return grid;
+  }
+  hipLaunchKernelGGL(zero_empty_segments_k<SW>, dim3(num_cus() * 2), dim3(256), 0, st, a.N, a.in_ptr, a.gP_lo, a.Ud_lo, a.Td_lo, a.ud_pitch);
 #ifdef GNM_TIMING_ABLATIONS      // builds for timing experiments only: the ablated kernels give wrong results
   static const int abl = getenv("GNM_CHAIN_ABL") ? atoi(getenv("GNM_CHAIN_ABL")) : 0;
   switch (abl) {

@@ -419,7 +419,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
 
 @on_device_of(lambda idx, N, E, H, prm, s, gh_out, *a, **k: gh_out)
 def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True,
-                   out: Optional[Dict[str, torch.Tensor]] = None, residual: bool = True):
+                   out: Optional[Dict[str, torch.Tensor]] = None, residual: bool = True, plan: Optional[dict] = None):
     """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
     and is OVERWRITTEN with d loss / d e_in (residual layers; without the residual the returned ge is a fresh [E,Hin]
     tensor).  Returns (gh_in, ge, grads dict).  `out` (optional) names the tensors
@@ -467,17 +467,36 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
         _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
               _ptr(gh_out), _ptr(s.inv_f), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
-        # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
-        Ud = torch.empty(N, H, **f32)
-        Td = torch.empty(N, H, **f32)
-        _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
-              _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
-              _ptr(sc.partials), C.byref(nblk), st)
-        bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
-        # by-source pass: gA2h, gB1h, gB2h
-        _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
-              _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
-              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), 0, st)
+        if plan is not None and H == 256 and TWO_SIDED:
+            # the two-sided sweep of the chained schedule's top layer, once per 128-column half (row pitch 256): by-destination
+            # AND by-source sums from one pass over ge, e_out, t; then the unserved sources and the conversion through m1, m2
+            UT = torch.empty(N, 2 * H, **f32)
+            DT = torch.empty(N, 2 * H, **f32)
+            Ud, Td = DT[:, :H], DT[:, H:]
+            need_f = lib.gnm_edge_bwd_fused_workspace_bytes()
+            ws = sc.ws(need_f)
+            _call("gnm_edge_bwd_top", N, E, H, _ptr(ge), _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(s.P), _ptr(Q), _ptr(s.hf),
+                  _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+                  _ptr(sc.partials), _ptr(plan["sinfo"]), plan["nodes_per_block"], _ptr(UT), C.byref(nblk), _ptr(ws), need_f, st)
+            _call("gnm_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s.e_out), _ptr(s.t),
+                  _ptr(s.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
+                  _ptr(gP), _ptr(UT), st)
+            bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
+            _call("gnm_node_bgrad", N, H, _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(idx["in_ptr"]),
+                  _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), _ptr(gP), st)
+            del UT, DT
+        else:
+            # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
+            Ud = torch.empty(N, H, **f32)
+            Td = torch.empty(N, H, **f32)
+            _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
+                  _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+                  _ptr(sc.partials), C.byref(nblk), st)
+            bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
+            # by-source pass: gA2h, gB1h, gB2h
+            _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+                  _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
+                  _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), 0, st)
         del Ud, Td, Q
         # gt, B_3 gradients, ge_in = ge_tot + gt W3
         if fused:
@@ -974,6 +993,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     ms.pred = None
     louts = [grad_targets(out, i) if out else None for i in range(num_layers)]
     chained = None
+    plan_w = graph.sweep_plan(dev) if (H == 256 and batch_norm and TWO_SIDED and hasattr(graph, "sweep_plan")) else None
     if chain_eligible(H, batch_norm):
         plan = graph.sweep_plan(dev) if TWO_SIDED and hasattr(graph, "sweep_plan") else None
         gh, ge, chained = layers_backward_chained(idx, N, E, H, P, num_layers, ms.layers, gh, ge, louts, plan)
@@ -983,7 +1003,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
         if chained is not None:
             gl = chained[i]
         else:
-            gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout)
+            gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout, plan=plan_w)
             ms.layers[i] = None     # release this layer's activations
         for j, k in enumerate(LIN5):
             G[p + k + ".weight"] = gl["W5"][j * H:(j + 1) * H]
