@@ -931,7 +931,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     h = torch.empty(N, H, **f32)
     gemm(NT, pe, P["linear_pe.weight"], h, bias=P["linear_pe.bias"])
     Fe, Q = e_raw.shape[1], P["linear1_edge.weight"].shape[0]
-    fused_enc = FUSED and H == 128 and Fe == 2 and Q == 16
+    fused_enc = FUSED and (H == 128 or (H == 256 and WIDE_FUSED)) and Fe == 2 and Q == 16
     e = torch.empty(E, H, **f32)
     e_int = a1 = None
     if fused_enc:
