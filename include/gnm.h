@@ -173,7 +173,8 @@ int gnm_edge_t_stats_fwd(int64_t E, int H, float* t, const float* P, const int32
 int gnm_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in,
                       const float* stat_e, const float* P, const int32_t* isrc,
                       const int32_t* in_ptr, float* e_out, float* hf, float* inv_f, void* stream);
-/* edge_gate2 (H = 128): gnm_edge_gate_fwd AND gnm_node_agg_src_fwd as ONE two-sided sweep over the destination-sorted
+/* edge_gate2 (H = 128; H = 256: the sweep is column-separable and runs once per 128-column half with row pitch 256):
+ *   gnm_edge_gate_fwd AND gnm_node_agg_src_fwd as ONE two-sided sweep over the destination-sorted
  *   rows (same outputs: e_out, hf, inv_f, hb, inv_b, z, BatchNorm_h partials; e_out is not re-read): the by-source
  *   sums through the sweep plan (sinfo / dinfo / fix_nodes of gnm_graph_build_sweep_plan over
  *   gnm_sweep_partition(N, 2)); the plan's fix_nodes are covered by gathers.  inv_f == inv_b == NULL: a forward
@@ -318,7 +319,9 @@ int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* 
                            const int32_t* in_ptr, float* gP_lo, float* Ud_lo, float* Td_lo, double* partials_lo,
                            const uint32_t* sinfo, int64_t plan_nodes_per_block, float* UT_lo,
                            int* nblk_out, void* ws, size_t ws_bytes, void* stream);
-/* edge_bwd_top: the top layer of the stack (no layer above to chain with): gnm_edge_bwd_dst on the chained kernel's sweep
+/* edge_bwd_top (H = 128; H = 256 with a sweep plan: once per 128-column half with row pitch 256 -- the by-destination and
+ * by-source backward of EVERY layer of a 256-wide stack, followed by gnm_edge_bwd_src_fix / gnm_node_bgrad at H = 256):
+ * the top layer of the stack (no layer above to chain with): gnm_edge_bwd_dst on the chained kernel's sweep
  * (ge updated in place to ge + gsigma*sigma', gP[:,2H:3H], Ud, Td, BatchNorm_e backward partials) plus, with sinfo, the
  * by-source sums exactly as gnm_edge_bwd_chain_src leaves them (then gnm_edge_bwd_src_fix, gnm_node_bgrad).          */
 int gnm_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const float* e_out, const float* t, const float* stat_e,
@@ -348,7 +351,7 @@ int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const f
                        const float* W3, float* gW3, float* gb3, double* partials, void* ws,
                        size_t ws_bytes, void* stream);
 
-/* ---- edge-feature encoder (full_graph.py:24-26), H = 128, edge_features F = 2, hidden Q = 16 ----
+/* ---- edge-feature encoder (full_graph.py:24-26), H = 128 or 256, edge_features F = 2, hidden Q = 16 ----
  * fwd: e0[j] = W2 relu(W1 e_raw[perm j] + b1) + b2, internal order, one pass writing [E,H]
  *      (gnm_gather_rows + 2 gemm NT).
  * bwd: from ge0 [E,H]: gW2 [H,Q], gb2 [H], gW1 [Q,F], gb1 [Q] in one pass reading ge0 once

@@ -1189,6 +1189,57 @@ def test_two_sided_forward_sweep_matches_the_separate_passes(ids):
     assert not bad, bad
 
 
+@pytest.mark.default_mode_only
+def test_wide_layers_fused_kernels_and_sweeps_match_the_generic_route():
+    """H = 256 (the reference's default dim_latent, hyperparameters.py:8).  Default: t + BatchNorm sums from the fused forward
+    kernel (edge_t32_h256_k), gt and ge_in from one pass (edge_gt_nn_h256_k), the fused edge-encoder kernels, and the two-sided
+    sweeps of the 128-wide path run once per 128-column half with row pitch 256.  engine.WIDE_FUSED / TWO_SIDED / TWO_SIDED_FWD
+    off = the generic route (split-mode GEMMs, gt and B_3 e materialised, separate by-source passes).  Same arithmetic up to
+    the order of the fp32 sums: logits within 2e-6 (rel-L2), gradients at the bar they have against the oracle, every
+    configuration run-to-run bit-identical; on generator node ids and on shuffled ones (the renumbered index)."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    for ids in ("sorted", "shuffled"):
+        model, src, dst, n, inp = _model_and_inputs(30000, 256, 3, 21, dev)
+        pe_np = inp["pe"]
+        if ids == "shuffled":
+            p = np.random.default_rng(6).permutation(n).astype(np.int32)
+            src, dst = p[src], p[dst]
+            pe_s = np.empty_like(pe_np)
+            pe_s[p] = pe_np
+            pe_np = pe_s
+        g = G.AssemblyGraph(src, dst, n).to(dev)
+        e, pe, y = torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(pe_np).to(dev), torch.from_numpy(inp["y"]).to(dev)
+        crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+
+        def run(**opts):
+            with engine.options(**opts):
+                model.zero_grad(set_to_none=True)
+                s = model(g, None, e, pe)
+                loss = crit(s.squeeze(-1), y)
+                loss.backward()
+                torch.cuda.synchronize()
+                return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
+        base = run(WIDE_FUSED=False, TWO_SIDED=False, TWO_SIDED_FWD=False)
+        for name, opts in (("fused kernels", dict(TWO_SIDED=False, TWO_SIDED_FWD=False)),
+                           ("fused kernels + two-sided sweeps (default)", dict())):
+            s1, l1, g1 = run(**opts)
+            s2, l2, g2 = run(**opts)
+            assert torch.equal(s1, s2) and l1 == l2 and all(torch.equal(g1[k], g2[k]) for k in g1), (ids, name, "not deterministic")
+            r = rel_l2(s1.cpu().numpy(), base[0].cpu().numpy())
+            print(f"H = 256, {name} vs the generic route [{ids}]: logits rel_l2 = {r:.2e}")
+            assert r <= 2e-6 and abs(l1 - base[1]) <= 1e-6 * abs(base[1]), (ids, name, r)
+            gmax = max(float(v.abs().max()) for v in base[2].values())
+            bad = []
+            for k in base[2]:
+                a, b = g1[k].double(), base[2][k].double()
+                rr = float((a - b).norm() / b.norm().clamp_min(1e-30))
+                if rr > GRAD_L2 and float((a - b).abs().max()) > 1e-6 * gmax:
+                    bad.append((k, rr))
+            assert not bad, (ids, name, bad)
+
+
 def _adversarial_graphs():
     """Graphs the sweep plan has to get right without the band it was designed for."""
     rng = np.random.default_rng(12)
@@ -1211,15 +1262,17 @@ def _adversarial_graphs():
 
 
 @pytest.mark.default_mode_only
-def test_two_sided_sweeps_on_graphs_without_a_band():
-    """The two-sided sweeps on graphs the plan was not designed for (no locality, hubs with thousands of rows, paths, self loops and
+@pytest.mark.parametrize("H", [128, 256])
+def test_two_sided_sweeps_on_graphs_without_a_band(H):
+    """(H = 256: the same sweeps once per 128-column half, row pitch 256.)
+    The two-sided sweeps on graphs the plan was not designed for (no locality, hubs with thousands of rows, paths, self loops and
     duplicates, more simultaneously open sources than accumulator slots, five nodes): whatever the plan leaves to the fix-up
     kernels, logits and gradients equal the separate-pass schedule's (logits 2e-6 rel-L2, gradients at the oracle bar) and two runs
     are bit-identical."""
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import engine, synth
     dev = _dev()
-    H, L = 128, 2
+    L = 2
     sd = synth.synth_state_dict(H, L, 3)
     for name, (src, dst, n) in _adversarial_graphs().items():
         rng = np.random.default_rng(len(name))
