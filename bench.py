@@ -83,6 +83,8 @@ def op_model(op: str, N: int, E: int, H: int):
         "gnm_edge_bwd_src": (3 * eh + 6 * nh, 0.0),           # e_out, t, ge in; Qf Ud Td in; gA2h gB1h gB2h out
         "gnm_edge_bwd_gt": (3 * eh, 0.0),                     # ge, t in; gt out
         "gnm_edge_t_fused_fwd": (2 * eh + 2 * nh, 2.0 * E * H * H),        # e_in in, t out, B1h/B2h rows
+        "gnm_edge_t_fused_fwd[256]": (2 * eh + 2 * nh, 2.0 * E * H * H),   # the 256-wide kernel (eight waves, one half of W3 stationary)
+        "gnm_edge_bwd_gt_nn": (4 * eh, 2.0 * E * H * H),                   # H = 256: ge, t in; gt, ge_in out; NN
         "gnm_edge_bwd_fused": (4 * eh, 4.0 * E * H * H),                   # ge in/out, t, e_in; NN + TN
         # fused(i) chained with dst(i-1): ge'(i), t(i), e_out(i-1), t(i-1) in; ge'(i-1) out; node rows as edge_bwd_dst
         "gnm_edge_bwd_chain": (5 * eh + 9 * nh, 4.0 * E * H * H),

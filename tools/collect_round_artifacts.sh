@@ -17,9 +17,11 @@ python tools/minibatch_epoch.py > $O/minibatch.log 2>&1; cp gpurun_out/minibatch
 if [ -z "$FAST" ]; then
   OUTDIR=traffic_shuf EXTRA="--shuffle-nodes" tools/collect_traffic.sh > $O/traffic_shuf.log 2>&1
   python tools/traffic_summary.py gpurun_out/traffic_shuf $O/traffic_shuffled.json $(cat .git_head) > $O/traffic_shuffled.txt 2>&1
-  for R in 110000 500000 1000000; do python bench.py --reads $R --steps 5 --warmup 2 --no-cpu-baseline --no-alt-orders > $O/train_R$R.json 2>/dev/null; done
+  for R in 110000 375000 500000 1000000; do python bench.py --reads $R --steps 5 --warmup 2 --no-cpu-baseline --no-alt-orders > $O/train_R$R.json 2>/dev/null; done
   for R in 750000 3000000; do python bench.py --reads $R --inference --steps 5 --warmup 2 --no-cpu-baseline > $O/infer_R$R.json 2>/dev/null; done
   python bench.py --hidden 256 --reads 375000 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-matmul --no-alt-orders > $O/h256.json 2>/dev/null
+  for m in "0 0 0" "1 0 0" "1 0 1" "1 1 1"; do set -- $m; GNM_WIDE_FUSED=$1 GNM_TWO_SIDED=$2 GNM_TWO_SIDED_FWD=$3 python bench.py --hidden 256 --reads 375000 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-matmul --no-alt-orders 2>/dev/null | python -c "
+import json,sys;b=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('H=256 wide_fused=$1 two_sided_bwd=$2 two_sided_fwd=$3', round(b['ms_per_step'],2), 'ms/step;', {k:round(v,2) for k,v in b['op_ms'].items() if v>5})" >> $O/h256_steps.txt; done
   python bench.py --shuffle-nodes --steps 10 --warmup 3 --no-cpu-baseline --no-alt-matmul > $O/bench_shuffled_nodes.json 2>/dev/null
   python tools/minibatch_epoch.py --shuffle-nodes > $O/minibatch_shuffled.log 2>&1; cp gpurun_out/minibatch_shuffled.json $O/ 2>/dev/null
   for m in "1 1" "0 1" "1 0" "0 0"; do set -- $m; GNM_TWO_SIDED=$1 GNM_TWO_SIDED_FWD=$2 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt-matmul --no-alt-orders 2>/dev/null | python -c "
