@@ -721,6 +721,14 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
         elif side is not None and i > 0:
             pending = (gP, s.h_in, g["W5"], g["b5"])
+        elif side is None and i > 0 and TN_SPLIT and plan is not None:
+            # no side stream (lean activations, per-op timing): the same two launches the deferred path issues, back to back --
+            # the row partition of a launch depends on its column-group count, and the two modes must stay bit-identical
+            ws_t = sc.ws(max(need_p, need_f, need_t))
+            _call("gnm_tn128", N, _ptr(gP[:, 3 * H:]), 5 * H, 2, _ptr(s.h_in), _ptr(g["W5"][3 * H:]), _ptr(g["b5"][3 * H:]),
+                  _ptr(sc.partials), _ptr(ws_t), need_t, st, tag="gnm_node_proj_bwd_tn")
+            _call("gnm_tn128", N, _ptr(gP), 5 * H, 3, _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc.partials), _ptr(ws_t),
+                  need_t, st, tag="gnm_node_proj_bwd_tn")
         else:
             _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
                   _ptr(sc.partials), _ptr(ws), need_p, 0, st)
