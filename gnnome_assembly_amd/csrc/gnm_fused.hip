@@ -748,13 +748,153 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256_k(
   }
 }
 
+// edge_t32_h256_k with the split / staging of tile k+1 issued INSIDE the matrix phase of tile k: a wave's 48 MFMAs are one
+// dependent chain (62 cycles apiece on its own), which leaves the vector ALU idle -- the next tile's 4 rows per thread are
+// split and written to the OTHER half of the image set between the chunks of the chain, so that per tile only the epilogue
+// stays outside the matrix phase.  Same arithmetic, same summation order: bit-identical results.
+__global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
+    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
+    const int32_t* __restrict__ idst, double* __restrict__ partials, int nchunk, int64_t tiles_per_chunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MmB3::kImgBytes];
+  __shared__ float os[2 * ER3 * FP];
+  __shared__ int sd[2][2 * ER3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int cb = wave & 3, kh = wave >> 2;
+  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;
+  const int J = jj & 1, chunk = xcd * (nchunk / kXcds) + (jj >> 1);
+  const int64_t ntiles = (M + ER3 - 1) / ER3;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_chunk;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_chunk);
+  const int64_t nfull = min(tb1, M / ER3);
+  const int srow = tid >> 6, sc = (tid & 63) * 4;
+  unsigned char* const simg = xraw + (sc >> 7) * MmB3::kImgBytes;
+  const int slc4 = sc & (FH - 1);
+  const int erow = tid >> 5, ec4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  const int32_t* const ibase = (lane & 32) ? idst : isrc;
+
+  MmB3::Frag wf;
+  MmB3::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
+  const float4 b4 = ld4(bias + J * FH + ec4);
+  float4 pre[2][4];
+  int pidx[2] = {0, 0};
+  auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4(X + clampi(r0 + srow + 8 * it, Mlast) * WH + sc);
+    idx = ibase[clampi(r0 + (lane & 31), Mlast)];
+  };
+  Stat4 st;
+  st.zero();
+  // tile `tile` is staged in image half hb; (nbuf, nidx) hold tile + 1, which is staged into half hb ^ 1 during the MFMAs
+  auto body = [&](auto tag, float4 (&nbuf)[4], int& nidx, int64_t tile, int hb) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * ER3;
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    {
+      const __bf16* p0 = reinterpret_cast<const __bf16*>(xraw + kh * MmB3::kImgBytes) + (32 * hb + li) * BP + 8 * lg;
+      bf16x8 a0[3];
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) a0[s_] = *reinterpret_cast<const bf16x8*>(p0 + s_ * BIMG);
+#pragma unroll
+      for (int c = 0; c < BKC; ++c) {
+        bf16x8 n0[3];               // the next chunk's fragments are requested before this chunk's MFMAs (one workgroup per CU:
+#pragma unroll                      // nobody else hides the LDS round trip)
+        for (int s_ = 0; s_ < 3; ++s_) n0[s_] = c + 1 < BKC ? *reinterpret_cast<const bf16x8*>(p0 + s_ * BIMG + 16 * (c + 1)) : a0[s_];
+        __builtin_amdgcn_sched_barrier(0);
+        mfb(acc, a0[2], wf.w[c][0]);
+        mfb(acc, a0[0], wf.w[c][2]);
+        mfb(acc, a0[1], wf.w[c][1]);
+        if (c < 4) MmB3::stage(simg, 32 * (hb ^ 1) + srow + 8 * c, slc4, nbuf[c]);     // the next tile, one row per chunk
+        mfb(acc, a0[1], wf.w[c][0]);
+        mfb(acc, a0[0], wf.w[c][1]);
+        mfb(acc, a0[0], wf.w[c][0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) a0[s_] = n0[s_];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float4 g1[2], g2[2];          // this tile's B1h[src] / B2h[dst] rows: in flight across the two barriers below
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = erow + 16 * it;
+      const int64_t s_ = sd[hb][row], d_ = sd[hb][ER3 + row];
+      g1[it] = ld4(P + s_ * (5 * WH) + 3 * WH + J * FH + ec4);
+      g2[it] = ld4(P + d_ * (5 * WH) + 4 * WH + J * FH + ec4);
+    }
+    if (wave == 0) sd[hb ^ 1][lane] = nidx;
+    prefetch(nbuf, nidx, tile + 3);
+    __syncthreads();          // every wave is past the previous tile's epilogue: the partial-result images are free
+    float* const oh = os + kh * (ER3 * FP);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oh[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + cb * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = erow + 16 * it;
+      const int64_t grow = r0 + row;
+      const float4 v = (ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4)) + b4 + g1[it] + g2[it];
+      if (FULL || grow < M) {
+        st4_nt(Y + grow * WH + J * FH + ec4, v);
+        st.add_prod(v, v);
+      }
+    }
+  };
+  if (tb0 < tb1) {
+    prefetch(pre[0], pidx[0], tb0);
+    prefetch(pre[1], pidx[1], tb0 + 1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) MmB3::stage(simg, srow + 8 * it, slc4, pre[0][it]);
+    if (wave == 0) sd[0][lane] = pidx[0];
+    prefetch(pre[0], pidx[0], tb0 + 2);
+    __syncthreads();
+  }
+  int64_t tile = tb0;
+  for (; tile + 2 <= nfull; tile += 2) {
+    body(full_t{}, pre[1], pidx[1], tile, 0);
+    body(full_t{}, pre[0], pidx[0], tile + 1, 1);
+  }
+  int hb = 0;
+  for (; tile < tb1; ++tile, hb ^= 1) {
+    if (hb == 0) body(ragged_t{}, pre[1], pidx[1], tile, 0);
+    else body(ragged_t{}, pre[0], pidx[0], tile, 1);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st.a[i] += __shfl_xor(st.a[i], 32, 64);
+    st.b[i] += __shfl_xor(st.b[i], 32, 64);
+  }
+  double* red = reinterpret_cast<double*>(xraw);
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[(wave * 2 + 0) * FH + lane * 4 + i] = st.a[i];
+      red[(wave * 2 + 1) * FH + lane * 4 + i] = st.b[i];
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * FH) {
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlockW / 64; ++w) acc += red[w * 2 * FH + tid];
+    partials[((size_t)chunk * 2 + (tid >> 7)) * WH + J * FH + (tid & (FH - 1))] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // H = 256 backward twin: gt = gamma*rstd*(gu - m1 - that*m2), gu = ge*[t*scale+shift > 0] (autograd of
 // gated_gcn_full.py:122) formed while the tile is staged, written ONCE for the weight-gradient GEMM, and
 // ge_out = ge + gt W3 (autograd of :113) in the same pass; organisation of edge_t32_h256_k (class J = output half of
 // ge_out, eight waves = 4 column blocks x 2 contraction halves of gt).  Both classes read all 256 columns of ge / t
 // (the second through L2), each writes its own half of gt and of ge_out: ge_out must NOT alias ge.
-// Replaces edge_bwd_gt + gemm NN [E,256,256] (gt re-read, ge read twice).
+// Replaces edge_bwd_gt + gemm NN [E,256,256] (gt re-read, ge read twice).  (Staging the next tile inside the matrix phase as
+// edge_t32_h256p_k does was measured here too: 31.2 vs 30.8 ms per step -- this kernel moves twice the bytes and waits on HBM.)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
     int64_t M, const float* __restrict__ ge, const float* __restrict__ t, const float* __restrict__ stat,
@@ -1732,6 +1872,7 @@ static int g_chain_variant = 0;  // chained edge backward: 0 = edge_bwd_chain_k 
 int chain_variant() { return g_chain_variant; }
 static int g_enc_bwd = 1;        // edge encoder backward: 1 = fp32-MFMA kernel, 0 = VALU kernel (round 1)
 int enc_bwd_variant() { return g_enc_bwd; }
+static int g_wide_pipe = 1;      // H = 256 forward t kernel: 1 = next tile staged inside the matrix phase, 0 = phases one after the other
 static int g_enc_fwd = 1;        // edge encoder forward: 1 = fp32-MFMA kernel, 0 = VALU kernel
 int enc_fwd_variant() { return g_enc_fwd; }
 }
@@ -1741,6 +1882,7 @@ extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "chain")) { g_chain_variant = v; return 0; }
   if (what && !strcmp(what, "enc_bwd")) { g_enc_bwd = v; return 0; }
   if (what && !strcmp(what, "enc_fwd")) { g_enc_fwd = v; return 0; }
+  if (what && !strcmp(what, "wide_pipe")) { g_wide_pipe = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }
@@ -1795,8 +1937,12 @@ extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const f
     int nchunk = num_cus() / 2 / kXcds * kXcds;            // one 8-wave workgroup per CU, two classes per chunk
     if (nchunk < kXcds) nchunk = kXcds;
     if (nchunk > kMaxPartialBlocks) nchunk = kMaxPartialBlocks / kXcds * kXcds;
-    hipLaunchKernelGGL(edge_t32_h256_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
-                       partials, nchunk, cdiv_(ntiles, nchunk));
+    if (g_wide_pipe)
+      hipLaunchKernelGGL(edge_t32_h256p_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                         partials, nchunk, cdiv_(ntiles, nchunk));
+    else
+      hipLaunchKernelGGL(edge_t32_h256_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                         partials, nchunk, cdiv_(ntiles, nchunk));
     GNM_LAUNCH_CHECK("edge_t_fused_fwd (256)");
     *nblk_out = nchunk;
     return 0;
