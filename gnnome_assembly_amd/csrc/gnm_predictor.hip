@@ -57,12 +57,24 @@ __device__ __forceinline__ void mf4(floatx16& acc, const float4& a, const float4
 // prefetch in front of the MFMAs (measured: 70 % of wave time parked).  The ragged last tile runs
 // through a predicated copy of the body.
 // ------------------------------------------------------------------------------------------
-template <bool SAVE>
-__global__ __launch_bounds__(kBlock, 2) void pred_fwd_k(
+// PHT = the edge feature width: 128 (two workgroups per CU), or 256 (the reference's default dim_latent: the e tile image is 66 KB,
+// one workgroup per CU, W1e's 64 x 256 block of a wave in 128 registers)
+template <int PHT> struct PredDims {
+  static constexpr int PEP = PHT + 4;                 // LDS pitch of the e tile / ge output image
+  static constexpr int CPR = PHT / 4;                 // threads per row of the coalesced tile image
+  static constexpr int RPP = kBlock / CPR;            // rows per pass
+  static constexpr int NP = PT / RPP;                 // passes per 64-row tile
+  static constexpr int NB = PHT / 128;                // 32-column blocks of the e width per wave (backward)
+};
+
+template <bool SAVE, int PHT>
+__global__ __launch_bounds__(kBlock, PHT == 128 ? 2 : 1) void pred_fwd_k(
     int64_t E, const float* __restrict__ e, const float* __restrict__ Wp, const float* __restrict__ b1,
     const float* __restrict__ Pn, const int32_t* __restrict__ isrc, const int32_t* __restrict__ idst,
     const int32_t* __restrict__ perm, const float* __restrict__ W2, const float* __restrict__ b2,
     float* __restrict__ hid, float* __restrict__ scores, int64_t tiles_per_block) {
+  using D = PredDims<PHT>;
+  constexpr int PEP = D::PEP, NP = D::NP, RPP = D::RPP;
   __shared__ float xs[PT * PEP];
   __shared__ float os[PT * PGP];
   __shared__ int sidx[4 * PT];
@@ -75,26 +87,26 @@ __global__ __launch_bounds__(kBlock, 2) void pred_fwd_k(
   const int64_t tb0 = (int64_t)chunk * tiles_per_block;
   const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
   const int64_t nfull = min(tb1, E / PT);
-  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;      // e tile image: 8 rows x 32 float4 per pass
+  const int lrow = tid / D::CPR, lc4 = (tid % D::CPR) * 4;   // e tile image: RPP rows x PHT / 4 float4 per pass
   const int er = tid >> 4, ec4 = (tid & 15) * 4;        // hid tile image: 16 rows x 16 float4 per pass
   const int64_t Elast = E - 1;
   const int32_t* const ibase = wave == 0 ? isrc : wave == 1 ? idst : perm;   // wave 3 re-reads perm (unused)
 
-  float4 wf[PH / 8];
+  float4 wf[PHT / 8];
   {
-    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)cb * (PH / 8)) * 64 + lane;
+    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)cb * (PHT / 8)) * 64 + lane;
 #pragma unroll
-    for (int q = 0; q < PH / 8; ++q) wf[q] = p[q * 64];
+    for (int q = 0; q < PHT / 8; ++q) wf[q] = p[q * 64];
   }
   const float4 b1v = ld4(b1 + ec4), w2v = ld4(W2 + ec4);
   const float b2v = b2[0];
 
-  float4 pre[8];
+  float4 pre[NP];
   int pre_idx = 0;
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = tile * PT;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) pre[it] = ld4_nt(e + clampr(r0 + lrow + 8 * it, Elast) * PH + lc4);
+    for (int it = 0; it < NP; ++it) pre[it] = ld4_nt(e + clampr(r0 + lrow + RPP * it, Elast) * PHT + lc4);
     pre_idx = ibase[clampr(r0 + lane, Elast)];
   };
   auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(kBlock, 2) void pred_fwd_k(
     const int64_t r0 = tile * PT;
     __syncthreads();   // previous tile's epilogue is done with os / sidx, its MFMAs with xs
 #pragma unroll
-    for (int it = 0; it < 8; ++it) st4(xs + (lrow + 8 * it) * PEP + lc4, pre[it]);
+    for (int it = 0; it < NP; ++it) st4(xs + (lrow + RPP * it) * PEP + lc4, pre[it]);
     sidx[tid] = pre_idx;
     __syncthreads();
     // this tile's Ps[src] / Pd[dst] rows: issued now, consumed after the MFMAs
@@ -120,7 +132,10 @@ __global__ __launch_bounds__(kBlock, 2) void pred_fwd_k(
     {
       const float* p = xs + (rb * 32 + li) * PEP + 4 * lg;
 #pragma unroll
-      for (int q = 0; q < PH / 8; ++q) mf4(acc, ld4(p + 8 * q), wf[q]);
+      for (int q = 0; q < PHT / 8; ++q) {
+        mf4(acc, ld4(p + 8 * q), wf[q]);
+        if (PHT > 128 && (q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep hipcc from hoisting every fragment read
+      }
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) os[(rb * 32 + (k & 3) + 8 * (k >> 2) + 4 * lg) * PGP + cb * 32 + li] = acc[k];
@@ -145,12 +160,15 @@ __global__ __launch_bounds__(kBlock, 2) void pred_fwd_k(
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock, 2) void pred_bwd_k(
+template <int PHT>
+__global__ __launch_bounds__(kBlock, PHT == 128 ? 2 : 1) void pred_bwd_k(
     int64_t E, float* __restrict__ hid, const float* __restrict__ gscore, const int32_t* __restrict__ perm,
     const float* __restrict__ W2, const float* __restrict__ e, const float* __restrict__ Wp,   // W1e packed NN
-    float* __restrict__ ge, float* __restrict__ slab,      // [grid][64][128] partial gW1e
+    float* __restrict__ ge, float* __restrict__ slab,      // [grid][64][PHT] partial gW1e
     double* __restrict__ partials,                         // [grid][3][64]: sum gs*relu(hid) | sum ghid | sum gs
     int64_t tiles_per_block) {
+  using D = PredDims<PHT>;
+  constexpr int PEP = D::PEP, NP = D::NP, RPP = D::RPP, NB = D::NB;
   __shared__ float gsm[PT * PGP];      // ghid tile
   __shared__ float es[PT * PEP];       // e tile, later the ge output image
   __shared__ float gsc[4 * PT];        // gscore of the tile's rows (one copy per wave)
@@ -162,31 +180,35 @@ __global__ __launch_bounds__(kBlock, 2) void pred_bwd_k(
   const int64_t tb0 = (int64_t)chunk * tiles_per_block;
   const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
   const int64_t nfull = min(tb1, E / PT);
-  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int lrow = tid / D::CPR, lc4 = (tid % D::CPR) * 4;
   const int er = tid >> 4, ec4 = (tid & 15) * 4;
   const int64_t Elast = E - 1;
+  const int cb0 = wave * NB;           // this wave's NB 32-column blocks of the e width: cb0 .. cb0 + NB - 1
 
-  float4 wf[PS / 8];   // W1e as the NN operand: this wave's output columns wave*32 .. +31, K = 64
-  {
-    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)wave * (PS / 8)) * 64 + lane;
+  float4 wf[NB][PS / 8];   // W1e as the NN operand: this wave's output columns, K = 64
 #pragma unroll
-    for (int q = 0; q < PS / 8; ++q) wf[q] = p[q * 64];
+  for (int b = 0; b < NB; ++b) {
+    const float4* p = reinterpret_cast<const float4*>(Wp) + ((int64_t)(cb0 + b) * (PS / 8)) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < PS / 8; ++q) wf[b][q] = p[q * 64];
   }
   const float4 w2v = ld4(W2 + ec4);
-  floatx16 tn0, tn1;   // gW1e blocks: rows (ghid columns) 0-31 / 32-63 x e columns wave*32 .. +31
+  floatx16 tn[NB][2];      // gW1e blocks: rows (ghid columns) 0-31 / 32-63 x this wave's e columns
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { tn0[k] = 0.f; tn1[k] = 0.f; }
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { tn[b][0][k] = 0.f; tn[b][1][k] = 0.f; }
   Stat4 st;            // a: sum gs*relu(hid), b: sum ghid  (this thread's 4 columns)
   st.zero();
   double sgs = 0.0;    // sum of gscore over this lane's rows (every wave holds a copy; wave 0's is used)
 
-  float4 pe_[8], ph[PT / 16];
+  float4 pe_[NP], ph[PT / 16];
   int pidx = 0;        // perm of the tile AFTER the prefetched one (row = lane; all four waves alike)
   float pgs = 0.f;     // gscore of the prefetched tile's row
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = tile * PT;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) pe_[it] = ld4(e + clampr(r0 + lrow + 8 * it, Elast) * PH + lc4);
+    for (int it = 0; it < NP; ++it) pe_[it] = ld4(e + clampr(r0 + lrow + RPP * it, Elast) * PHT + lc4);
 #pragma unroll
     for (int p = 0; p < PT / 16; ++p) ph[p] = ld4(hid + clampr(r0 + p * 16 + er, Elast) * PS + ec4);
     pgs = gscore[pidx];                               // pidx was loaded one prefetch earlier
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(kBlock, 2) void pred_bwd_k(
       sgs += (double)g_;
     }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) st4(es + (lrow + 8 * it) * PEP + lc4, pe_[it]);
+    for (int it = 0; it < NP; ++it) st4(es + (lrow + RPP * it) * PEP + lc4, pe_[it]);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < PT / 16; ++p) {
@@ -217,45 +239,56 @@ __global__ __launch_bounds__(kBlock, 2) void pred_bwd_k(
     __syncthreads();
     prefetch(tile + 1 < tb1 ? tile + 1 : tile);
     // ---- ge tile = ghid W1e  (K = 64) ----
-    floatx16 acc0, acc1;
+    floatx16 acc[NB][2];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { acc[b][0][k] = 0.f; acc[b][1][k] = 0.f; }
     {
       const float* p0 = gsm + li * PGP + 4 * lg;
       const float* p1 = gsm + (32 + li) * PGP + 4 * lg;
 #pragma unroll
       for (int q = 0; q < PS / 8; ++q) {
-        mf4(acc0, ld4(p0 + 8 * q), wf[q]);
-        mf4(acc1, ld4(p1 + 8 * q), wf[q]);
+        const float4 a0 = ld4(p0 + 8 * q), a1 = ld4(p1 + 8 * q);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          mf4(acc[b][0], a0, wf[b][q]);
+          mf4(acc[b][1], a1, wf[b][q]);
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep hipcc from hoisting every fragment read (spills)
       }
     }
     // ---- gW1e[n][c] += sum_rows ghid[row][n] e[row][c] ----
     const float* ga = gsm + 4 * lg * PGP + li;               // row 8q + 4lg + r: one lane-dependent base,
-    const float* eb = es + 4 * lg * PEP + wave * 32 + li;    // compile-time offsets (ds_read immediates)
+    const float* eb = es + 4 * lg * PEP + cb0 * 32 + li;     // compile-time offsets (ds_read immediates)
 #pragma unroll
     for (int q = 0; q < PT / 8; ++q) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a0 = ga[(8 * q + r) * PGP], a1 = ga[(8 * q + r) * PGP + 32];
-        const float b = eb[(8 * q + r) * PEP];
-        tn0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, tn0, 0, 0, 0);
-        tn1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, tn1, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float bv = eb[(8 * q + r) * PEP + 32 * b];
+          tn[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, tn[b][0], 0, 0, 0);
+          tn[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, tn[b][1], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();   // e tile is dead: reuse it as the ge output image
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int row = (k & 3) + 8 * (k >> 2) + 4 * lg;
-      es[row * PEP + wave * 32 + li] = acc0[k];
-      es[(32 + row) * PEP + wave * 32 + li] = acc1[k];
-    }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int row = (k & 3) + 8 * (k >> 2) + 4 * lg;
+        es[row * PEP + (cb0 + b) * 32 + li] = acc[b][0][k];
+        es[(32 + row) * PEP + (cb0 + b) * 32 + li] = acc[b][1][k];
+      }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = lrow + 8 * it;
-      if (FULL || r0 + row < E) st4(ge + (r0 + row) * PH + lc4, ld4(es + row * PEP + lc4));
+    for (int it = 0; it < NP; ++it) {
+      const int row = lrow + RPP * it;
+      if (FULL || r0 + row < E) st4(ge + (r0 + row) * PHT + lc4, ld4(es + row * PEP + lc4));
     }
   };
   if (tb0 < tb1) {
@@ -265,13 +298,15 @@ __global__ __launch_bounds__(kBlock, 2) void pred_bwd_k(
   for (int64_t tile = tb0; tile < nfull; ++tile) body(std::true_type{}, tile);
   if (nfull < tb1 && nfull >= tb0) body(std::false_type{}, nfull);
   // ---- partial gW1e slab, column sums ----
-  float* sl = slab + (size_t)chunk * PS * PH;
+  float* sl = slab + (size_t)chunk * PS * PHT;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int n = (k & 3) + 8 * (k >> 2) + 4 * lg;
-    sl[n * PH + wave * 32 + li] = tn0[k];
-    sl[(32 + n) * PH + wave * 32 + li] = tn1[k];
-  }
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int n = (k & 3) + 8 * (k >> 2) + 4 * lg;
+      sl[n * PHT + (cb0 + b) * 32 + li] = tn[b][0][k];
+      sl[(32 + n) * PHT + (cb0 + b) * 32 + li] = tn[b][1][k];
+    }
   __syncthreads();
   double* red = reinterpret_cast<double*>(es);     // [16 row-slots][2][64] doubles = 16 KB
 #pragma unroll
@@ -319,56 +354,73 @@ __global__ void pred_slab_reduce_k(const float* __restrict__ slab, int nslab, in
 using namespace gnm;
 
 static inline int64_t cdivp(int64_t a, int64_t b) { return (a + b - 1) / b; }
-static constexpr size_t kPackF = (size_t)2 * (PH / 8) * 64 * 16;   // W1e NT pack: 2 column blocks x 16 k-quads
-static constexpr size_t kPackB = (size_t)4 * (PS / 8) * 64 * 16;   // W1e NN pack: 4 column blocks x 8 k-quads
+static size_t pack_f_bytes(int H) { return (size_t)2 * (H / 8) * 64 * 16; }     // W1e NT pack: 2 column blocks x H / 8 k-quads
+static size_t pack_b_bytes(int H) { return (size_t)(H / 32) * (PS / 8) * 64 * 16; }   // W1e NN pack: H / 32 column blocks x 8 k-quads
 
+// sized for H = 256 (the larger of the two widths that are built)
 extern "C" size_t gnm_predictor_fused_workspace_bytes(void) {
-  return kPackF + kPackB + (size_t)kMaxPartialBlocks * PS * PH * sizeof(float);
+  return pack_f_bytes(2 * PH) + pack_b_bytes(2 * PH) + (size_t)kMaxPartialBlocks * PS * 2 * PH * sizeof(float);
+}
+
+template <int PHT>
+static int predictor_fused_fwd_impl(int64_t E, const float* e, const float* W1e, int64_t ldw, const float* b1, const float* Pn,
+                                    const int32_t* isrc, const int32_t* idst, const int32_t* perm, const float* W2,
+                                    const float* b2, float* hid, float* scores, void* ws, hipStream_t st) {
+  hipLaunchKernelGGL(pack_wk_k, dim3(8), dim3(256), 0, st, W1e, ldw, 2, PHT / 8, 0, (float*)ws);
+  GNM_LAUNCH_CHECK("predictor pack (NT)");
+  const int64_t ntiles = cdivp(E, PT);
+  const int grid = persistent_grid(ntiles, 4, occ_blocks<pred_fwd_k<true, PHT>>());
+  if (hid)
+    hipLaunchKernelGGL((pred_fwd_k<true, PHT>), dim3(grid), dim3(kBlock), 0, st, E, e, (const float*)ws, b1, Pn, isrc, idst,
+                       perm, W2, b2, hid, scores, cdivp(ntiles, grid));
+  else
+    hipLaunchKernelGGL((pred_fwd_k<false, PHT>), dim3(grid), dim3(kBlock), 0, st, E, e, (const float*)ws, b1, Pn, isrc, idst,
+                       perm, W2, b2, hid, scores, cdivp(ntiles, grid));
+  GNM_LAUNCH_CHECK("predictor_fused_fwd");
+  return 0;
 }
 
 extern "C" int gnm_predictor_fused_fwd(int64_t E, int H, int HS, const float* e, const float* W1e, int64_t ldw,
                                        const float* b1, const float* Pn, const int32_t* isrc, const int32_t* idst,
                                        const int32_t* perm, const float* W2, const float* b2, float* hid,
                                        float* scores, void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(H == PH && HS == PS, "predictor_fused_fwd: H=%d HS=%d (only 128/64 is built)", H, HS);
+  GNM_CHECK_ARG((H == PH || H == 2 * PH) && HS == PS, "predictor_fused_fwd: H=%d HS=%d (128 or 256 / 64 are built)", H, HS);
   GNM_CHECK_ARG(E > 0 && e && W1e && ldw >= H && b1 && Pn && isrc && idst && perm && W2 && b2 && scores,
                 "predictor_fused_fwd: null/neg argument");
-  GNM_CHECK_ARG(ws && ws_bytes >= kPackF, "predictor_fused_fwd: workspace too small");
+  GNM_CHECK_ARG(ws && ws_bytes >= pack_f_bytes(H), "predictor_fused_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pack_wk_k, dim3(8), dim3(256), 0, st, W1e, ldw, 2, PH / 8, 0, (float*)ws);
-  GNM_LAUNCH_CHECK("predictor pack (NT)");
+  return H == PH ? predictor_fused_fwd_impl<PH>(E, e, W1e, ldw, b1, Pn, isrc, idst, perm, W2, b2, hid, scores, ws, st)
+                 : predictor_fused_fwd_impl<2 * PH>(E, e, W1e, ldw, b1, Pn, isrc, idst, perm, W2, b2, hid, scores, ws, st);
+}
+
+template <int PHT>
+static int predictor_fused_bwd_impl(int64_t E, float* hid, const float* gscore, const int32_t* perm, const float* W2,
+                                    const float* e, const float* W1e, int64_t ldw, float* ge, float* gW1e, float* gsums,
+                                    double* partials, void* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float* wp = (float*)((char*)ws + pack_f_bytes(PHT));
+  float* slab = (float*)((char*)ws + pack_f_bytes(PHT) + pack_b_bytes(PHT));
+  hipLaunchKernelGGL(pack_wk_k, dim3(8), dim3(256), 0, st, W1e, ldw, PHT / 32, PS / 8, 1, wp);
+  GNM_LAUNCH_CHECK("predictor pack (NN)");
   const int64_t ntiles = cdivp(E, PT);
-  const int grid = persistent_grid(ntiles, 4, occ_blocks<pred_fwd_k<true>>());
-  if (hid)
-    hipLaunchKernelGGL(pred_fwd_k<true>, dim3(grid), dim3(kBlock), 0, st, E, e, (const float*)ws, b1, Pn, isrc, idst,
-                       perm, W2, b2, hid, scores, cdivp(ntiles, grid));
-  else
-    hipLaunchKernelGGL(pred_fwd_k<false>, dim3(grid), dim3(kBlock), 0, st, E, e, (const float*)ws, b1, Pn, isrc, idst,
-                       perm, W2, b2, hid, scores, cdivp(ntiles, grid));
-  GNM_LAUNCH_CHECK("predictor_fused_fwd");
-  return 0;
+  const int grid = persistent_grid(ntiles, 4, occ_blocks<pred_bwd_k<PHT>>());
+  hipLaunchKernelGGL(pred_bwd_k<PHT>, dim3(grid), dim3(kBlock), 0, st, E, hid, gscore, perm, W2, e, (const float*)wp, ge,
+                     slab, partials, cdivp(ntiles, grid));
+  GNM_LAUNCH_CHECK("predictor_fused_bwd");
+  hipLaunchKernelGGL(pred_slab_reduce_k, dim3(32), dim3(256), 0, st, (const float*)slab, grid, PS * PHT, gW1e);
+  GNM_LAUNCH_CHECK("predictor_fused_bwd slab reduce");
+  // gsums[0:64] = gW2, [64:128] = gb1, [128] = gb2 (129..191: zeros)
+  return gnm_reduce_partials(partials, grid, 3, PS, gsums, stream) ? -3 : 0;
 }
 
 extern "C" int gnm_predictor_fused_bwd(int64_t E, int H, int HS, float* hid, const float* gscore,
                                        const int32_t* perm, const float* W2, const float* e, const float* W1e,
                                        int64_t ldw, float* ge, float* gW1e, float* gsums, double* partials,
                                        void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(H == PH && HS == PS, "predictor_fused_bwd: H=%d HS=%d (only 128/64 is built)", H, HS);
+  GNM_CHECK_ARG((H == PH || H == 2 * PH) && HS == PS, "predictor_fused_bwd: H=%d HS=%d (128 or 256 / 64 are built)", H, HS);
   GNM_CHECK_ARG(E > 0 && hid && gscore && perm && W2 && e && W1e && ldw >= H && ge && gW1e && gsums && partials,
                 "predictor_fused_bwd: null/neg argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_predictor_fused_workspace_bytes(), "predictor_fused_bwd: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  float* wp = (float*)((char*)ws + kPackF);
-  float* slab = (float*)((char*)ws + kPackF + kPackB);
-  hipLaunchKernelGGL(pack_wk_k, dim3(8), dim3(256), 0, st, W1e, ldw, 4, PS / 8, 1, wp);
-  GNM_LAUNCH_CHECK("predictor pack (NN)");
-  const int64_t ntiles = cdivp(E, PT);
-  const int grid = persistent_grid(ntiles, 4, occ_blocks<pred_bwd_k>());
-  hipLaunchKernelGGL(pred_bwd_k, dim3(grid), dim3(kBlock), 0, st, E, hid, gscore, perm, W2, e, (const float*)wp, ge,
-                     slab, partials, cdivp(ntiles, grid));
-  GNM_LAUNCH_CHECK("predictor_fused_bwd");
-  hipLaunchKernelGGL(pred_slab_reduce_k, dim3(32), dim3(256), 0, st, (const float*)slab, grid, PS * PH, gW1e);
-  GNM_LAUNCH_CHECK("predictor_fused_bwd slab reduce");
-  // gsums[0:64] = gW2, [64:128] = gb1, [128] = gb2 (129..191: zeros)
-  return gnm_reduce_partials(partials, grid, 3, PS, gsums, stream) ? -3 : 0;
+  return H == PH ? predictor_fused_bwd_impl<PH>(E, hid, gscore, perm, W2, e, W1e, ldw, ge, gW1e, gsums, partials, ws, stream)
+                 : predictor_fused_bwd_impl<2 * PH>(E, hid, gscore, perm, W2, e, W1e, ldw, ge, gW1e, gsums, partials, ws, stream);
 }

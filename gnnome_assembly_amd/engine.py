@@ -796,7 +796,7 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     Pn = torch.empty(N, 2 * HS, **f32)
     gemm(NT, x, W1sd, Pn)
     scores = torch.empty(E, 1, **f32)
-    if H == 128 and HS == 64 and FUSED:
+    if (H == 128 or (H == 256 and WIDE_FUSED)) and HS == 64 and FUSED:
         # one pass over e: hid GEMM + gathers + relu + W2 dot; hid is only written when backward needs it
         hid = torch.empty(E, HS, **f32) if save else None
         need = lib.gnm_predictor_fused_workspace_bytes()
@@ -828,7 +828,7 @@ def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores, out: Optiona
     g = {}
     gscores = _f32c(gscores.reshape(-1))
     ghid = s.hid   # in place
-    fused = H == 128 and HS == 64 and FUSED
+    fused = (H == 128 or (H == 256 and WIDE_FUSED)) and HS == 64 and FUSED
     gW1 = out["W1"] if "W1" in out else torch.empty(HS, 3 * H, **f32)
     if fused:
         # one pass: ghid (in place), ge = ghid W1e, gW1e, and the gW2 / gb1 / gb2 column sums
@@ -862,12 +862,12 @@ def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores, out: Optiona
     _call("gnm_seg_sum_rows", N, HS, _ptr(ghid), _ptr(idx["in_ptr"]), C.c_void_p(0),
                                     _ptr(gPn[:, HS:]), 2 * HS, st)
     if fused:
-        # [x^T gPs | x^T gPd] in one W-free TN pass (x is the 128-wide operand), then transpose the 128 x 128 result
+        # [x^T gPs | x^T gPd] in one W-free TN pass (x's 128-column groups against the 128-wide gPn), then transpose the H x 128 result
         xt = torch.empty(H, 2 * HS, **f32)
         junk = torch.empty(H, **f32)
         need = lib.gnm_tn128_workspace_bytes()
         ws = sc.ws(need)
-        _call("gnm_tn128", N, _ptr(s.x), H, 1, _ptr(gPn), _ptr(xt), _ptr(junk), _ptr(sc.partials), _ptr(ws), need, st)
+        _call("gnm_tn128", N, _ptr(s.x), H, H // 128, _ptr(gPn), _ptr(xt), _ptr(junk), _ptr(sc.partials), _ptr(ws), need, st)
         gW1[:, :H] = xt[:, :HS].t()
         gW1[:, H:2 * H] = xt[:, HS:].t()
     else:

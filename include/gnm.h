@@ -381,7 +381,7 @@ int gnm_predictor_score_bwd(int64_t E, int HS, float* hid, const float* gscore, 
  * bwd: ghid = gscore[perm j] W2 [hid>0] (in place over hid), ge = ghid W1e, gW1e[HS,H] = ghid^T e,
  *      gsums[0:HS] = gW2, gsums[HS:2HS] = gb1, gsums[2HS] = gb2 (gsums holds 3*HS floats).
  *      partials: the BatchNorm partials buffer.  ws: gnm_predictor_fused_workspace_bytes().          */
-size_t gnm_predictor_fused_workspace_bytes(void);
+size_t gnm_predictor_fused_workspace_bytes(void);   /* sized for H = 256; the two kernels are built for H = 128 and 256, HS = 64 */
 int gnm_predictor_fused_fwd(int64_t E, int H, int HS, const float* e, const float* W1e, int64_t ldw,
                             const float* b1, const float* Pn, const int32_t* isrc, const int32_t* idst,
                             const int32_t* perm, const float* W2, const float* b2, float* hid,
