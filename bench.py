@@ -127,7 +127,7 @@ OP_KERNELS = {
     "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true, true, 128>"], "gnm_node_bgrad": ["node_bgrad_k<128>"], "gnm_edge_bwd_top": ["edge_bwd_chain_k"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
     "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128, true>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
-    "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3_k"]},
+    "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3p_k", "edge_t32_b3_k"]},
     "gnm_node_proj_fwd": {"f32": ["rowtile_nt_k<MmF32, false, 5>"], "bf16x3": ["rowtile_nt_k<MmB3, false, 1>"]},
     "gnm_node_proj_bwd_nn": {"f32": ["rowtile_nn_acc_k<MmF32>"], "bf16x3": ["rowtile_nn_group32_b3_k<4>"]},
     "gnm_node_proj_bwd_tn": {"f32": ["tn_colgroup_k<MmF32>"], "bf16x3": ["tn_colgroup32_b3_k", "tn_tr_k"]},

@@ -626,6 +626,111 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3_k(
   block_stat_store<FH>(st, reinterpret_cast<double*>(xraw), partials, chunk);
 }
 
+// edge_t32_b3_k with the split / staging of tile k+1 issued inside the matrix phase of tile k (see edge_t32_h256p_k): same
+// arithmetic and summation order, bit-identical results.
+__global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
+    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
+    const int32_t* __restrict__ idst, double* __restrict__ partials, int64_t tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ float os[ER3 * FP];
+  __shared__ int sd[2][2 * ER3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t ntiles = (M + ER3 - 1) / ER3;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, M / ER3);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  const int32_t* const ibase = (lane & 32) ? idst : isrc;
+
+  MmB3::Frag wf;
+  MmB3::load_w(wf, Wp, wave, lane);
+  const float4 b4 = ld4(bias + lc4);
+  float4 pre[2][4];
+  int pidx[2] = {0, 0};
+  auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+    idx = ibase[clampi(r0 + (lane & 31), Mlast)];
+  };
+  Stat4 st;
+  st.zero();
+  auto body = [&](auto tag, float4 (&nbuf)[4], int& nidx, int64_t tile, int hb) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    const int64_t r0 = tile * ER3;
+    float4 g1[4], g2[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t s_ = sd[hb][row], d_ = sd[hb][ER3 + row];
+      g1[it] = ld4(P + s_ * (5 * FH) + 3 * FH + lc4);
+      g2[it] = ld4(P + d_ * (5 * FH) + 4 * FH + lc4);
+    }
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    {
+      const __bf16* p0 = reinterpret_cast<const __bf16*>(xraw) + (32 * hb + li) * BP + 8 * lg;
+#pragma unroll
+      for (int c = 0; c < BKC; ++c) {
+        bf16x8 a0[3];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) a0[s_] = *reinterpret_cast<const bf16x8*>(p0 + s_ * BIMG + 16 * c);
+        mfb(acc, a0[2], wf.w[c][0]);
+        mfb(acc, a0[0], wf.w[c][2]);
+        mfb(acc, a0[1], wf.w[c][1]);
+        if (c < 4) MmB3::stage(xraw, 32 * (hb ^ 1) + lrow + 8 * c, lc4, nbuf[c]);
+        mfb(acc, a0[1], wf.w[c][0]);
+        mfb(acc, a0[0], wf.w[c][1]);
+        mfb(acc, a0[0], wf.w[c][0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    sd[hb ^ 1][lane] = nidx;
+    prefetch(nbuf, nidx, tile + 3);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) os[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t grow = r0 + row;
+      const float4 v = ld4(os + row * FP + lc4) + b4 + g1[it] + g2[it];
+      if (FULL || grow < M) {
+        st4_nt(Y + grow * FH + lc4, v);
+        st.add_prod(v, v);
+      }
+    }
+  };
+  if (tb0 < tb1) {
+    prefetch(pre[0], pidx[0], tb0);
+    prefetch(pre[1], pidx[1], tb0 + 1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) MmB3::stage(xraw, lrow + 8 * it, lc4, pre[0][it]);
+    sd[0][lane] = pidx[0];
+    prefetch(pre[0], pidx[0], tb0 + 2);
+    __syncthreads();
+  }
+  int64_t tile = tb0;
+  for (; tile + 2 <= nfull; tile += 2) {
+    body(full_t{}, pre[1], pidx[1], tile, 0);
+    body(full_t{}, pre[0], pidx[0], tile + 1, 1);
+  }
+  int hb = 0;
+  for (; tile < tb1; ++tile, hb ^= 1) {
+    if (hb == 0) body(ragged_t{}, pre[1], pidx[1], tile, 0);
+    else body(ragged_t{}, pre[0], pidx[0], tile, 1);
+  }
+  __syncthreads();
+  block_stat_store<FH>(st, reinterpret_cast<double*>(xraw), partials, chunk);
+}
+
 // ------------------------------------------------------------------------------------------
 // H = 256 (the reference's default dim_latent, hyperparameters.py:8): t = e W3^T + b3 + B1h[src] + B2h[dst] and the
 // BatchNorm sums in ONE pass over e (gated_gcn_full.py:113,120-122), split mode.  The three bf16 images of the
@@ -1872,6 +1977,9 @@ static int g_chain_variant = 0;  // chained edge backward: 0 = edge_bwd_chain_k 
 int chain_variant() { return g_chain_variant; }
 static int g_enc_bwd = 1;        // edge encoder backward: 1 = fp32-MFMA kernel, 0 = VALU kernel (round 1)
 int enc_bwd_variant() { return g_enc_bwd; }
+static int g_t_pipe = 1;         // H = 128 forward t kernel: 1 = edge_t32_b3p_k (next tile staged inside the matrix phase: 14.9 -> 14.3 ms per step; the same recipe
+                                 // bought nothing in the node projections: 11.6 ms either way), 0 = edge_t32_b3_k
+int t_pipe_variant() { return g_t_pipe; }
 static int g_wide_pipe = 1;      // H = 256 forward t kernel: 1 = next tile staged inside the matrix phase, 0 = phases one after the other
 static int g_enc_fwd = 1;        // edge encoder forward: 1 = fp32-MFMA kernel, 0 = VALU kernel
 int enc_fwd_variant() { return g_enc_fwd; }
@@ -1883,6 +1991,7 @@ extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "enc_bwd")) { g_enc_bwd = v; return 0; }
   if (what && !strcmp(what, "enc_fwd")) { g_enc_fwd = v; return 0; }
   if (what && !strcmp(what, "wide_pipe")) { g_wide_pipe = v; return 0; }
+  if (what && !strcmp(what, "t_pipe")) { g_t_pipe = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }
@@ -1908,7 +2017,11 @@ static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, cons
   if constexpr (MM::kSplit) {
     const int64_t ntiles = cdiv_(E, ER3);
     const int grid = persistent_grid(ntiles, 8, occ_blocks<edge_t32_b3_k>());
-    hipLaunchKernelGGL(edge_t32_b3_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+    if (t_pipe_variant())
+      hipLaunchKernelGGL(edge_t32_b3p_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                         partials, cdiv_(ntiles, grid));
+    else
+      hipLaunchKernelGGL(edge_t32_b3_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
                        partials, cdiv_(ntiles, grid));
     GNM_LAUNCH_CHECK("edge_t_fused_fwd");
     *nblk_out = grid;
