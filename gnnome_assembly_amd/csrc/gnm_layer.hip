@@ -362,6 +362,7 @@ __global__ __launch_bounds__(kBlock, 7) void edge_bwd_src_fix_k(
   const float4 sc = ld4(stat + 2 * H + c4), sh = ld4(stat + 3 * H + c4);
   for (int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave; i < nfix; i += (int64_t)gridDim.x * kWavesPerBlock) {
     const int64_t v = fix_nodes[i];
+    if (v < 0) continue;                      // a list compacted on the device carries -1 behind its last entry
     const int a = out_ptr[v], b = out_ptr[v + 1];
     float4 a2acc = f4(0.f), us = f4(0.f), ts = f4(0.f);
     for (int64_t m = a + sub; m < b; m += RPW) {

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(kBlock, 8) void node_agg_src_fix_k(int64_t nfix, co
   const int sub = lane / G, c4 = (lane % G) * 4;
   for (int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave; i < nfix; i += (int64_t)gridDim.x * kWavesPerBlock) {
     const int64_t v = fix_nodes[i];
+    if (v < 0) continue;                      // a list compacted on the device carries -1 behind its last entry
     const int a = out_ptr[v], b = out_ptr[v + 1];
     float4 num = f4(0.f), den = f4(0.f);
     for (int64_t m = a + sub; m < b; m += RPW) {

@@ -249,8 +249,9 @@ class AssemblyGraph:
     def sweep_plan(self, device=None, wg_per_cu: int = 1):
         """The sweep plan of this graph on `device` (gnm_graph_build_sweep_plan over the partition the sweep kernel with
         `wg_per_cu` workgroups per CU uses there -- 1: the chained backward, 2: the two-sided forward gate): dict(sinfo, dinfo [E] int32 tensors holding the plan words, fix_nodes [nfix] int32, nodes_per_block,
-        nfix, peak_live), or None for a graph that was born on a device (its index never visits the host; the
-        engine then keeps the separate by-source passes)."""
+        nfix, peak_live).  A graph that was born on a device (its index never visits the host: mini-batch sub-graphs, from_tensors)
+        gets the same plan from gnm_graph_build_sweep_plan_device (fix_nodes then is [N] with -1 for the served nodes and nfix = N);
+        None only with GNM_DEVICE_PLANS=0 -- the engine then keeps the separate by-source passes."""
         device = torch.device(device) if device is not None else self.device
         key = (device, wg_per_cu)
         if key in self._plans:
@@ -265,6 +266,8 @@ class AssemblyGraph:
                 _lib.check(lib.gnm_sweep_partition(n, wg_per_cu, C.byref(npb), C.byref(grid)), "gnm_sweep_partition")
             plan = build_sweep_plan(h, n, npb.value)
             plan = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
+        elif self.num_edges() > 0 and device.type == "cuda" and DEVICE_PLANS:
+            plan = build_sweep_plan_device(self.index(device), self._n, device, wg_per_cu)
         self._plans[key] = plan
         return plan
 
@@ -286,6 +289,35 @@ def build_sweep_plan(host_index, n: int, nodes_per_block: int, nslots: int = SWE
                                               ptr(fix), C.byref(nfix), C.byref(peak)), "gnm_graph_build_sweep_plan")
     return {"sinfo": sinfo.view(np.int32), "dinfo": dinfo.view(np.int32), "fix_nodes": fix[:nfix.value].copy(),
             "nodes_per_block": int(nodes_per_block), "nfix": int(nfix.value), "peak_live": int(peak.value)}
+
+
+# graphs born on a device (mini-batch sub-graphs, from_tensors on device tensors): the plan is built there too
+# (gnm_graph_build_sweep_plan_device); GNM_DEVICE_PLANS=0 leaves them on the separate by-source passes
+DEVICE_PLANS = os.environ.get("GNM_DEVICE_PLANS", "1") != "0"
+
+
+def build_sweep_plan_device(idx, n: int, device, wg_per_cu: int, nslots: int = SWEEP_SLOTS, margin: int = SWEEP_MARGIN):
+    """The plan of build_sweep_plan from a DEVICE index, without a host round trip and without a synchronisation: the plan
+    words and the fix list come from gnm_graph_build_sweep_plan_device; the list is [N] with -1 for the served nodes (the fix-up
+    kernels skip negative entries), so `nfix` is N, not the count."""
+    lib = _lib.load()
+    e = int(idx["isrc"].numel())
+    i32 = dict(dtype=torch.int32, device=device)
+    npb, grid = C.c_int64(0), C.c_int(0)
+    with torch.cuda.device(device):
+        _lib.check(lib.gnm_sweep_partition(n, wg_per_cu, C.byref(npb), C.byref(grid)), "gnm_sweep_partition")
+        sinfo, dinfo = torch.empty(e, **i32), torch.empty(e, **i32)
+        served = torch.empty(n, dtype=torch.uint8, device=device)
+        fix = torch.empty(n, **i32)
+        first, last, peak = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(1, **i32)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(lib.gnm_graph_build_sweep_plan_device(p(idx["isrc"]), p(idx["idst"]), p(idx["in_ptr"]), n, e, npb.value,
+                                                         SWEEP_TILE_ROWS, nslots, margin, p(sinfo), p(dinfo), p(served), p(fix),
+                                                         p(first), p(last), p(peak),
+                                                         C.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                   "gnm_graph_build_sweep_plan_device")
+    return {"sinfo": sinfo, "dinfo": dinfo, "fix_nodes": fix, "nodes_per_block": int(npb.value), "nfix": int(n),
+            "peak_live": None, "served": served, "peak_dev": peak}
 
 
 def _to_numpy(a):

@@ -91,6 +91,15 @@ int gnm_graph_locality_order(const int32_t* src, const int32_t* dst, int64_t N, 
 int gnm_graph_build_sweep_plan(const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, int64_t N, int64_t E,
                                int64_t nodes_per_block, int tile_rows, int nslots, int64_t margin, uint32_t* sinfo,
                                uint32_t* dinfo, int32_t* fix_nodes, int64_t* nfix_out, int32_t* peak_live_out);
+/* The same plan built ON THE DEVICE (device pointers, kernels queued on `stream`, no host synchronisation), bit for bit the
+ * words of gnm_graph_build_sweep_plan: for graphs whose index never visits the host (the induced sub-graphs of the mini-batch
+ * mode, train.py:288-343).  served[N] (bytes): 1 for the sources the sweep serves; fix_nodes[N] (optional): v for the nodes it does
+ * not serve, -1 for the others -- the *_fix kernels skip negative entries, so the list is used as it is with nfix = N.
+ * first / last [N] int32: scratch; peak [1] int32 (optional): most slots in use.  tile_rows = 16, nslots <= 64.          */
+int gnm_graph_build_sweep_plan_device(const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, int64_t N, int64_t E,
+                                      int64_t nodes_per_block, int tile_rows, int nslots, int64_t margin, uint32_t* sinfo,
+                                      uint32_t* dinfo, uint8_t* served, int32_t* fix_nodes, int32_t* first, int32_t* last,
+                                      int32_t* peak, void* stream);
 /* the partition of a sweep kernel on the current device: workgroup w owns the destination nodes
  * [w * nodes_per_block, (w+1) * nodes_per_block); *grid_out (optional) = workgroups launched.
  * wg_per_cu: 1 for gnm_edge_bwd_chain_src, 2 for gnm_edge_gate2_fwd (a plan serves ONE partition)            */

@@ -1240,6 +1240,74 @@ def test_wide_layers_fused_kernels_and_sweeps_match_the_generic_route():
             assert not bad, (ids, name, bad)
 
 
+@pytest.mark.mode_independent
+def test_device_built_sweep_plan_equals_the_host_built_one():
+    """gnm_graph_build_sweep_plan_device (one wave per sweep workgroup, the slot allocator on a stack in LDS) against the host
+    builder on the same index: plan words bit for bit, the same unserved nodes, the same peak slot count -- for the synthetic
+    assembly graph with generator and shuffled (renumbered) node ids, both partitions, and the graphs without a band."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import graph as gmod, synth
+    dev = _dev()
+    cases = {}
+    src, dst, n = synth.make_graph(60000, 5)
+    cases["assembly graph"] = (src, dst, n)
+    p = np.random.default_rng(9).permutation(n).astype(np.int32)
+    cases["assembly graph, shuffled ids"] = (p[src], p[dst], n)
+    cases.update(_adversarial_graphs())
+    for name, (src, dst, n) in cases.items():
+        g = G.AssemblyGraph(src, dst, n).to(dev)
+        idx = g.index(dev)
+        for wg in (1, 2):
+            host = g.sweep_plan(dev, wg)
+            devp = gmod.build_sweep_plan_device(idx, n, dev, wg)
+            torch.cuda.synchronize()
+            assert devp["nodes_per_block"] == host["nodes_per_block"]
+            assert torch.equal(devp["sinfo"], host["sinfo"]), (name, wg, "sinfo")
+            assert torch.equal(devp["dinfo"], host["dinfo"]), (name, wg, "dinfo")
+            fix = devp["fix_nodes"]
+            assert torch.equal(fix[fix >= 0], host["fix_nodes"]) and bool((fix[fix >= 0] == torch.nonzero(fix >= 0).squeeze(1)).all()), (name, wg, "fix list")
+            assert int(devp["peak_dev"].item()) == host["peak_live"], (name, wg, "peak")
+
+
+@pytest.mark.default_mode_only
+def test_device_born_graph_runs_the_two_sided_sweeps():
+    """A graph built from DEVICE tensors (what cluster.induced_subgraph returns for a mini-batch) gets its plan on the device and runs
+    the two-sided sweeps: logits and gradients equal those of the same graph built on the host (same plan -> same arithmetic,
+    bit for bit), and GNM_DEVICE_PLANS=0 / graph.DEVICE_PLANS = False (the separate passes) agrees to the usual bars."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import graph as gmod
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(30000, 128, 3, 4, dev)
+    e, pe, y = (torch.from_numpy(inp[k]).to(dev) for k in ("e", "pe", "y"))
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+
+    def run(g):
+        model.zero_grad(set_to_none=True)
+        s = model(g, None, e, pe)
+        crit(s.squeeze(-1), y).backward()
+        torch.cuda.synchronize()
+        return s.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters()}
+    g_host = G.AssemblyGraph(src, dst, n, node_order="keep").to(dev)
+    g_dev = G.AssemblyGraph.from_tensors(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+    assert g_dev.sweep_plan(dev, 1) is not None and g_dev.sweep_plan(dev, 2) is not None
+    s0, g0 = run(g_host)
+    s1, g1 = run(g_dev)
+    assert torch.equal(s0, s1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+    old = gmod.DEVICE_PLANS
+    try:
+        gmod.DEVICE_PLANS = False
+        g_sep = G.AssemblyGraph.from_tensors(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+        assert g_sep.sweep_plan(dev, 1) is None
+        s2, g2 = run(g_sep)
+    finally:
+        gmod.DEVICE_PLANS = old
+    assert rel_l2(s2.cpu().numpy(), s0.cpu().numpy()) <= 2e-6
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    bad = [(k, float((g2[k].double() - g0[k].double()).norm() / g0[k].double().norm().clamp_min(1e-30))) for k in g0
+           if float((g2[k] - g0[k]).abs().max()) > 1e-6 * gmax]
+    assert all(r <= GRAD_L2 for _, r in bad), bad
+
+
 def _adversarial_graphs():
     """Graphs the sweep plan has to get right without the band it was designed for."""
     rng = np.random.default_rng(12)
