@@ -24,14 +24,6 @@ print("rc", lib.gnm_debug_chain_timing(buf))
 a = np.frombuffer(buf, dtype=np.int64).reshape(256, NW, 12).astype(np.float64)
 nt = a[:, :, 10]
 per = a[:, :, :10] / np.maximum(nt[:, :, None], 1)
-if os.environ.get("CHAIN2"):
-    names2 = ["seg A: phase 0 | walk", "wait barrier 1", "seg B: MFMAs | prefetch issue", "wait barrier 2",
-              "  gather: wait loads + ring", "  gather: arithmetic 2 rows", "  gather: bn flush"]
-    print("chain2: ticks per tile, mean over WGs; waves 0-3 matrix role, waves 4-7 gather role")
-    for q in range(7):
-        print(f"{names2[q]:32s}", " ".join(f"{per[:, w, q].mean():8.1f}" for w in range(8)))
-    print("sum", " ".join(f"{per[:, w, :7].sum(-1).mean():8.1f}" for w in range(8)))
-    sys.exit(0)
 names = ["loop-top(gather issue->)", "phase0 after the rows arrived", "barrier1", "prefetch+MFMA TN+NN", "barrier2", "dst arithmetic", "barrier3", "walk / bn sums (waves 0-2 / 4-7)", "by-source run sums + gather issue", "phase0: wait for the rows"]
 print("tiles per WG:", nt[:4, 0])
 print("ticks per tile (s_memtime ticks = 100 MHz? reported raw), mean over WGs, per wave:")
