@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNM_LIBRARY") or os.path.join(_HERE, "libgnm.so")   # GNM_LIBRARY: A/B against another build (tools)
 
 _lib = None
-ABI_VERSION = 4     # GNM_ABI_VERSION of include/gnm.h
+ABI_VERSION = 5     # GNM_ABI_VERSION of include/gnm.h
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -46,10 +46,10 @@ SIGNATURES = {
     "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "gnm_edge_bwd_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
-    "gnm_ln_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "gnm_ln_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
-    "gnm_ln_node_bwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
-    "gnm_ln_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
+    "gnm_ln_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "gnm_ln_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _i32, _p]),
+    "gnm_ln_node_bwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _i32, _p]),
+    "gnm_ln_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _i32, _p]),
     "gnm_ln_edge_bwd_src": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_rowtile_workspace_bytes": (_sz, [_i32]),
     "gnm_set_occupancy_cap": (_i32, [_i32]),
@@ -67,7 +67,7 @@ SIGNATURES = {
     "gnm_edge_bwd_chain_src": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_p, _i64, _p] + [_pi, _p, _sz, _p]),
     "gnm_edge_bwd_top": (_i32, [_i64, _i64, _i32] + [_p] * 15 + [_p, _i64, _p, _pi, _p, _sz, _p]),
     "gnm_edge_bwd_src_fix": (_i32, [_i64, _p, _i64, _i64, _i32] + [_p] * 10 + [_p]),
-    "gnm_node_bgrad": (_i32, [_i64, _i32] + [_p] * 9 + [_p]),
+    "gnm_node_bgrad": (_i32, [_i64, _i32] + [_p] * 8 + [_i64, _p, _p]),
     "gnm_graph_build_sweep_plan": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p, _p, C.POINTER(C.c_int64), _pi]),
     "gnm_graph_build_sweep_plan_device": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_sweep_partition": (_i32, [_i64, _i32, C.POINTER(C.c_int64), _pi]),

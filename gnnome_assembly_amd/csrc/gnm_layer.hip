@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void node_bgrad_k(int64_t N, const float* _
                                                        const float* __restrict__ bstat, const float* __restrict__ gamma,
                                                        const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ out_ptr,
                                                        const float* __restrict__ UT, const float* __restrict__ Ud,
-                                                       const float* __restrict__ Td, int ud_pitch, float* __restrict__ gP) {
+                                                       const float* __restrict__ Td, int64_t ud_pitch, float* __restrict__ gP) {
   constexpr int G = H / 4;
   const int64_t total = N * G;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -665,10 +665,10 @@ extern "C" int gnm_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int6
 
 extern "C" int gnm_node_bgrad(int64_t N, int H, const float* stat_e, const float* bstat_e, const float* gamma_e,
                               const int32_t* in_ptr, const int32_t* out_ptr, const float* UT, const float* Ud,
-                              const float* Td, float* gP, void* stream) {
+                              const float* Td, int64_t ud_pitch, float* gP, void* stream) {
   GNM_CHECK_ARG(N >= 0 && stat_e && bstat_e && gamma_e && in_ptr && out_ptr && UT && Ud && Td && gP,
                 "node_bgrad: null/neg argument");
-  const int ud_pitch = Td == Ud + H ? 2 * H : H;      // [Ud | Td] as one [N,2H] array, or two [N,H] arrays
+  GNM_CHECK_ARG(ud_pitch == H || ud_pitch == 2 * H, "node_bgrad: ud_pitch must be H (two [N,H] arrays) or 2H (one [N,2H] array)");
   GNM_DISPATCH_H(H, hipLaunchKernelGGL(node_bgrad_k<HH>, dim3(ew_grid(N * (HH / 4))), dim3(kBlock), 0,
                                        (hipStream_t)stream, N, stat_e, bstat_e, gamma_e, in_ptr, out_ptr, UT, Ud, Td, ud_pitch, gP));
   GNM_LAUNCH_CHECK("node_bgrad");

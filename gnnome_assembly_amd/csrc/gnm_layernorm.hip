@@ -20,13 +20,20 @@ __device__ __forceinline__ float row_sum(float v) {
 }
 __device__ __forceinline__ float hsum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-// xhat = (x - mean_row) * rstd_row over the H channels of the row held by G lanes
+// live[j] = 1 for the channels c4 + j < width, 0 for the dead (zero-padded) channels of a layer that runs on the next
+// kernel width up (layers.padded_width): nn.LayerNorm(out_channels) normalises over the layer's REAL width
+__device__ __forceinline__ float4 live_mask(int c4, int width) {
+  return make_float4(c4 < width ? 1.f : 0.f, c4 + 1 < width ? 1.f : 0.f, c4 + 2 < width ? 1.f : 0.f, c4 + 3 < width ? 1.f : 0.f);
+}
+
+// xhat = (x - mean_row) * rstd_row over the `width` live channels of the row held by G lanes (dead channels hold 0 on
+// entry and get xhat = 0); inv_w = 1 / width
 template <int H>
-__device__ __forceinline__ float4 row_normalize(float4 x, float& rstd) {
+__device__ __forceinline__ float4 row_normalize(float4 x, const float4& live, float inv_w, float& rstd) {
   constexpr int G = H / 4;
-  const float mu = row_sum<G>(hsum4(x)) * (1.0f / H);
-  const float4 d = x - f4(mu);
-  const float var = row_sum<G>(hsum4(d * d)) * (1.0f / H);
+  const float mu = row_sum<G>(hsum4(x)) * inv_w;
+  const float4 d = (x - f4(mu)) * live;
+  const float var = row_sum<G>(hsum4(d * d)) * inv_w;
   rstd = 1.0f / sqrtf(var + kEpsLN);
   return d * rstd;
 }
@@ -37,11 +44,13 @@ __global__ __launch_bounds__(kBlock) void ln_edge_gate_fwd_k(
     int64_t N, const float* __restrict__ t, const float* __restrict__ e_in, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ P, const int32_t* __restrict__ isrc,
     const int32_t* __restrict__ in_ptr, float* __restrict__ e_out, float* __restrict__ hf,
-    float* __restrict__ inv_f, int64_t nodes_per_block) {
+    float* __restrict__ inv_f, int64_t nodes_per_block, int width) {
   constexpr int G = H / 4, RPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane / G, c4 = (lane % G) * 4;
+  const float4 live = live_mask(c4, width);
+  const float inv_w = 1.0f / (float)width;
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int64_t v0 = (int64_t)chunk * nodes_per_block;
   const int64_t v1 = min(N, v0 + nodes_per_block);
@@ -52,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void ln_edge_gate_fwd_k(
     for (int64_t j = a + sub; j < b; j += RPW) {
       const int64_t s = isrc[j];
       float rstd;
-      const float4 th = row_normalize<H>(ld4_nt(t + j * H + c4), rstd);
+      const float4 th = row_normalize<H>(ld4_nt(t + j * H + c4), live, inv_w, rstd);
       float4 er_ = f4(0.f);
       if constexpr (RES) er_ = ld4_nt(e_in + j * H + c4);
       const float4 eo = relu4(fma4(th, ga, be)) + er_;
@@ -81,14 +90,15 @@ __global__ __launch_bounds__(kBlock) void ln_node_update_fwd_k(int64_t N, const 
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ h_in,
-                                                               float* __restrict__ h_out) {
+                                                               float* __restrict__ h_out, int width) {
   constexpr int G = H / 4;
   const int64_t total = N * G;     // a multiple of G: the lanes of a row are in range together
+  const float inv_w = 1.0f / (float)width;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int c4 = (int)(i % G) * 4;
     const int64_t o = (i / G) * H + c4;
     float rstd;
-    const float4 zh = row_normalize<H>(ld4(z + o), rstd);
+    const float4 zh = row_normalize<H>(ld4(z + o), live_mask(c4, width), inv_w, rstd);
     float4 hr_ = f4(0.f);
     if constexpr (RES) hr_ = ld4(h_in + o);
     st4(h_out + o, relu4(fma4(zh, ld4(gamma + c4), ld4(beta + c4))) + hr_);
@@ -102,11 +112,13 @@ __global__ __launch_bounds__(kBlock) void ln_node_bwd_k(
     int64_t N, const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ gh_out, const float* __restrict__ hf, const float* __restrict__ inv_f,
     const float* __restrict__ hb, const float* __restrict__ inv_b, float* __restrict__ gP,
-    float* __restrict__ Q, double* __restrict__ partials, int64_t rows_per_block) {
+    float* __restrict__ Q, double* __restrict__ partials, int64_t rows_per_block, int width) {
   constexpr int G = H / 4, RPW = 64 / G;
   __shared__ double lds[kWavesPerBlock * 2 * H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / G, c4 = (lane % G) * 4;
+  const float4 live = live_mask(c4, width);
+  const float inv_w = 1.0f / (float)width;
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int64_t r0 = (int64_t)chunk * rows_per_block;
   const int64_t r1 = min(N, r0 + rows_per_block);
@@ -116,13 +128,13 @@ __global__ __launch_bounds__(kBlock) void ln_node_bwd_k(
   for (int64_t v = r0 + wave * RPW + sub; v < r1; v += kWavesPerBlock * RPW) {
     const int64_t o = v * H + c4;
     float rstd;
-    const float4 zh = row_normalize<H>(ld4(z + o), rstd);
+    const float4 zh = row_normalize<H>(ld4(z + o), live, inv_w, rstd);
     const float4 gw = gate4(fma4(zh, ga, be), ld4(gh_out + o));
     st.add_prod(gw, zh);
     const float4 a = ga * gw;
-    const float m1 = row_sum<G>(hsum4(a)) * (1.0f / H);
-    const float m2 = row_sum<G>(hsum4(a * zh)) * (1.0f / H);
-    const float4 gz = (a - f4(m1) - zh * m2) * rstd;
+    const float m1 = row_sum<G>(hsum4(a)) * inv_w;
+    const float m2 = row_sum<G>(hsum4(a * zh)) * inv_w;
+    const float4 gz = (a - f4(m1) * live - zh * m2) * rstd;
     st4(gP + v * (5 * H) + c4, gz);
     const float4 qf = gz * ld4(inv_f + o);
     const float4 qb = gz * ld4(inv_b + o);
@@ -142,12 +154,14 @@ __global__ __launch_bounds__(kBlock) void ln_edge_bwd_dst_k(
     int64_t N, const float* __restrict__ e_out, const float* __restrict__ t, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ ge, const float* __restrict__ P,
     const float* __restrict__ Q, const int32_t* __restrict__ isrc, const int32_t* __restrict__ in_ptr,
-    float* __restrict__ gP, float* __restrict__ gt, double* __restrict__ partials, int64_t nodes_per_block) {
+    float* __restrict__ gP, float* __restrict__ gt, double* __restrict__ partials, int64_t nodes_per_block, int width) {
   constexpr int G = H / 4, RPW = 64 / G;
   __shared__ double lds[kWavesPerBlock * 2 * H];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane / G, c4 = (lane % G) * 4;
+  const float4 live = live_mask(c4, width);
+  const float inv_w = 1.0f / (float)width;
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int64_t v0 = (int64_t)chunk * nodes_per_block;
   const int64_t v1 = min(N, v0 + nodes_per_block);
@@ -172,13 +186,13 @@ __global__ __launch_bounds__(kBlock) void ln_edge_bwd_dst_k(
         const float4 g = fma4(gsig, dsg, ld4_nt(ge + j * H + c4));
         st4_nt(ge + j * H + c4, g);
         float rstd;
-        const float4 th = row_normalize<H>(ld4_nt(t + j * H + c4), rstd);
+        const float4 th = row_normalize<H>(ld4_nt(t + j * H + c4), live, inv_w, rstd);
         const float4 gu = gate4(fma4(th, ga, be), g);
         st.add_prod(gu, th);
         const float4 ag = ga * gu;
-        const float m1 = row_sum<G>(hsum4(ag)) * (1.0f / H);
-        const float m2 = row_sum<G>(hsum4(ag * th)) * (1.0f / H);
-        const float4 gtv = (ag - f4(m1) - th * m2) * rstd;
+        const float m1 = row_sum<G>(hsum4(ag)) * inv_w;
+        const float m2 = row_sum<G>(hsum4(ag * th)) * inv_w;
+        const float4 gtv = (ag - f4(m1) * live - th * m2) * rstd;
         st4_nt(gt + j * H + c4, gtv);
         a3acc = fma4(sg, qb_s, a3acc);
         gtsum += gtv;
@@ -256,30 +270,31 @@ static inline int ewgrid(int64_t items) {
 extern "C" int gnm_ln_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in,
                                     const float* gamma, const float* beta, const float* P,
                                     const int32_t* isrc, const int32_t* in_ptr, float* e_out, float* hf,
-                                    float* inv_f, void* stream) {
+                                    float* inv_f, int width, void* stream) {
+  GNM_CHECK_ARG(width >= 1 && width <= H, "ln_edge_gate_fwd: width must be in [1, H]");
   GNM_CHECK_ARG(N >= 0 && E >= 0 && t && gamma && beta && P && isrc && in_ptr && e_out && hf && inv_f,
                 "ln_edge_gate_fwd: null/neg argument");      // e_in == NULL: no residual
   GNM_DISPATCH_H(H, {
     const int grid = persistent_grid(N, 64, occ_blocks<ln_edge_gate_fwd_k<HH>>());
     if (e_in)
       hipLaunchKernelGGL((ln_edge_gate_fwd_k<HH, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, gamma,
-                         beta, P, isrc, in_ptr, e_out, hf, inv_f, cdivl(N, grid));
+                         beta, P, isrc, in_ptr, e_out, hf, inv_f, cdivl(N, grid), width);
     else
       hipLaunchKernelGGL((ln_edge_gate_fwd_k<HH, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, t, e_in, gamma,
-                         beta, P, isrc, in_ptr, e_out, hf, inv_f, cdivl(N, grid));
+                         beta, P, isrc, in_ptr, e_out, hf, inv_f, cdivl(N, grid), width);
   });
   GNM_LAUNCH_CHECK("ln_edge_gate_fwd");
   return 0;
 }
 
 extern "C" int gnm_ln_node_update_fwd(int64_t N, int H, const float* z, const float* gamma, const float* beta,
-                                      const float* h_in, float* h_out, void* stream) {
-  GNM_CHECK_ARG(N >= 0 && z && gamma && beta && h_out, "ln_node_update_fwd: null/neg argument");   // h_in == NULL: no residual
+                                      const float* h_in, float* h_out, int width, void* stream) {
+  GNM_CHECK_ARG(N >= 0 && z && gamma && beta && h_out && width >= 1 && width <= H, "ln_node_update_fwd: null/neg argument or width outside [1, H]");   // h_in == NULL: no residual
   GNM_DISPATCH_H(H, {
     if (h_in)
-      hipLaunchKernelGGL((ln_node_update_fwd_k<HH, true>), dim3(ewgrid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, gamma, beta, h_in, h_out);
+      hipLaunchKernelGGL((ln_node_update_fwd_k<HH, true>), dim3(ewgrid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, gamma, beta, h_in, h_out, width);
     else
-      hipLaunchKernelGGL((ln_node_update_fwd_k<HH, false>), dim3(ewgrid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, gamma, beta, h_in, h_out);
+      hipLaunchKernelGGL((ln_node_update_fwd_k<HH, false>), dim3(ewgrid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, gamma, beta, h_in, h_out, width);
   });
   GNM_LAUNCH_CHECK("ln_node_update_fwd");
   return 0;
@@ -288,13 +303,14 @@ extern "C" int gnm_ln_node_update_fwd(int64_t N, int H, const float* z, const fl
 extern "C" int gnm_ln_node_bwd(int64_t N, int H, const float* z, const float* gamma, const float* beta,
                                const float* gh_out, const float* hf, const float* inv_f, const float* hb,
                                const float* inv_b, float* gP, float* Q, double* partials, int* nblk_out,
-                               void* stream) {
+                               int width, void* stream) {
+  GNM_CHECK_ARG(width >= 1 && width <= H, "ln_node_bwd: width must be in [1, H]");
   GNM_CHECK_ARG(N >= 0 && z && gamma && beta && gh_out && hf && inv_f && hb && inv_b && gP && Q && partials && nblk_out,
                 "ln_node_bwd: null/neg argument");
   GNM_DISPATCH_H(H, {
     const int grid = persistent_grid(N, 256, occ_blocks<ln_node_bwd_k<HH>>());
     hipLaunchKernelGGL(ln_node_bwd_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, z, gamma, beta,
-                       gh_out, hf, inv_f, hb, inv_b, gP, Q, partials, cdivl(N, grid));
+                       gh_out, hf, inv_f, hb, inv_b, gP, Q, partials, cdivl(N, grid), width);
     *nblk_out = grid;
   });
   GNM_LAUNCH_CHECK("ln_node_bwd");
@@ -304,13 +320,14 @@ extern "C" int gnm_ln_node_bwd(int64_t N, int H, const float* z, const float* ga
 extern "C" int gnm_ln_edge_bwd_dst(int64_t N, int64_t E, int H, const float* e_out, const float* t,
                                    const float* gamma, const float* beta, float* ge, const float* P,
                                    const float* Q, const int32_t* isrc, const int32_t* in_ptr, float* gP,
-                                   float* gt, double* partials, int* nblk_out, void* stream) {
+                                   float* gt, double* partials, int* nblk_out, int width, void* stream) {
+  GNM_CHECK_ARG(width >= 1 && width <= H, "ln_edge_bwd_dst: width must be in [1, H]");
   GNM_CHECK_ARG(N >= 0 && E >= 0 && e_out && t && gamma && beta && ge && P && Q && isrc && in_ptr && gP && gt &&
                     partials && nblk_out, "ln_edge_bwd_dst: null/neg argument");
   GNM_DISPATCH_H(H, {
     const int grid = persistent_grid(N, 64, occ_blocks<ln_edge_bwd_dst_k<HH>>());
     hipLaunchKernelGGL(ln_edge_bwd_dst_k<HH>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, N, e_out, t, gamma,
-                       beta, ge, P, Q, isrc, in_ptr, gP, gt, partials, cdivl(N, grid));
+                       beta, ge, P, Q, isrc, in_ptr, gP, gt, partials, cdivl(N, grid), width);
     *nblk_out = grid;
   });
   GNM_LAUNCH_CHECK("ln_edge_bwd_dst");

@@ -356,11 +356,14 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
 
 @on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
 def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True,
-                  residual: bool = True, plan: Optional[dict] = None):
+                  residual: bool = True, plan: Optional[dict] = None, ln_width: Optional[int] = None):
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
     Returns (h_out, e_out, LayerSaved or None).  H = out_channels; h_in [N,Hin], e_in [E,Hin] with Hin != H only
     when residual is False (the reference drops the residual then: gated_gcn_full.py:41-42).
-    plan (graph.sweep_plan(device, 2), BatchNorm, H = 128 or 256): gate + by-source aggregation as ONE two-sided sweep."""
+    plan (graph.sweep_plan(device, 2), BatchNorm, H = 128 or 256): gate + by-source aggregation as ONE two-sided sweep.
+    ln_width (LayerNorm mode, a layer zero-padded to the kernel width H): the layer's real out_channels -- nn.LayerNorm
+    normalises over those (gated_gcn_full.py:58-59), the dead channels are left out of the row statistics."""
+    lnw = H if ln_width is None else int(ln_width)
     if residual and h_in.shape[1] != H:
         raise _lib.GnmError("layer_forward: a residual layer needs in_channels == out_channels")
     res_e = _ptr(e_in) if residual else C.c_void_p(0)
@@ -393,7 +396,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     else:       # LayerNorm: row statistics inside the kernel, no barrier
         stat_e = None
         _call("gnm_ln_edge_gate_fwd", N, E, H, _ptr(t), res_e, _ptr(prm.gamma_e), _ptr(prm.beta_e), _ptr(P),
-              _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), st)
+              _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(e_out), _ptr(hf), _ptr(inv_f), lnw, st)
     # by-source gated mean on the same gate, z, BatchNorm statistics over N (:133-147)
     if not two_sided:
         hb = torch.empty(N, H, **f32)
@@ -408,7 +411,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
         _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), res_h, _ptr(h_out), st)
     else:
         stat_h = None
-        _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), res_h, _ptr(h_out), st)
+        _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), res_h, _ptr(h_out), lnw, st)
     saved = None
     if save:
         lean = ACTIVATIONS == "lean"
@@ -419,7 +422,8 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
 
 @on_device_of(lambda idx, N, E, H, prm, s, gh_out, *a, **k: gh_out)
 def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True,
-                   out: Optional[Dict[str, torch.Tensor]] = None, residual: bool = True, plan: Optional[dict] = None):
+                   out: Optional[Dict[str, torch.Tensor]] = None, residual: bool = True, plan: Optional[dict] = None,
+                   ln_width: Optional[int] = None):
     """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
     and is OVERWRITTEN with d loss / d e_in (residual layers; without the residual the returned ge is a fresh [E,Hin]
     tensor).  Returns (gh_in, ge, grads dict).  `out` (optional) names the tensors
@@ -427,6 +431,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     e.g. views of a flat gradient buffer) instead of fresh allocations."""
     out = out or {}
     Hin = s.h_in.shape[1]
+    lnw = H if ln_width is None else int(ln_width)
     fused = H == 128 and FUSED and residual          # the fused backward kernels have the residual adds built in
     new = lambda key, *shape: out[key] if key in out else torch.empty(*shape, dtype=torch.float32, device=gh_out.device)  # noqa: E731
     lib = _lib.load()
@@ -444,12 +449,12 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     if not batch_norm:
         # ---- LayerNorm mode: no global barriers, gt is produced by the by-destination pass ----
         _call("gnm_ln_node_bwd", N, H, _ptr(s.z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(gh_out), _ptr(s.hf),
-              _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), _ptr(sc.partials), C.byref(nblk), st)
+              _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), _ptr(sc.partials), C.byref(nblk), lnw, st)
         _, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
         gt = torch.empty(E, H, **f32)
         _call("gnm_ln_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(prm.gamma_e), _ptr(prm.beta_e),
               _ptr(ge), _ptr(s.P), _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt),
-              _ptr(sc.partials), C.byref(nblk), st)
+              _ptr(sc.partials), C.byref(nblk), lnw, st)
         _, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
         _call("gnm_ln_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q), _ptr(idx["out_ptr"]),
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
@@ -483,7 +488,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
                   _ptr(gP), _ptr(UT), st)
             bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
             _call("gnm_node_bgrad", N, H, _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(idx["in_ptr"]),
-                  _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), _ptr(gP), st)
+                  _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), Ud.stride(0), _ptr(gP), st)
             del UT, DT
         else:
             # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
@@ -692,7 +697,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                   _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), src_cap, st)
         else:       # the sums are there (chain_src + fix): only the conversion through m1, m2 is left
             _call("gnm_node_bgrad", N, H, _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(idx["in_ptr"]),
-                  _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), _ptr(gP), st)
+                  _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), Ud.stride(0), _ptr(gP), st)
         del Ud, Td, Q
         UT = None
         g["W5"], g["b5"] = tgt(i, "W5", 5 * H, H), tgt(i, "b5", 5 * H)
@@ -923,9 +928,10 @@ def layer_params(P: Dict[str, torch.Tensor], i: int) -> LayerParams:
 
 
 @on_device_of(lambda graph, e_raw, pe, *a, **k: pe)
-def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int, save: bool, batch_norm: bool = True):
+def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int, save: bool, batch_norm: bool = True,
+                  ln_width: Optional[int] = None):
     """GraphGatedGCNModel.forward.  e_raw [E,edge_features] in edge-id order, pe [N,nb_pos_enc+2].
-    Returns (scores [E,1] in edge-id order, ModelSaved or None)."""
+    Returns (scores [E,1] in edge-id order, ModelSaved or None).  ln_width: see layer_forward."""
     lib = _lib.load()
     dev = pe.device
     _chk_dev(e_raw, pe)
@@ -955,7 +961,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw) if save else None
     plan2 = graph.sweep_plan(dev, 2) if (TWO_SIDED_FWD and batch_norm and H in (128, 256) and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
-        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2)
+        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width)
         if save:
             ms.layers.append(ls)
     scores, ps = predictor_forward(idx, N, E, H, P["predictor.W1.weight"], P["predictor.W1.bias"],
@@ -981,7 +987,7 @@ def grad_targets(out: Dict[str, torch.Tensor], i: int) -> Optional[Dict[str, tor
 
 @on_device_of(lambda graph, P, num_layers, ms, gscores, *a, **k: gscores)
 def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores, batch_norm: bool = True,
-                   out: Optional[Dict[str, torch.Tensor]] = None):
+                   out: Optional[Dict[str, torch.Tensor]] = None, ln_width: Optional[int] = None):
     """Gradients of every parameter (keys = state_dict keys) from d loss / d scores.  With `out` (state_dict key ->
     contiguous tensor of the parameter's shape, e.g. the .grad views of dp.FlatGradients) the kernels write the
     gradients straight into those tensors and the same tensors are returned."""
@@ -1011,7 +1017,8 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
         if chained is not None:
             gl = chained[i]
         else:
-            gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout, plan=plan_w)
+            gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout, plan=plan_w,
+                                        ln_width=ln_width)
             ms.layers[i] = None     # release this layer's activations
         for j, k in enumerate(LIN5):
             G[p + k + ".weight"] = gl["W5"][j * H:(j + 1) * H]

@@ -34,8 +34,9 @@ class _LayerFn(torch.autograd.Function):
     """One GatedGCN_1d.forward with edge-id-order e at the boundary."""
 
     @staticmethod
-    def forward(ctx, graph, need, batch_norm, residual, h, e, *flat):
+    def forward(ctx, graph, need, norm, residual, h, e, *flat):
         names = _LAYER_KEYS
+        batch_norm, ln_width = norm           # ln_width: the layer's real out_channels (LayerNorm statistics, engine.layer_forward)
         P = {"gnn.convs.0." + k: v for k, v in zip(names, flat)}
         idx = graph.index(h.device)
         N, E, H = graph.num_nodes(), graph.num_edges(), flat[0].shape[0]        # H = out_channels (A_1.weight is [out, in])
@@ -43,8 +44,8 @@ class _LayerFn(torch.autograd.Function):
         e_int = e.detach().index_select(0, perm).contiguous()
         prm = engine.layer_params(P, 0)
         h_int = engine.node_rows_in(idx, engine._f32c(h.detach()))       # caller's node numbering -> internal (graph.py)
-        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h_int, e_int, need, batch_norm, residual)
-        ctx.graph, ctx.saved, ctx.P, ctx.dims, ctx.bn, ctx.res = graph, saved, P, (N, E, H), batch_norm, residual
+        h_out, e_out, saved = engine.layer_forward(idx, N, E, H, prm, h_int, e_int, need, batch_norm, residual, ln_width=ln_width)
+        ctx.graph, ctx.saved, ctx.P, ctx.dims, ctx.bn, ctx.res, ctx.lnw = graph, saved, P, (N, E, H), batch_norm, residual, ln_width
         out_e = torch.empty_like(e_out)
         out_e.index_copy_(0, perm, e_out)
         return engine.node_rows_out(idx, h_out), out_e
@@ -60,7 +61,7 @@ class _LayerFn(torch.autograd.Function):
         ge = ge_out.index_select(0, perm).contiguous()        # fresh buffer, overwritten below
         gh_in, ge_in, g = engine.layer_backward(idx, N, E, H, prm, ctx.saved,
                                                 engine.node_rows_in(idx, engine._f32c(gh_out)), ge, ctx.bn,
-                                                residual=ctx.res)
+                                                residual=ctx.res, ln_width=ctx.lnw)
         gh_in = engine.node_rows_out(idx, gh_in)
         ctx.saved = None
         ge_user = torch.empty_like(ge_in)
@@ -122,7 +123,7 @@ class GatedGCN_1d(nn.Module):
                     F.pad(t, (0, d), value=1.0 if k in ("bn_h.weight", "bn_e.weight") else 0.0) for k, t in zip(_LAYER_KEYS, flat)]
             if di:
                 h, e = F.pad(h, (0, di)), F.pad(e, (0, di))
-        h, e = _LayerFn.apply(g, need, bool(self.batch_norm), self.residual, h, e, *flat)
+        h, e = _LayerFn.apply(g, need, (bool(self.batch_norm), W), self.residual, h, e, *flat)
         if Wp != W:
             h, e = h[:, :W], e[:, :W]
         if self.dropout and self.training:

@@ -65,12 +65,15 @@ class _ModelFn(torch.autograd.Function):
     to the predictor, activations are released layer by layer in backward."""
 
     @staticmethod
-    def forward(ctx, graph, e, pe, num_layers, names, need, batch_norm, *flat):
+    def forward(ctx, graph, e, pe, num_layers, names, need, norm, *flat):
         # `need` (grad mode on and some parameter requires grad) is decided by the caller: inside
         # Function.forward grad mode is always off, and needs_input_grad stays set under no_grad.
+        # norm = (batch_norm, real hidden width): LayerNorm statistics run over the model's real width when the kernels
+        # run it zero-padded to the next width up (gated_gcn_full.py:58-59: nn.LayerNorm(out_channels))
+        batch_norm, ln_width = norm
         P = {k: v.detach() for k, v in zip(names, flat)}
-        scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need, batch_norm)
-        ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L, ctx.bn = graph, saved, P, names, num_layers, batch_norm
+        scores, saved = engine.model_forward(graph, e.detach(), pe.detach(), P, num_layers, need, batch_norm, ln_width=ln_width)
+        ctx.graph, ctx.saved, ctx.P, ctx.names, ctx.L, ctx.bn, ctx.lnw = graph, saved, P, names, num_layers, batch_norm, ln_width
         ctx.params = flat if need else None
         return scores
 
@@ -85,11 +88,11 @@ class _ModelFn(torch.autograd.Function):
         fg = dp.fresh_flat_gradients(ctx.params)
         if fg is not None and all(ctx.needs_input_grad[7:]):
             out = {k: p.grad for k, p in zip(ctx.names, ctx.params)}
-            engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores, ctx.bn, out=out)
+            engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores, ctx.bn, out=out, ln_width=ctx.lnw)
             fg.fresh = False
             ctx.saved = None
             return (None,) * (7 + len(ctx.names))
-        G = engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores, ctx.bn)
+        G = engine.model_backward(ctx.graph, ctx.P, ctx.L, ctx.saved, gscores, ctx.bn, ln_width=ctx.lnw)
         ctx.saved = None
         return (None, None, None, None, None, None, None) + tuple(G[k] for k in ctx.names)
 
@@ -143,7 +146,7 @@ class GraphGatedGCNModel(nn.Module):
             names, flat = zip(*self.named_parameters())
             padded = tuple(_pad_param(k, v, H, Hp) for k, v in zip(names, flat))
             need = torch.is_grad_enabled() and any(p.requires_grad for p in flat)
-            return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, self.batch_norm, *padded)
+            return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, (self.batch_norm, H), *padded)
         if pe.is_cuda and not _is_flat(self):
             flatten_parameters(self)          # once per device placement: stacked-parameter views instead of torch.cat
         names, flat = zip(*self.named_parameters())
@@ -153,7 +156,7 @@ class GraphGatedGCNModel(nn.Module):
             # stops at the encoders, so refuse instead of returning a silent None for these gradients
             raise NotImplementedError("GraphGatedGCNModel: gradients w.r.t. the inputs e / pe are not computed; "
                                       "detach them (the stand-alone layers do return input gradients)")
-        return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, self.batch_norm, *flat)
+        return _ModelFn.apply(graph, e, pe, self.num_layers, names, need, (self.batch_norm, H), *flat)
 
 
 class _BCEFn(torch.autograd.Function):

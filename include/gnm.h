@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 4   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels */
+#define GNM_ABI_VERSION 5   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -244,20 +244,23 @@ int gnm_edge_bwd_gt(int64_t E, int H, const float* ge, const float* t, const flo
  * ln_edge_bwd_dst    ge <- ge + gsigma*sigma'; gt = LNbwd(ge*[u>0]) -> gt[E,H]; gP[:,2H:3H] = sum
  *                    sigma*Qb[s]; gP[:,4H:5H] = sum_dst gt; partials (sum gu, sum gu*that)
  * ln_edge_bwd_src    gP[:,H:2H] = sum_src sigma*Qf[d]; gP[:,3H:4H] = sum_src gt
- * (B_3 gradients and ge_in then come from gnm_gemm_f32 TN/NN + gnm_colsum_f32 on gt.)          */
+ * (B_3 gradients and ge_in then come from gnm_gemm_f32 TN/NN + gnm_colsum_f32 on gt.)
+ * width (ABI 5): the layer's REAL channel count, 1 <= width <= H.  nn.LayerNorm(out_channels) takes its mean and
+ * variance over out_channels; a layer that runs on the next kernel width up (H > width: the channels width .. H-1 are
+ * dead -- zero weights, zero inputs) must not count them: they get xhat = 0 and are left out of every row mean.  */
 int gnm_ln_edge_gate_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in,
                          const float* gamma, const float* beta, const float* P, const int32_t* isrc,
-                         const int32_t* in_ptr, float* e_out, float* hf, float* inv_f, void* stream);
+                         const int32_t* in_ptr, float* e_out, float* hf, float* inv_f, int width, void* stream);
 int gnm_ln_node_update_fwd(int64_t N, int H, const float* z, const float* gamma, const float* beta,
-                           const float* h_in, float* h_out, void* stream);
+                           const float* h_in, float* h_out, int width, void* stream);
 int gnm_ln_node_bwd(int64_t N, int H, const float* z, const float* gamma, const float* beta,
                     const float* gh_out, const float* hf, const float* inv_f, const float* hb,
                     const float* inv_b, float* gP, float* Q, double* partials, int* nblk_out,
-                    void* stream);
+                    int width, void* stream);
 int gnm_ln_edge_bwd_dst(int64_t N, int64_t E, int H, const float* e_out, const float* t,
                         const float* gamma, const float* beta, float* ge, const float* P, const float* Q,
                         const int32_t* isrc, const int32_t* in_ptr, float* gP, float* gt,
-                        double* partials, int* nblk_out, void* stream);
+                        double* partials, int* nblk_out, int width, void* stream);
 int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const float* gt, const float* Q,
                         const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
                         float* gP, void* stream);
@@ -318,7 +321,7 @@ int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_o
  * e_out, t, stat_e, Q and ge = this call's ge_out), and once layer i-1's BatchNorm-backward means are known
  * gnm_node_bgrad turns the raw sums into gP[:,3H:4H] = gB1h = c (Us - outdeg m1 - m2 Ts) and gP[:,4H:5H] = gB2h =
  * c (Ud - indeg m1 - m2 Td).  Together = gnm_edge_bwd_src.  Ud_lo / Td_lo: two [N,H] arrays or the halves of one [N,2H]
- * array (Td_lo == Ud_lo + H); gnm_node_bgrad accepts either layout.
+ * array (Td_lo == Ud_lo + H); gnm_node_bgrad takes the row pitch of Ud / Td (H or 2H, in floats) as ud_pitch (ABI 5).
  *                                                                     autograd of gated_gcn_full.py:133-143 */
 int gnm_edge_bwd_chain_src(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
                            const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
@@ -343,7 +346,7 @@ int gnm_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int64_t N, int6
                          const int32_t* out_pos, const int32_t* out_dst, float* gP, float* UT, void* stream);
 int gnm_node_bgrad(int64_t N, int H, const float* stat_e, const float* bstat_e, const float* gamma_e,
                    const int32_t* in_ptr, const int32_t* out_ptr, const float* UT, const float* Ud, const float* Td,
-                   float* gP, void* stream);
+                   int64_t ud_pitch, float* gP, void* stream);
 size_t gnm_node_proj_bwd_workspace_bytes(int ncols);
 int gnm_node_proj_bwd(int64_t N, int H, int ncols, const float* gP, const float* h_in, const float* W,
                       const float* gh_out, float* gh_in, float* gW, float* gb, double* partials,

@@ -422,10 +422,13 @@ def test_standalone_modules_match_oracle():
     assert not bad, bad
 
 
-def test_odd_hidden_width_runs_zero_padded():
+@pytest.mark.parametrize("bn", [True, False])
+def test_odd_hidden_width_runs_zero_padded(bn):
     """nn.Linear(in, out) of the reference takes any width (gated_gcn_full.py:44-50); the row kernels are instantiated for
     32 / 64 / 128 / 256.  A width in between (96) runs on the next one up with dead channels: model logits, loss and every
-    parameter gradient against the fp64 oracle at the usual bars, state_dict shapes untouched."""
+    parameter gradient against the fp64 oracle at the usual bars, state_dict shapes untouched.  batch_norm=False: the
+    reference's nn.LayerNorm(out_channels) (gated_gcn_full.py:58-59) takes its row statistics over the 96 (48) REAL channels --
+    the LayerNorm kernels get the real width and leave the dead channels out."""
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import synth
     from oracle import gatedgcn_oracle as orc
@@ -434,7 +437,7 @@ def test_odd_hidden_width_runs_zero_padded():
     src, dst, n = synth.make_graph(400, seed, permute_edge_ids=True)
     inp = synth.make_inputs(src, dst, n, seed)
     sd = synth.synth_state_dict(H, L, seed)
-    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, True, 16)
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, bn, 16)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.to(dev)
     assert model.gnn.convs[0].A_1.weight.shape == (H, H)
@@ -446,13 +449,13 @@ def test_odd_hidden_width_runs_zero_padded():
     torch.cuda.synchronize()
     p64 = sd_to_torch(sd, torch.float64, requires_grad=True)
     ts, td = torch.from_numpy(src), torch.from_numpy(dst)
-    r = orc.model_forward(p64, ts, td, n, torch.from_numpy(inp["e"]).double(), torch.from_numpy(inp["pe"]).double())
+    r = orc.model_forward(p64, ts, td, n, torch.from_numpy(inp["e"]).double(), torch.from_numpy(inp["pe"]).double(), bn)
     l64 = orc.bce_loss(r, torch.from_numpy(inp["y"]).double(), float(inp["pos_weight"]))
     l64.backward()
     assert_parity(s.detach().cpu().numpy(), r.detach().numpy(), "H=96 logits")
     assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item()) + 1e-7
     p32 = sd_to_torch(sd, torch.float32, requires_grad=True)
-    orc.bce_loss(orc.model_forward(p32, ts, td, n, torch.from_numpy(inp["e"]), torch.from_numpy(inp["pe"])),
+    orc.bce_loss(orc.model_forward(p32, ts, td, n, torch.from_numpy(inp["e"]), torch.from_numpy(inp["pe"]), bn),
                  torch.from_numpy(inp["y"]), float(inp["pos_weight"])).backward()
     gmax = max(float(v.grad.norm()) for v in p64.values())
     bad = []
@@ -465,16 +468,35 @@ def test_odd_hidden_width_runs_zero_padded():
             bad.append((k, ro, rr))
     assert not bad, bad
     # the stand-alone layer at an odd width, residual on (in == out == 48 -> padded to 64)
-    lay = G.layers.GatedGCN_1d(48, 48, True).to(dev)
+    lay = G.layers.GatedGCN_1d(48, 48, bn).to(dev)
     rng = np.random.default_rng(4)
+    with torch.no_grad():       # norm weights / biases off their init values: a dead channel must not see them either
+        for nm in ("bn_h", "bn_e"):
+            getattr(lay, nm).weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 48).astype(np.float32)))
+            getattr(lay, nm).bias.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, 48).astype(np.float32)))
     h0 = torch.from_numpy(rng.standard_normal((n, 48)).astype(np.float32))
     e0 = torch.from_numpy(rng.standard_normal((src.size, 48)).astype(np.float32))
-    h1, e1 = lay(g, h0.to(dev), e0.to(dev))
-    lsd = {"gnn.convs.0." + k: v.detach().cpu().double() for k, v in lay.state_dict().items()}
-    rh, re = orc.layer_forward(lsd, 0, ts.long(), td.long(), n, h0.double(), e0.double())
+    hd, ed = h0.to(dev).requires_grad_(True), e0.to(dev).requires_grad_(True)
+    h1, e1 = lay(g, hd, ed)
+    lsd = {"gnn.convs.0." + k: v.detach().cpu().double().requires_grad_(True) for k, v in lay.state_dict().items()}
+    h64, e64 = h0.double().requires_grad_(True), e0.double().requires_grad_(True)
+    rh, re = orc.layer_forward(lsd, 0, ts.long(), td.long(), n, h64, e64, bn)
     assert h1.shape == (n, 48) and e1.shape == (src.size, 48)
-    assert_parity(h1.detach().cpu().numpy(), rh.numpy(), "H=48 layer h", l2=2e-5)
-    assert_parity(e1.detach().cpu().numpy(), re.numpy(), "H=48 layer e", l2=2e-5)
+    assert_parity(h1.detach().cpu().numpy(), rh.detach().numpy(), "H=48 layer h", l2=2e-5)
+    assert_parity(e1.detach().cpu().numpy(), re.detach().numpy(), "H=48 layer e", l2=2e-5)
+    # ... and its backward (input and parameter gradients) under a fixed cotangent
+    ch = torch.from_numpy(rng.standard_normal((n, 48)).astype(np.float32))
+    ce = torch.from_numpy(rng.standard_normal((src.size, 48)).astype(np.float32))
+    ((h1 * ch.to(dev)).sum() + (e1 * ce.to(dev)).sum()).backward()
+    ((rh * ch.double()).sum() + (re * ce.double()).sum()).backward()
+    rows = []
+    _cmp("H=48 layer gh", hd.grad, h64.grad, rows)
+    _cmp("H=48 layer ge", ed.grad, e64.grad, rows)
+    for k, prm in lay.named_parameters():
+        _cmp("H=48 layer g " + k, prm.grad, lsd["gnn.convs.0." + k].grad, rows)
+    _report(rows)
+    gmx = max(r_[3] for r_ in rows)
+    assert all(r_[1] <= 1e-3 or r_[2] <= 2e-6 * max(gmx, 1.0) for r_ in rows), [r_ for r_ in rows if r_[1] > 1e-3]
 
 
 @pytest.mark.mode_independent
