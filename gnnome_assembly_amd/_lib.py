@@ -41,6 +41,9 @@ SIGNATURES = {
     "gnm_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_node_agg_src_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p]),
+    "gnm_s3_bytes": (_sz, [_i64, _i32]),
+    "gnm_split_rows_s3": (_i32, [_i64, _i32, _p, _p, _p]),
+    "gnm_node_update_fwd_s3": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
     "gnm_node_bwd_stats": (_i32, [_i64, _i32, _p, _p, _p, _p, _pi, _p]),
     "gnm_node_bwd_apply": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
@@ -59,10 +62,13 @@ SIGNATURES = {
     "gnm_edge_t_fused_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),
     "gnm_edge_bwd_gt_nn": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_fwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_node_proj_fwd_s3": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_workspace_bytes": (_sz, [_i32]),
     "gnm_node_proj_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_nn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_tn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _i32, _p]),
+    "gnm_node_proj_bwd_nn_stats": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),
+    "gnm_tn128_bgrad": (_i32, [_i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_bwd_chain": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_pi, _p, _sz, _p]),
     "gnm_edge_bwd_chain_src": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_p, _i64, _p] + [_pi, _p, _sz, _p]),
     "gnm_edge_bwd_top": (_i32, [_i64, _i64, _i32] + [_p] * 15 + [_p, _i64, _p, _pi, _p, _sz, _p]),
@@ -84,6 +90,7 @@ SIGNATURES = {
     "gnm_predictor_fused_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_tn128_workspace_bytes": (_sz, []),
     "gnm_tn128": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_tn128_s3": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_decode_build_adjacency": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p]),
     "gnm_decode_iteration": (_i64, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _i64, _p]),
     "gnm_reduce_partials": (_i32, [_p, _i32, _i32, _i32, _p, _p]),

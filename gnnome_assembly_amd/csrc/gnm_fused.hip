@@ -535,6 +535,82 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
 }
 
 // ------------------------------------------------------------------------------------------
+// Node projections from the PRE-SPLIT image of h (round 5; gnm_layer.hip "the pre-split image"):
+//   P[:, cg*128 + c] = h W5_cg^T + b5       rowtile_nt_k<MmB3, false, 1> without its split staging
+// The five column-group classes of a row chunk each staged the same 64 x 128 tile of h with 8 split3 per thread
+// (~320 of the ~420 VALU instructions of a tile, against 96 MFMAs per wave: the kernel's matrix pipe was ~60 % busy and
+// its vector ALU the rest).  Here the three bf16 images arrive as they are from HBM (768 bytes per row, written by the
+// kernel that produced h) and go to LDS as twelve 16-byte copies per thread; the MFMA phase, its fragment order and
+// the epilogue are the old kernel's, so P is bit-identical.
+// ------------------------------------------------------------------------------------------
+constexpr int S3P = 3 * FH;      // bf16 elements per row of the split image [hi 128 | mid 128 | lo 128]
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBlock, 2) void rowtile_nt_s3_k(
+    int64_t M, const __bf16* __restrict__ Xs, const void* __restrict__ Wp, const float* __restrict__ bias,
+    float* __restrict__ Y, int64_t ldy, int64_t tiles_per_block, int ncgs) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];   // three [64][BP] bf16 images
+  float* xs = reinterpret_cast<float*>(xraw);                                    // reused as the fp32 output image
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  // the ncgs workgroups of a row chunk sit on one XCD and share the image rows in its L2 (as rowtile_nt_k)
+  const int xcd = blockIdx.x % kXcds, jb = blockIdx.x / kXcds;
+  const int cgb = jb % ncgs;
+  const int chunk = xcd * (gridDim.x / ncgs / kXcds) + jb / ncgs;
+  const int64_t ntiles = (M + FTR - 1) / FTR;
+  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
+  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
+  const int64_t nfull = min(tb1, M / FTR);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;   // this thread's slot in the coalesced fp32 output image
+  const int r16 = tid >> 4, slot = tid & 15;         // ... and in the copy of the split image: piece j = rows 16 (j / 3) + r16,
+  const int64_t Mlast = M - 1;                       //     part j % 3, 16-byte slot `slot` (a wave reads 4 rows x 256 bytes)
+
+  MmB3::Frag wf;
+  MmB3::load_w(wf, Wp, cgb * 4 + wave, lane);
+
+  u32x4_ pre[12];
+  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile * FTR;
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+      pre[j] = *reinterpret_cast<const u32x4_*>(Xs + clampi(r0 + 16 * (j / 3) + r16, Mlast) * S3P + (j % 3) * FH + slot * 8);
+  };
+  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(tag)::value;
+    __syncthreads();   // everyone is done with the previous tile's output image
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+      *reinterpret_cast<u32x4_*>(xraw + (j % 3) * (BIMG * 2) + (16 * (j / 3) + r16) * (BP * 2) + slot * 16) = pre[j];
+    __syncthreads();
+    const int64_t r0 = tile * FTR;
+    prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // next tile's image rows, in flight under the MFMAs
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    MmB3::mma(xraw, wf, acc0, acc1, li, lg);
+    __syncthreads();         // all waves are done reading the images
+    acc_to_lds(xs, acc0, acc1, wave, li, lg);
+    __syncthreads();
+    const float4 b4 = ld4(bias + cgb * FH + lc4);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = lrow + 8 * it;
+      const int64_t grow = r0 + row;
+      const float4 v = ld4(xs + row * FP + lc4) + b4;
+      if (FULL || grow < M) st4(Y + grow * ldy + cgb * FH + lc4, v);
+    }
+  };
+  if (tb0 < tb1) prefetch(tb0);
+  if (tb0 < nfull) {
+    // throw-away stores behind the first prefetch: the loop-entry scoreboard equals the back edge's (see rowtile_nt_k)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * ldy + cgb * FH + lc4, f4(0.f));
+    for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
+  }
+  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
+}
+
+// ------------------------------------------------------------------------------------------
 // Split-mode edge t kernel with 32-row tiles: t = e W3^T + b3 + B1h[src] + B2h[dst] + BatchNorm sums.
 // 69 KB of LDS and <= 256 VGPRs -> two workgroups per CU (the 64-row version needs 330 registers, and
 // with one wave per SIMD its split staging and epilogue leave the matrix pipe 32 % busy).  The two
@@ -1584,6 +1660,119 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
 }
 
 // ------------------------------------------------------------------------------------------
+// rowtile_nn2_k (round 5): rowtile_nn_group32_b3_k with the BatchNorm_h backward sums of the layer BELOW in its epilogue.
+// The epilogue holds the rows of gh_in = the gh_out of the layer below, whose BatchNorm_h backward begins with
+// (sum gw, sum gw zhat), gw = gh_out [bn_h(z) > 0] (node_bwd_stats_k: z and gh_out read once more, a launch of its own):
+// the sums are taken here from the rows on chip and the z rows, in fp64, parked per thread in LDS between tiles (no
+// registers live across the matrix phase: the kernel sits at 256 with the weight fragments, sixteen accumulators per tile
+// and four tiles of prefetched rows).
+// (The conversion of the raw by-source / by-destination sums into gB1h / gB2h -- node_bgrad_k -- was built into this
+//  kernel's operand load first: two rows of loads per row of operand, +36 live registers, 250-580 spilled in every arrangement
+//  tried.  It went to the weight-gradient kernel instead, which has the registers: tn_tr_k<., CONV>.)
+// ------------------------------------------------------------------------------------------
+struct Nn2Args {
+  int64_t M; const float* X; int64_t ldx; int ncg; const void* Wp; const float* R; float* Y; int64_t groups_per_block;
+  const float* z_lo; const float* stat_lo; double* partials;
+};
+
+template <int T>
+__global__ __launch_bounds__(kBlock, 2) void rowtile_nn2_k(const Nn2Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ double sacc[8 * 2 * FH];      // [row slot 0..7][sum a | sum b][128 columns], one owner thread per entry
+  float* xs = reinterpret_cast<float*>(xraw);
+  static_assert(T % 2 == 0, "two tile buffers");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lg = lane >> 5;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int64_t M = a.M;
+  const int ncg = a.ncg;
+  const int64_t ngroups = (M + NR3 * T - 1) / (NR3 * T);
+  const int64_t g0 = (int64_t)chunk * a.groups_per_block;
+  const int64_t g1 = min(ngroups, g0 + a.groups_per_block);
+  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
+  const int64_t Mlast = M - 1;
+  const float* __restrict__ X = a.X;
+  const int64_t ldx = a.ldx;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sacc[(lrow * 2 + 0) * FH + lc4 + j] = 0.0; sacc[(lrow * 2 + 1) * FH + lc4 + j] = 0.0; }
+  float4 pre[T][4];
+  auto prefetch = [&](float4 (&buf)[4], int64_t g, int cg, int tl) __attribute__((always_inline)) {
+    if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
+    const int64_t r0 = (g * T + tl) * NR3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * ldx + cg * FH + lc4);
+  };
+  if (g0 < g1) {
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) prefetch(pre[tl], g0, 0, tl);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    const int64_t t0 = g * T;
+    floatx16 acc[T];
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
+    for (int cg = 0; cg < ncg; ++cg) {
+      MmB3::Frag wf;
+      MmB3::load_w(wf, a.Wp, cg * 4 + wave, lane);
+#pragma unroll
+      for (int tl = 0; tl < T; ++tl) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        __syncthreads();
+        prefetch(pre[tl], g, cg + 1, tl);
+        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < T; ++tl) {
+      const int64_t r0 = (t0 + tl) * NR3;
+      float4 rr[4], zz[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        rr[it] = ld4(a.R + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+        zz[it] = ld4(a.z_lo + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
+      }
+      __syncthreads();   // MFMAs (first pass) / the previous tile's row reads are done with the image memory
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xs[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[tl][e];
+      __syncthreads();
+      Stat4 st;
+      st.zero();
+      const float4 mu = ld4(a.stat_lo + lc4), rs = ld4(a.stat_lo + FH + lc4);
+      const float4 sc = ld4(a.stat_lo + 2 * FH + lc4), sh = ld4(a.stat_lo + 3 * FH + lc4);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = lrow + 8 * it;
+        const int64_t grow = r0 + row;
+        const float4 v = ld4(xs + row * FP + lc4) + rr[it];
+        if (grow < M) {
+          st4(a.Y + grow * FH + lc4, v);
+          const float4 gw = gate4(fma4(zz[it], sc, sh), v);      // node_bwd_stats_k's expressions
+          st.add_prod(gw, (zz[it] - mu) * rs);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sacc[(lrow * 2 + 0) * FH + lc4 + j] += st.a[j];
+        sacc[(lrow * 2 + 1) * FH + lc4 + j] += st.b[j];
+      }
+    }
+    __syncthreads();   // the output image overlays both tile buffers: done before the next group stages
+  }
+  __syncthreads();
+  // partials[chunk][2][128], as block_stat_store lays them out; the 8 row slots added in a fixed order
+  for (int idx = tid; idx < 2 * FH; idx += kBlock) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_ += sacc[(k * 2 + idx / FH) * FH + idx % FH];
+    a.partials[(size_t)chunk * 2 * FH + idx] = s_;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // General row GEMM in split mode (the hidden sizes the fused 128-wide kernels are not built for, e.g. the reference's
 // own default 256):  Y[r][cls*128 + c] = sum_cg X[r][cg*128 + k] Wblk[cls][cg][k][c]  (+ bias, + R, relu)
 // with K = ncg * 128 and N = ncls * 128.  The kernel above with an output-column class per workgroup: the ncls
@@ -1961,9 +2150,9 @@ static inline int64_t cdiv_(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 namespace gnm {   // gnm_tr.hip: the split-mode TN kernel on swizzled row-major images + transpose reads
 int tn_tr_rows_per_tile();
-int tn_tr_occupancy();
-void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, int64_t ldb, int ncgb, float* slab,
-                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st);
+int tn_tr_occupancy(bool s3 = false, bool conv = false);
+void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B, int64_t ldb, int ncgb, float* slab,
+                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv = nullptr);
 size_t edge_bwd_tr_pack_bytes();
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
@@ -1983,6 +2172,8 @@ int t_pipe_variant() { return g_t_pipe; }
 static int g_wide_pipe = 1;      // H = 256 forward t kernel: 1 = next tile staged inside the matrix phase, 0 = phases one after the other
 static int g_enc_fwd = 1;        // edge encoder forward: 1 = fp32-MFMA kernel, 0 = VALU kernel
 int enc_fwd_variant() { return g_enc_fwd; }
+static int g_tn_s3_occ = 2;      // tn_tr_k with a pre-split B: built for 2 or 3 workgroups per CU
+int tn_s3_occ_variant() { return g_tn_s3_occ; }
 }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "tn")) { g_tn_variant = v; return 0; }
@@ -1992,6 +2183,7 @@ extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "enc_fwd")) { g_enc_fwd = v; return 0; }
   if (what && !strcmp(what, "wide_pipe")) { g_wide_pipe = v; return 0; }
   if (what && !strcmp(what, "t_pipe")) { g_t_pipe = v; return 0; }
+  if (what && !strcmp(what, "tn_s3_occ")) { g_tn_s3_occ = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }
@@ -2118,6 +2310,27 @@ extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, co
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd: workspace too small");
   return g_matmul_mode ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
                        : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
+}
+
+// the same from the pre-split image of h (gnm_split_rows_s3 / gnm_node_update_fwd_s3): split matmul mode only
+extern "C" int gnm_node_proj_fwd_s3(int64_t N, int H, int ncols, const void* hs, const float* W, const float* b,
+                                    float* Pout, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "node_proj_fwd_s3: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(g_matmul_mode == 1, "node_proj_fwd_s3: the pre-split image belongs to the bf16x3 matmul mode");
+  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && hs && W && b && Pout, "node_proj_fwd_s3: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd_s3: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  launch_pack<MmB3>(W, FH, ncols / 32, 0, ws, st);
+  GNM_LAUNCH_CHECK("pack_w (NT, node, s3)");
+  const int64_t ntiles = cdiv_(N, FTR);
+  const int ncg = ncols / FH;
+  int nslot = (num_cus() * occ_blocks<rowtile_nt_s3_k>()) / ncg / kXcds * kXcds;
+  if (nslot > (int)((ntiles + kXcds - 1) / kXcds * kXcds)) nslot = (int)((ntiles + kXcds - 1) / kXcds * kXcds);
+  if (nslot < kXcds) nslot = kXcds;
+  hipLaunchKernelGGL(rowtile_nt_s3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, (const __bf16*)hs, (const void*)ws, b, Pout,
+                     (int64_t)ncols, cdiv_(ntiles, nslot), ncg);
+  GNM_LAUNCH_CHECK("node_proj_fwd_s3");
+  return 0;
 }
 
 namespace gnm {
@@ -2285,19 +2498,22 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
 }
 
 static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,
-                        double* partials, float* slab, void* stream, int max_blocks_per_cu = 0) {
+                        double* partials, float* slab, void* stream, int max_blocks_per_cu = 0, const void* Bs3 = nullptr,
+                        const TnConv* cv = nullptr) {
   hipStream_t st = (hipStream_t)stream;
-  const bool tr = g_matmul_mode && g_tn_variant == 1;
+  const bool tr = (g_matmul_mode && g_tn_variant == 1) || Bs3 || cv;
   const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : g_matmul_mode ? TR3 : FTR);
-  int occ = tr ? tn_tr_occupancy() : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  int occ = tr ? tn_tr_occupancy(Bs3 != nullptr, cv != nullptr) : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
   if (max_blocks_per_cu > 0 && occ > max_blocks_per_cu) occ = max_blocks_per_cu;    // the caller shares the CUs with another stream
   int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
   nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
   if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
-  if (tr)
-    tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st);
+  if (Bs3)
+    tn_tr_launch(N, A, lda, ncg, Bs3, -1, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv);
+  else if (tr)
+    tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv);
   else if (g_matmul_mode)
     hipLaunchKernelGGL(tn_colgroup32_b3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
                        nslot, cdiv_(ntiles, nslot));
@@ -2435,6 +2651,30 @@ extern "C" int gnm_node_proj_bwd_nn(int64_t N, int H, int ncols, const float* gP
                         : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st)) ? -2 : 0;
 }
 
+// gnm_node_proj_bwd_nn with the BatchNorm_h backward sums of the layer below (gnm_node_bwd_stats over gh_in and z_lo) in its
+// epilogue; see rowtile_nn2_k.  bf16x3 mode, H = 128.  partials / *nblk_out: as gnm_node_bwd_stats leaves them.
+extern "C" int gnm_node_proj_bwd_nn_stats(int64_t N, int H, int ncols, const float* gP, const float* W, const float* gh_out,
+                                          float* gh_in, const float* z_lo, const float* stat_h_lo, double* partials,
+                                          int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "node_proj_bwd_nn_stats: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(g_matmul_mode == 1, "node_proj_bwd_nn_stats: bf16x3 matmul mode only");
+  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && W && gh_out && gh_in && z_lo && stat_h_lo && partials && nblk_out,
+                "node_proj_bwd_nn_stats: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_bwd_nn_stats: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int ncg = ncols / FH;
+  hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
+  GNM_LAUNCH_CHECK("pack_w (NN, node, stats)");
+  constexpr int T = 4;
+  const int64_t ngroups = cdiv_(N, NR3 * T);
+  const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn2_k<T>>());
+  const Nn2Args a{N, gP, (int64_t)ncols, ncg, (const void*)ws, gh_out, gh_in, cdiv_(ngroups, grid), z_lo, stat_h_lo, partials};
+  hipLaunchKernelGGL(rowtile_nn2_k<T>, dim3(grid), dim3(kBlock), 0, st, a);
+  *nblk_out = grid;
+  GNM_LAUNCH_CHECK("node_proj_bwd_nn_stats");
+  return 0;
+}
+
 extern "C" int gnm_node_proj_bwd_tn(int64_t N, int H, int ncols, const float* gP, const float* h_in, float* gW, float* gb,
                                     double* partials, void* ws, size_t ws_bytes, int max_blocks_per_cu, void* stream) {
   GNM_CHECK_ARG(H == FH, "node_proj_bwd_tn: H=%d (only 128 is built)", H);
@@ -2463,5 +2703,32 @@ extern "C" int gnm_tn128(int64_t M, const float* A, int64_t lda, int ncg, const 
                 "tn128: bad argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128: workspace too small");
   return tn_colgroups(M, A, lda, ncg, B, out, colsum, partials, (float*)ws, stream);
-  return 0;
+}
+
+// gnm_tn128 over the column groups gB1h | gB2h of gP (ncg = 2: out = gW5[3H:5H], colsum = gb5[3H:5H]) with gnm_node_bgrad in
+// its operand load: the groups are formed from the raw sums UT = [Us | Ts] (pitch 2H), Ud, Td (pitch ud_pitch = H or 2H) and
+// the BatchNorm_e backward means, and WRITTEN to gP[:, 3H:5H] (row pitch 5H) for gnm_node_proj_bwd_nn*, which runs behind
+// this call.  B: the layer's h_in [M,128] (fp32), or Bs: its pre-split image (exactly one of the two).  bf16x3 mode, H = 128.
+extern "C" int gnm_tn128_bgrad(int64_t M, int H, const float* UT, const float* Ud, const float* Td, int64_t ud_pitch,
+                               const float* stat_e, const float* bstat_e, const float* gamma_e, const int32_t* in_ptr,
+                               const int32_t* out_ptr, float* gP, const float* B, const void* Bs, float* out, float* colsum,
+                               double* partials, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "tn128_bgrad: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(g_matmul_mode == 1, "tn128_bgrad: bf16x3 matmul mode only");
+  GNM_CHECK_ARG(M > 0 && UT && Ud && Td && (ud_pitch == H || ud_pitch == 2 * H) && stat_e && bstat_e && gamma_e && in_ptr &&
+                    out_ptr && gP && (!B != !Bs) && out && colsum && partials, "tn128_bgrad: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128_bgrad: workspace too small");
+  const TnConv cv{{UT, Ud}, {UT + H, Td}, {(int64_t)2 * H, ud_pitch}, {out_ptr, in_ptr}, stat_e, bstat_e, gamma_e,
+                  gP + 3 * H, (int64_t)5 * H};
+  return tn_colgroups(M, nullptr, 0, 2, B, out, colsum, partials, (float*)ws, stream, 0, Bs, &cv);
+}
+
+// the same with B as the pre-split image of the [M,128] tensor (gnm_split_rows_s3 / gnm_node_update_fwd_s3): bf16x3 mode only
+extern "C" int gnm_tn128_s3(int64_t M, const float* A, int64_t lda, int ncg, const void* Bs, float* out, float* colsum,
+                            double* partials, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(g_matmul_mode == 1, "tn128_s3: the pre-split image belongs to the bf16x3 matmul mode");
+  GNM_CHECK_ARG(M > 0 && A && Bs && out && colsum && partials && ncg > 0 && lda >= (int64_t)ncg * FH && ncg <= 16,
+                "tn128_s3: bad argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128_s3: workspace too small");
+  return tn_colgroups(M, A, lda, ncg, nullptr, out, colsum, partials, (float*)ws, stream, 0, Bs);
 }

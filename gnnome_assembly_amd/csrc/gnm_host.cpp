@@ -263,6 +263,17 @@ extern "C" int gnm_graph_build_sweep_plan(const int32_t* isrc, const int32_t* id
   int peak = 0;
   const int64_t nblk = (N + nodes_per_block - 1) / nodes_per_block;
   std::vector<int> free_slots, pending;
+  // The sweep kernels address a workgroup's rows through 32-bit buffer offsets (row index x up to 1024 bytes for a
+  // 256-wide layer): a hub-heavy graph whose node partition gives one workgroup more rows than that cannot be swept --
+  // report it (return code 3, nothing written) and the caller keeps the separate by-source passes.
+  for (int64_t w = 0; w < nblk; ++w) {
+    const int64_t v0 = w * nodes_per_block, v1 = std::min<int64_t>(N, v0 + nodes_per_block);
+    if (((int64_t)in_ptr[v1] - in_ptr[v0] + 64) * 1024 >= (int64_t)INT32_MAX) {
+      gnm::set_error("graph_build_sweep_plan: workgroup %lld of the node partition owns %lld rows: beyond the sweep kernels' 32-bit "
+                     "row offsets (the graph runs the separate by-source passes)", (long long)w, (long long)(in_ptr[v1] - in_ptr[v0]));
+      return 3;
+    }
+  }
   for (int64_t w = 0; w < nblk; ++w) {
     const int64_t v0 = w * nodes_per_block, v1 = std::min<int64_t>(N, v0 + nodes_per_block);
     const int64_t rb = in_ptr[v0], re = in_ptr[v1];

@@ -23,6 +23,15 @@ __global__ void plan_first_last_k(int64_t E, const int32_t* __restrict__ isrc, i
 constexpr int PW = 4;             // waves (= sweep workgroups planned) per workgroup of this kernel
 constexpr int PSL = 64;           // slot capacity of the LDS structures (nslots <= 64 as on the host)
 
+// The allocator state (stk / tab / pend / res) lives in LDS and is written by lane 0 and read by every lane of the SAME wave.  The
+// lanes of a wave run in lock step, so this needs no hardware barrier -- but the compiler must not move such a read above the write
+// it depends on: a wavefront-scope release / acquire pair around a wave barrier pins the order.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(64 * PW) void plan_build_k(
     int64_t N, const int32_t* __restrict__ isrc, const int32_t* __restrict__ idst, const int32_t* __restrict__ in_ptr,
     const int32_t* __restrict__ first, const int32_t* __restrict__ last, int64_t nodes_per_block, int nslots, int64_t margin,
@@ -46,6 +55,7 @@ __global__ __launch_bounds__(64 * PW) void plan_build_k(
     stk[lane] = nslots - 1 - lane;     // the host pushes nslots-1 .. 0: the first pop is slot 0
     tab[lane] = -1;
   }
+  wave_lds_sync();
   int nfree = nslots, npend = 0, live = 0, peak = 0, dslot = 0;      // wave-uniform state
   constexpr uint32_t kOpen = kSweepOpen, kClose = kSweepClose;
   // software pipeline (a tile's work is a chain of three dependent global loads otherwise: rows -> first / last / in_ptr):
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(64 * PW) void plan_build_k(
     nfree += npend;
     live -= npend;
     npend = 0;
+    wave_lds_sync();
     uint32_t ms = 0, md = 0;                                     // rows of the tile with my source / my destination
 #pragma unroll
     for (int q = 0; q < kSweepTileRows; ++q) {
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(64 * PW) void plan_build_k(
     const bool closes = lead_s && l < r0 + nv;
     const bool inside = opens && f >= rb && l < re && s >= v0 - margin && s < v1 + margin;
     if (lane < kSweepTileRows) res[lane] = -1;
+    wave_lds_sync();
     unsigned long long todo = __ballot(lead_s);
     while (todo) {                                               // the tile's leaders in row order (wave-uniform loop)
       const int r = __ffsll((long long)todo) - 1;
@@ -124,6 +136,7 @@ __global__ __launch_bounds__(64 * PW) void plan_build_k(
         ++npend;
       }
       if (lane == 0) res[r] = slot;
+      wave_lds_sync();                                           // tab / pend / res as lane 0 left them, before the next leader looks
     }
     if (lead_s) {
       const int sl = res[lane];

@@ -158,6 +158,13 @@ struct ChainArgs {
   int hfull;       // row pitch of the layer-(i-1) tensors (0 / 128: 128; 256: the top sweep of a 256-wide layer, one half per launch)
 };
 
+// tn_tr_k<., CONV> (gnm_tr.hip): the two column groups of the A operand are formed from raw sums
+struct TnConv {
+  const float* U[2]; const float* T[2]; int64_t pitch[2]; const int32_t* ptr[2];     // per column group: sums, pitches, CSR pointers
+  const float* stat_e; const float* bstat_e; const float* gamma_e;
+  float* Xw; int64_t ldxw;                                                            // the formed groups go to Xw[r][cg*128 + c]
+};
+
 constexpr int kSweepTileRows = 16;      // rows per tile of the sweep kernels (= ER of gnm_tr.hip)
 constexpr int kSweepSlots = 32;         // accumulator slots per workgroup (<= 28 are ever live on the chr19-scale graph)
 constexpr int64_t kSweepMargin = 1 << 16;   // a served source lies within this many ids of its workgroup's node range

@@ -16,10 +16,23 @@ constexpr int TRIMG = TRR * SPITCH;         // bytes per image (8 KB)
 // 32-row tiles, 48 KB of LDS, coalesced float4 loads one tile ahead; each of the 4 waves owns a 64 x 64 block of
 // the 128 x 128 result (64 accumulator registers).  Two or three workgroups share a CU, so one's split / staging
 // VALU work and HBM waits run under the others' MFMAs.
-__global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __restrict__ A, int64_t lda, int ncg,
-                                                     const float* __restrict__ B, int64_t ldb, int ncgb,
+// BS3 (round 5): B is the pre-split image of a [M,128] tensor (768 bytes per row: gnm_split_rows_s3 / gnm_node_update_fwd_s3;
+// ncgb = 1) -- the ncg workgroup classes of a slot no longer split the same B tile ncg times, they copy it (six 16-byte
+// pieces per thread into the swizzled images); same parts, same MFMA order: bit-identical results.
+// CONV (round 5): the A operand does not exist yet -- the two column groups of this launch are gB1h, gB2h, which the chained
+// edge kernel left as RAW sums (Us | Ts by source, Ud | Td by destination); with the BatchNorm_e backward means m1, m2
+//     gB1h = c (Us - outdeg m1 - m2 Ts),   gB2h = c (Ud - indeg m1 - m2 Td),   c = gamma_e rstd_e      (node_bgrad_k)
+// A tile is FORMED from the sums on its way into the images (two rows of loads per operand row) and written once to
+// gP[:, 3H:5H] for the kernel that multiplies gP by W5 right behind this one: the elementwise launch in between (6 [N,H]
+// streams, 0.87 ms per layer) is gone.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool BS3, bool CONV, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* __restrict__ A, int64_t lda, int ncg,
+                                                     const void* __restrict__ Bv, int64_t ldb, int ncgb,
                                                      float* __restrict__ slab, double* __restrict__ partials, int nslot,
-                                                     int64_t tiles_per_slot) {
+                                                     int64_t tiles_per_slot, const TnConv cv) {
+  const float* __restrict__ B = reinterpret_cast<const float*>(Bv);
+  const __bf16* __restrict__ Bs = reinterpret_cast<const __bf16*>(Bv);
   __shared__ __attribute__((aligned(16))) unsigned char lds[6 * TRIMG];
   unsigned char* ia = lds;
   unsigned char* ib = lds + 3 * TRIMG;
@@ -47,15 +60,44 @@ __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;     // column sums of A for columns lc4 .. lc4+3
-  float4 pa[4], pb[4];
+  float4 pa[4], pb[BS3 ? 1 : 4];
+  u32x4_t ps[BS3 ? 6 : 1];
+  float4 pt[CONV ? 4 : 1];                        // CONV: the T rows and the CSR pointers the degrees come from
+  int dg[CONV ? 4 : 1][2];
+  float4 cc = f4(0.f), m1 = f4(0.f), m2 = f4(0.f);
+  if constexpr (CONV) {
+    cc = ld4(cv.gamma_e + lc4) * ld4(cv.stat_e + SW + lc4);
+    m1 = ld4(cv.bstat_e + lc4);
+    m2 = ld4(cv.bstat_e + SW + lc4);
+  }
+  const float* const Ucg = CONV ? cv.U[cg] : nullptr;
+  const float* const Tcg = CONV ? cv.T[cg] : nullptr;
+  const int64_t pcg = CONV ? cv.pitch[cg] : 0;
+  const int32_t* const dptr = CONV ? cv.ptr[cg] : nullptr;
+  const int r16 = tid >> 4, s16 = tid & 15;       // BS3: piece j = row 16 (j / 3) + r16, part j % 3, 16-byte slot s16
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * TRR;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       int64_t r = r0 + lrow + 8 * it;
       r = r < Mlast ? r : Mlast;
-      pa[it] = ld4_nt(A + r * lda + cg * SW + lc4);
-      pb[it] = ld4(B + r * ldb + cgb * SW + lc4);        // shared by the workgroups of the slot through L2
+      if constexpr (CONV) {
+        pa[it] = ld4_nt(Ucg + r * pcg + lc4);
+        pt[it] = ld4_nt(Tcg + r * pcg + lc4);
+        dg[it][0] = dptr[r];
+        dg[it][1] = dptr[r + 1];
+      } else {
+        pa[it] = ld4_nt(A + r * lda + cg * SW + lc4);
+      }
+      if constexpr (!BS3) pb[it] = ld4(B + r * ldb + cgb * SW + lc4);        // shared by the workgroups of the slot through L2
+    }
+    if constexpr (BS3) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        int64_t r = r0 + 16 * (j / 3) + r16;
+        r = r < Mlast ? r : Mlast;
+        ps[j] = *reinterpret_cast<const u32x4_t*>(Bs + r * (3 * SW) + (j % 3) * SW + s16 * 8);
+      }
     }
   };
   if (tb0 < tb1) prefetch(tb0);
@@ -64,10 +106,24 @@ __global__ __launch_bounds__(kBlock, 2) void tn_tr_k(int64_t M, const float* __r
     __syncthreads();                          // the previous tile's fragment reads are done
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
+      if constexpr (CONV) {
+        const float deg = (float)(dg[it][1] - dg[it][0]);
+        pa[it] = cc * (pa[it] - m1 * deg - m2 * pt[it]);                      // node_bgrad_k's expression
+        int64_t r = r0 + lrow + 8 * it;                                      // rows past the end were loaded from the last row:
+        r = r < Mlast ? r : Mlast;                                           // they rewrite its value
+        st4(cv.Xw + r * cv.ldxw + cg * SW + lc4, pa[it]);
+      }
       if (r0 + lrow + 8 * it >= M) pa[it] = f4(0.f);      // rows past the end contribute nothing
       c0 += (double)pa[it].x; c1 += (double)pa[it].y; c2 += (double)pa[it].z; c3 += (double)pa[it].w;
       simg_stage(ia, TRIMG, lrow + 8 * it, lc4, pa[it]);
-      simg_stage(ib, TRIMG, lrow + 8 * it, lc4, pb[it]);
+      if constexpr (!BS3) simg_stage(ib, TRIMG, lrow + 8 * it, lc4, pb[it]);
+    }
+    if constexpr (BS3) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int r = 16 * (j / 3) + r16;
+        *reinterpret_cast<u32x4_t*>(ib + (j % 3) * TRIMG + r * SPITCH + ((s16 ^ swz(r)) << 4)) = ps[j];
+      }
     }
     __syncthreads();
     prefetch(tile + 1);                       // in flight under the MFMAs
@@ -923,11 +979,32 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
 }
 
 int tn_tr_rows_per_tile() { return TRR; }
-int tn_tr_occupancy() { return occ_blocks<tn_tr_k>(); }
-void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const float* B, int64_t ldb, int ncgb, float* slab,
-                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st) {
-  hipLaunchKernelGGL(tn_tr_k, dim3(nslot * ncg * ncgb), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, ncgb, slab, partials,
-                     nslot, tiles_per_slot);
+// s3: the pre-split-B variant; built for two (208 registers) and for three (168, 14 spilled) workgroups per CU, A/B by GNM_VARIANTS
+int tn_s3_occ_variant();   // gnm_fused.hip
+int tn_tr_occupancy(bool s3, bool conv) {
+  if (conv) return s3 ? occ_blocks<tn_tr_k<true, true, 2>>() : occ_blocks<tn_tr_k<false, true, 2>>();
+  if (!s3) return occ_blocks<tn_tr_k<false, false, 2>>();
+  return tn_s3_occ_variant() == 3 ? occ_blocks<tn_tr_k<true, false, 3>>() : occ_blocks<tn_tr_k<true, false, 2>>();
+}
+// ldb < 0: B is the pre-split image (ncgb = 1);  cv: the A operand is formed from raw sums (ncg = 2, ncgb = 1)
+void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B, int64_t ldb, int ncgb, float* slab,
+                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv) {
+  const TnConv none{};
+  if (cv && ldb < 0)
+    hipLaunchKernelGGL((tn_tr_k<true, true, 2>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, (int64_t)0, 1, slab,
+                       partials, nslot, tiles_per_slot, *cv);
+  else if (cv)
+    hipLaunchKernelGGL((tn_tr_k<false, true, 2>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, 1, slab,
+                       partials, nslot, tiles_per_slot, *cv);
+  else if (ldb < 0 && tn_s3_occ_variant() == 3)
+    hipLaunchKernelGGL((tn_tr_k<true, false, 3>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, (int64_t)0, 1, slab,
+                       partials, nslot, tiles_per_slot, none);
+  else if (ldb < 0)
+    hipLaunchKernelGGL((tn_tr_k<true, false, 2>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, (int64_t)0, 1, slab,
+                       partials, nslot, tiles_per_slot, none);
+  else
+    hipLaunchKernelGGL((tn_tr_k<false, false, 2>), dim3(nslot * ncg * ncgb), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, ncgb,
+                       slab, partials, nslot, tiles_per_slot, none);
 }
 
 }  // namespace gnm

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import collections
 import os
 import time
 
@@ -265,7 +266,8 @@ class AssemblyGraph:
             with torch.cuda.device(device):
                 _lib.check(lib.gnm_sweep_partition(n, wg_per_cu, C.byref(npb), C.byref(grid)), "gnm_sweep_partition")
             plan = build_sweep_plan(h, n, npb.value)
-            plan = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
+            if plan is not None:
+                plan = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
         elif self.num_edges() > 0 and device.type == "cuda" and DEVICE_PLANS:
             plan = build_sweep_plan_device(self.index(device), self._n, device, wg_per_cu)
         self._plans[key] = plan
@@ -284,9 +286,12 @@ def build_sweep_plan(host_index, n: int, nodes_per_block: int, nslots: int = SWE
     sinfo, dinfo = np.zeros(e, np.uint32), np.zeros(e, np.uint32)
     fix = np.empty(max(n, 1), np.int32)
     nfix, peak = C.c_int64(0), C.c_int(0)
-    _lib.check(lib.gnm_graph_build_sweep_plan(ptr(host_index["isrc"]), ptr(host_index["idst"]), ptr(host_index["in_ptr"]), n, e,
-                                              int(nodes_per_block), SWEEP_TILE_ROWS, nslots, margin, ptr(sinfo), ptr(dinfo),
-                                              ptr(fix), C.byref(nfix), C.byref(peak)), "gnm_graph_build_sweep_plan")
+    rc = lib.gnm_graph_build_sweep_plan(ptr(host_index["isrc"]), ptr(host_index["idst"]), ptr(host_index["in_ptr"]), n, e,
+                                        int(nodes_per_block), SWEEP_TILE_ROWS, nslots, margin, ptr(sinfo), ptr(dinfo),
+                                        ptr(fix), C.byref(nfix), C.byref(peak))
+    if rc == 3:         # one workgroup's rows exceed the sweep kernels' 32-bit offsets (a hub-heavy graph): no plan, separate passes
+        return None
+    _lib.check(rc, "gnm_graph_build_sweep_plan")
     return {"sinfo": sinfo.view(np.int32), "dinfo": dinfo.view(np.int32), "fix_nodes": fix[:nfix.value].copy(),
             "nodes_per_block": int(nodes_per_block), "nfix": int(nfix.value), "peak_live": int(peak.value)}
 
@@ -306,6 +311,13 @@ def build_sweep_plan_device(idx, n: int, device, wg_per_cu: int, nslots: int = S
     npb, grid = C.c_int64(0), C.c_int(0)
     with torch.cuda.device(device):
         _lib.check(lib.gnm_sweep_partition(n, wg_per_cu, C.byref(npb), C.byref(grid)), "gnm_sweep_partition")
+        if (e + 64) * 1024 >= 2 ** 31:
+            # more rows than ANY workgroup could address through the sweep kernels' 32-bit row offsets if it owned them all: look at
+            # the real shares (one synchronisation; the mini-batch sub-graphs this path exists for are far below the bound)
+            b = torch.arange(0, n + npb.value, npb.value, device=device).clamp_(max=n)
+            rows = idx["in_ptr"].long()[b]
+            if int((rows[1:] - rows[:-1]).max()) + 64 >= 2 ** 21:
+                return None
         sinfo, dinfo = torch.empty(e, **i32), torch.empty(e, **i32)
         served = torch.empty(n, dtype=torch.uint8, device=device)
         fix = torch.empty(n, **i32)
@@ -340,35 +352,70 @@ def from_dgl(g):
     return ag.to(dev) if dev is not None and torch.device(dev).type != "cpu" else ag
 
 
-_WRAPPED = {}      # id(foreign graph) -> AssemblyGraph, for graph objects that refuse new attributes
+_WRAPPED = {}      # id(foreign graph) -> AssemblyGraph, for graph objects that refuse new attributes (dropped by a weakref finalizer)
+# Wrappers by CONTENT.  The reference's loops call g = g.to(device) on every step (train.py:244,297; inference.py:446), and DGL
+# returns a NEW graph object each time: a cache on the object alone would rebuild the host index, the locality order and both
+# sweep plans (~1.5 s for a chr19-scale graph) per step.  A foreign graph is therefore also looked up by a fingerprint of its edge
+# list (node / edge counts + two position-weighted 64-bit sums over src and dst: three tiny reductions and one synchronisation);
+# the last GNM_GRAPH_CACHE (default 16) wrappers are kept -- a dataset's graphs, each ~45 bytes per edge of device memory.
+_BY_CONTENT = collections.OrderedDict()
+GRAPH_CACHE = int(os.environ.get("GNM_GRAPH_CACHE", "16"))
+
+
+def _fingerprint(g):
+    s, d = g.edges()
+    if not (torch.is_tensor(s) and torch.is_tensor(d)):
+        s, d = torch.as_tensor(np.asarray(s)), torch.as_tensor(np.asarray(d))
+    w = torch.arange(1, 2 * s.numel() + 1, 2, dtype=torch.int64, device=s.device)       # odd weights: order-sensitive
+    h = torch.stack(((s.long() * w).sum(), (d.long() * w).sum()))
+    return (int(g.num_nodes()), int(s.numel())) + tuple(int(x) for x in h.cpu())
 
 
 def as_assembly_graph(g, device=None):
     """What the modules call on their `graph` argument: an AssemblyGraph is returned as it is; any other object with the
-    DGLGraph surface (edges(), num_nodes()) is wrapped ONCE (from_dgl: the index is built then) and the wrapper is cached
-    on the object, so the reference's call sites -- model(g, x, e, pe) with a DGLGraph, train.py:252 -- need only the import
-    change.  `device`: where the features of this call live (a foreign graph may not carry a device)."""
+    DGLGraph surface (edges(), num_nodes()) is wrapped (from_dgl: the index is built then) and the wrapper is cached -- on the
+    object, and by the content of its edge list (see _BY_CONTENT: the reference's per-step g.to(device) makes a new object every
+    time) -- so the reference's call sites -- model(g, x, e, pe) with a DGLGraph, train.py:252 -- need only the import change.
+    `device`: where the features of this call live (a foreign graph may not carry a device)."""
     if isinstance(g, AssemblyGraph):
         return g
     ag = getattr(g, "_gnm_graph", None) or _WRAPPED.get(id(g))
-    if ag is None or ag.num_edges() != int(g.num_edges()) or ag.num_nodes() != int(g.num_nodes()):
+    if ag is not None and (ag.num_edges() != int(g.num_edges()) or ag.num_nodes() != int(g.num_nodes())):
+        ag = None                   # the object changed under the cached wrapper
+    if ag is None:
         if not (hasattr(g, "edges") and hasattr(g, "num_nodes")):
             raise TypeError(f"graph argument of type {type(g).__name__} has no edges() / num_nodes()")
-        ag = from_dgl(g)
-        try:
-            g._gnm_graph = ag
-        except AttributeError:
-            import weakref
-            _WRAPPED[id(g)] = ag
-            try:
-                weakref.finalize(g, _WRAPPED.pop, id(g), None)
-            except TypeError:
-                pass
+        key = _fingerprint(g) if GRAPH_CACHE > 0 else None
+        ag = _BY_CONTENT.get(key) if key is not None else None
+        if ag is None:
+            ag = from_dgl(g)
+            if key is not None:
+                _BY_CONTENT[key] = ag
+                while len(_BY_CONTENT) > GRAPH_CACHE:
+                    _BY_CONTENT.popitem(last=False)
+        else:
+            _BY_CONTENT.move_to_end(key)
+            # same structure, possibly other feature tensors: the wrapper shows the caller's current ndata / edata
+            ag.ndata = dict(getattr(g, "ndata", {}))
+            ag.edata = dict(getattr(g, "edata", {}))
+        _remember(g, ag)
     if device is not None and torch.device(device) != ag.device:
-        moved = ag.to(device)
-        try:
-            g._gnm_graph = moved
-        except AttributeError:
-            _WRAPPED[id(g)] = moved
-        return moved
+        ag = ag.to(device)
+        _remember(g, ag)
     return ag
+
+
+def _remember(g, ag):
+    """Cache the wrapper on the foreign object; objects that refuse attributes are tracked by id only while a weakref finalizer can
+    remove the entry again (an id is reused after the object dies) -- otherwise not at all: the content cache still finds them."""
+    try:
+        g._gnm_graph = ag
+        return
+    except AttributeError:
+        pass
+    import weakref
+    try:
+        weakref.finalize(g, _WRAPPED.pop, id(g), None)
+        _WRAPPED[id(g)] = ag
+    except TypeError:
+        _WRAPPED.pop(id(g), None)

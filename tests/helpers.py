@@ -86,15 +86,27 @@ def device_masks(ms, sd, e_raw_np, idx):
 def branch_exact_rows(src, dst, n, e_raw, pe, y, pw, sd, L, dev):
     """rows (name, rel_l2, max_abs, ref_norm) of the HIP gradients against the fp64 oracle backward evaluated
     on the SAME relu branches the device took, and the largest reference gradient norm."""
-    from gnnome_assembly_amd import AssemblyGraph, engine
+    from gnnome_assembly_amd import AssemblyGraph, engine, layers, models
     from oracle import gatedgcn_oracle as orc
     g = AssemblyGraph(src, dst, n).to(dev)
     P = {k: v.to(dev) for k, v in sd_to_torch(sd).items()}
+    H = P["linear_pe.weight"].shape[0]
+    Hp = layers.padded_width(H)
+    if Hp != H:         # a width between the kernel instantiations: dead channels, exactly as GraphGatedGCNModel.forward pads
+        P = {k: models._pad_param(k, v, H, Hp).contiguous() for k, v in P.items()}
     scores, ms = engine.model_forward(g, torch.from_numpy(e_raw).to(dev), torch.from_numpy(pe).to(dev), P, L, True)
     masks = device_masks(ms, sd, e_raw, g.index())
     loss, gs = engine.bce_with_logits(scores, torch.from_numpy(y).to(dev), pw)
     Gd = engine.model_backward(g, P, L, ms, gs)
     torch.cuda.synchronize()
+    if Hp != H:
+        masks["u"] = [m[:, :H] for m in masks["u"]]
+        masks["w"] = [m[:, :H] for m in masks["w"]]
+        for k, v in sd.items():
+            if k == "predictor.W1.weight":
+                Gd[k] = Gd[k].reshape(v.shape[0], 3, Hp)[:, :, :H].reshape(v.shape[0], 3 * H)
+            else:
+                Gd[k] = Gd[k][tuple(slice(0, d) for d in v.shape)]
     with torch.no_grad():
         _, l64, g64 = orc.manual_forward_backward(sd_to_torch(sd, torch.float64), torch.from_numpy(src), torch.from_numpy(dst),
                                                   n, torch.from_numpy(e_raw).double(), torch.from_numpy(pe).double(),

@@ -33,22 +33,36 @@ def matmul_mode(request):
 
 GRAD_L2 = 2e-4          # norm-relative bar for one parameter-gradient tensor (fp32 vs fp64 oracle)
 GRAD_ABS_FLOOR = 2e-7   # gradients that are analytically zero (biases in front of a BatchNorm)
-# Gradients that pass through BatchNorm_e backward (B_1/B_2/B_3, bn_e) are differences of
-# large sums and flip with single relu-boundary elements: the reference's OWN fp32 arithmetic
-# (the oracle run in fp32) differs from fp64 by up to ~1e-3 norm-relative on them.  A tensor
-# therefore passes if it is within GRAD_L2 of the fp64 oracle OR no further from it than
-# NOISE_X times the fp32 oracle is.
+# Gradients that pass through BatchNorm_e backward (B_1/B_2/B_3, bn_e) are differences of large sums and flip with single
+# relu-boundary elements: the reference's OWN fp32 arithmetic (the oracle run in fp32) differs from fp64 by up to ~1e-3
+# norm-relative on them.  Rounds 1-4 let such a tensor pass when it was no further from the fp64 oracle than NOISE_X times the
+# fp32 oracle is -- a bar that moves with the fixture and bounded nothing.  Since round 5 a BatchNorm model has NO
+# noise clause: a tensor outside GRAD_L2 must be EXACT (rel-L2 <= BRANCH_L2 = 5e-5) against the fp64 backward evaluated on the
+# relu branches the device took -- the network is piecewise linear in those branches, so that comparison has no kink
+# ambiguity and no fixture-dependent slack.  The noise clause survives only where there is no branch-exact oracle (LayerNorm
+# models: none of their tensors has ever needed it).
 NOISE_X = 3.0
 
 
-def _grad_ok(r_ours, r_ref32, max_abs, floor):
-    """Which clause lets this tensor pass is tallied per test (helpers.GRAD_CLAUSES -> gpurun_out/grad_clauses.json,
-    committed as profiles/r03_grad_clauses.txt); tests/test_zz_grad_clause_budget.py fails the suite when a test
-    takes more escapes (anything but the plain rel-L2 bar) than the committed baseline."""
-    clause = ("l2" if r_ours <= GRAD_L2 else "noise" if r_ours <= NOISE_X * r_ref32 + 1e-6 else
+def _grad_ok(r_ours, max_abs, floor, r_ref32=None):
+    """Which clause decides this tensor is tallied per test (helpers.GRAD_CLAUSES -> gpurun_out/grad_clauses.json, committed
+    under profiles/); "miss" tensors of a BatchNorm model go on to the branch-exact comparison (their caller moves them to
+    "branch_exact" or fails).  tests/test_zz_grad_clause_budget.py fails the suite when a test takes more "noise" / "floor"
+    escapes than the committed baseline.  r_ref32 (LayerNorm models only): the fp32 oracle's own distance from the fp64 one."""
+    clause = ("l2" if r_ours <= GRAD_L2 else
+              "noise" if (r_ref32 is not None and r_ours <= NOISE_X * r_ref32 + 1e-6) else
               "floor" if max_abs <= floor else "miss")
     tally_clause(clause)
     return clause != "miss"
+
+
+def _branch_exact_or_fail(bad, exact, bgmax, what):
+    """bad: rows (name, ...) that missed the plain bars; exact: name -> (name, rel_l2, max_abs, ref_norm) against the fp64
+    backward on the device's branches.  Every one of them must be exact; tallied as "branch_exact"."""
+    still = [b for b in bad if exact[b[0]][1] > BRANCH_L2 and exact[b[0]][2] > max(GRAD_ABS_FLOOR, 1e-6 * bgmax)]
+    tally_clause("branch_exact", len(bad) - len(still), forgiven=True)
+    assert not still, (f"{what}: gradient tensors outside rel-L2 {GRAD_L2:g} of the fp64 oracle AND not exact ({BRANCH_L2:g}) for the "
+                       f"relu branches the device took: {[(b, exact[b[0]]) for b in still]}")
 
 
 def _oracle_grads(z, sd, dtype, batch_norm=True):
@@ -210,17 +224,38 @@ def test_layer_kernels_vs_oracle(fname):
     _cmp("g gamma_h", g["gamma_h"], g64[pfx + "bn_h.weight"], rows)
     _cmp("g beta_h", g["beta_h"], g64[pfx + "bn_h.bias"], rows)
     _report(rows, f"layer_{fname}.txt")
-    # fp32 noise of the reference arithmetic on the same quantities (oracle run in fp32)
-    with torch.no_grad():
-        _, _, g32, dbg32 = orc.manual_forward_backward(
-            sd_to_torch(sd, torch.float32), torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(z["e_raw"]),
-            torch.from_numpy(z["pe"]), torch.from_numpy(z["y"]), float(z["pos_weight"]), keep=True)
-    noise = max(rel_l2(g32[pfx + "B_3.weight"].numpy(), g64[pfx + "B_3.weight"].numpy()),
-                rel_l2(dbg32[li]["ge_in"].numpy(), d["ge_in"].numpy()),
-                rel_l2(dbg32[li]["gh_in"].numpy(), d["gh_in"].numpy()))
-    print(f"reference-fp32 noise on this layer's backward: {noise:.3e}")
-    bad = [r for r in rows[:nfwd] if r[1] > 2e-5] + [r for r in rows[nfwd:] if not _grad_ok(r[1], noise, r[2], 0.0)]
-    assert not bad, f"mismatches: {bad}"
+    bad = [r for r in rows[:nfwd] if r[1] > 2e-5]
+    assert not bad, f"forward mismatches: {bad}"
+    miss = [r for r in rows[nfwd:] if not _grad_ok(r[1], r[2], 0.0)]
+    if miss:
+        # outside the plain bar: the same comparison against the fp64 backward evaluated on the relu branches THIS layer took
+        # on the device (the other layers, the predictor and the encoder keep the oracle's own branches: the layer's incoming
+        # gradients gh_out / ge_out come from above and do not depend on its branches)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        ud = ((s.t.double() * s.stat_e[2].double() + s.stat_e[3].double()) > 0).cpu()[inv]
+        wd = ((s.z.double() * s.stat_h[2].double() + s.stat_h[3].double()) > 0).cpu()
+        a1_pre = torch.from_numpy(z["e_raw"]).double() @ p64["linear1_edge.weight"].t() + p64["linear1_edge.bias"]
+        masks = {"u": [dbg[i]["u"] > 0 for i in range(L)], "w": [dbg[i]["w"] > 0 for i in range(L)], "hid": dbg["hid"] > 0,
+                 "a1": a1_pre > 0}
+        masks["u"][li], masks["w"][li] = ud, wd
+        with torch.no_grad():
+            _, _, gx, dx = orc.manual_forward_backward(
+                p64, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(z["e_raw"]).double(),
+                torch.from_numpy(z["pe"]).double(), torch.from_numpy(z["y"]).double(), float(z["pos_weight"]), keep=True, masks=masks)
+        assert torch.equal(dx[li]["gh_out"], d["gh_out"]) and torch.equal(dx[li]["ge_out"], d["ge_out"])
+        xrows = []
+        _cmp("gh_in", gh_in, dx[li]["gh_in"], xrows)
+        _cmp("ge_in", ge_in, dx[li]["ge_in"][perm], xrows)
+        _cmp("gW5", g["W5"], torch.cat([gx[pfx + k + ".weight"] for k in engine.LIN5], 0), xrows)
+        _cmp("gb5[A2,A3]", g["b5"][H:3 * H], torch.cat([gx[pfx + k + ".bias"] for k in engine.LIN5], 0)[H:3 * H], xrows)
+        _cmp("gW3", g["W3"], gx[pfx + "B_3.weight"], xrows)
+        _cmp("g gamma_e", g["gamma_e"], gx[pfx + "bn_e.weight"], xrows)
+        _cmp("g beta_e", g["beta_e"], gx[pfx + "bn_e.bias"], xrows)
+        _cmp("g gamma_h", g["gamma_h"], gx[pfx + "bn_h.weight"], xrows)
+        _cmp("g beta_h", g["beta_h"], gx[pfx + "bn_h.bias"], xrows)
+        _report(xrows, f"layer_branch_{fname}.txt")
+        _branch_exact_or_fail(miss, {r[0]: r for r in xrows}, max(r[3] for r in xrows), f"{fname} layer {li}")
     # biases that feed a BatchNorm directly have an analytically zero gradient
     zero_b = torch.cat([g["b5"][:H], g["b5"][3 * H:], g["b3"]]).abs().max().item()
     scale = float(gW5.abs().max())
@@ -267,27 +302,25 @@ def test_model_matches_golden(fname):
     print(f"{fname}: logits rel_l2 ours={ours:.2e} reference-fp32={ref_noise:.2e}")
     assert abs(loss.item() - float(z["loss64"])) <= 1e-5 * max(1.0, abs(float(z["loss64"])))
     stride = int(z["grad_stride"]) if H == 128 else 1
-    g32 = _oracle_grads(z, sd, torch.float32, bn)  # the reference arithmetic in fp32: noise level
+    g32 = None if bn else _oracle_grads(z, sd, torch.float32, bn)  # LayerNorm only: the reference arithmetic in fp32 (noise level)
     rows, bad = [], []
     gmax = max(float(np.linalg.norm(z["grad/" + k])) for k, _ in model.named_parameters())
     for k, prm in model.named_parameters():
         got = prm.grad.detach().cpu().double().numpy().reshape(-1)[::stride]
         want = z["grad/" + k]                      # reference fp64 (golden)
         _cmp(k, got, want, rows)
-        r32 = rel_l2(g32[k].reshape(-1)[::stride], want)
-        if not _grad_ok(rows[-1][1], r32, rows[-1][2], max(GRAD_ABS_FLOOR, 1e-6 * gmax)):
+        r32 = None if bn else rel_l2(g32[k].reshape(-1)[::stride], want)
+        if not _grad_ok(rows[-1][1], rows[-1][2], max(GRAD_ABS_FLOOR, 1e-6 * gmax), r32):
             bad.append(rows[-1] + (r32,))
     _report(rows, f"model_{fname}.txt")
     if bad and bn:
-        # A tensor outside the plain bars is accepted ONLY if the whole deviation is a relu decision that fell
-        # the other way in fp32 (every fp32 evaluation, the reference's own included, flips some): against
-        # the fp64 backward evaluated on the branches the device took it must agree to fp32 round-off.
+        # A tensor outside the plain bar passes ONLY if the whole deviation is a relu decision that fell the other way in
+        # fp32 (every fp32 evaluation, the reference's own included, flips some): against the fp64 backward evaluated on the
+        # branches the device took it must agree to fp32 round-off.  No noise clause (see GRAD_L2 above).
         brows, bgmax = _branch_exact_rows(z["src"], z["dst"], int(z["n"]), z["e_raw"], z["pe"], z["y"],
                                           float(z["pos_weight"]), sd, L, dev)
-        exact = {r[0]: r for r in brows}
-        nmiss = len(bad)
-        bad = [b for b in bad if exact[b[0]][1] > BRANCH_L2 and exact[b[0]][2] > max(GRAD_ABS_FLOOR, 1e-6 * bgmax)]
-        tally_clause("branch_exact", nmiss - len(bad), forgiven=True)
+        _branch_exact_or_fail(bad, {r[0]: r for r in brows}, bgmax, fname)
+        bad = []
     assert not bad, f"gradient mismatches (name, rel_l2, max_abs, ref_norm, reference-fp32 rel_l2): {bad}"
     # eval mode == train mode (BatchNorm has no running stats: gated_gcn_full.py:55-56)
     model.eval()
@@ -455,17 +488,22 @@ def test_odd_hidden_width_runs_zero_padded(bn):
     assert_parity(s.detach().cpu().numpy(), r.detach().numpy(), "H=96 logits")
     assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item()) + 1e-7
     p32 = sd_to_torch(sd, torch.float32, requires_grad=True)
-    orc.bce_loss(orc.model_forward(p32, ts, td, n, torch.from_numpy(inp["e"]), torch.from_numpy(inp["pe"]), bn),
-                 torch.from_numpy(inp["y"]), float(inp["pos_weight"])).backward()
+    if not bn:      # LayerNorm: the reference arithmetic in fp32 gives the noise level (there is no branch-exact oracle for it)
+        orc.bce_loss(orc.model_forward(p32, ts, td, n, torch.from_numpy(inp["e"]), torch.from_numpy(inp["pe"]), bn),
+                     torch.from_numpy(inp["y"]), float(inp["pos_weight"])).backward()
     gmax = max(float(v.grad.norm()) for v in p64.values())
     bad = []
     for k, prm in model.named_parameters():
         assert prm.grad.shape == p64[k].grad.shape
         want = p64[k].grad.numpy()
         ro = rel_l2(prm.grad.cpu().numpy(), want)
-        rr = rel_l2(p32[k].grad.double().numpy(), want)
-        if not _grad_ok(ro, rr, float(np.abs(prm.grad.cpu().numpy() - want).max()), GRAD_ABS_FLOOR * max(gmax, 1.0)):
+        rr = None if bn else rel_l2(p32[k].grad.double().numpy(), want)
+        if not _grad_ok(ro, float(np.abs(prm.grad.cpu().numpy() - want).max()), GRAD_ABS_FLOOR * max(gmax, 1.0), rr):
             bad.append((k, ro, rr))
+    if bad and bn:
+        brows, bgmax = _branch_exact_rows(src, dst, n, inp["e"], inp["pe"], inp["y"], float(inp["pos_weight"]), sd, L, dev)
+        _branch_exact_or_fail(bad, {r[0]: r for r in brows}, bgmax, "H=96")
+        bad = []
     assert not bad, bad
     # the stand-alone layer at an odd width, residual on (in == out == 48 -> padded to 64)
     lay = G.layers.GatedGCN_1d(48, 48, bn).to(dev)
@@ -856,19 +894,17 @@ def test_other_widths_and_norms_vs_oracle(H, L, bn):
     l64.backward()
     assert_parity(s.detach().cpu().numpy(), s64.detach().numpy(), f"H={H} L={L} bn={bn} logits")
     assert abs(loss.item() - l64.item()) < 1e-5
-    g32 = _oracle_grads(z, sd, torch.float32, bn)
+    g32 = None if bn else _oracle_grads(z, sd, torch.float32, bn)
     bad = []
     for k, prm in model.named_parameters():
         got, want = prm.grad.detach().cpu().double().numpy(), p64[k].grad.numpy()
-        r, r32 = rel_l2(got, want), rel_l2(g32[k], want)
-        if not _grad_ok(r, r32, float(np.abs(got - want).max()), GRAD_ABS_FLOOR):
+        r, r32 = rel_l2(got, want), (None if bn else rel_l2(g32[k], want))
+        if not _grad_ok(r, float(np.abs(got - want).max()), GRAD_ABS_FLOOR, r32):
             bad.append((k, r, r32))
-    if bad and bn:      # BatchNorm: only relu-kink flips may explain a miss (see test_model_matches_golden)
+    if bad and bn:      # BatchNorm: only relu-kink flips may explain a miss (see test_model_matches_golden); no noise clause
         brows, bgmax = _branch_exact_rows(src, dst, n, inp["e"], inp["pe"], inp["y"], float(inp["pos_weight"]), sd, L, dev)
-        exact = {r[0]: r for r in brows}
-        nmiss = len(bad)
-        bad = [b for b in bad if exact[b[0]][1] > BRANCH_L2 and exact[b[0]][2] > max(GRAD_ABS_FLOOR, 1e-6 * bgmax)]
-        tally_clause("branch_exact", nmiss - len(bad), forgiven=True)
+        _branch_exact_or_fail(bad, {r[0]: r for r in brows}, bgmax, f"H={H} L={L}")
+        bad = []
     assert not bad, bad
 
 
@@ -1107,6 +1143,261 @@ def test_chained_backward_matches_the_layer_by_layer_backward():
         r = float((a - b).norm() / b.norm().clamp_min(1e-30))
         if r > 2e-5 and float((a - b).abs().max()) > 1e-6 * gmax:
             bad.append((k, r))
+    assert not bad, bad
+
+
+# -----------------------------------------------------------------------------------------
+# round 5: the node side (pre-split image of h, fused conversion / BatchNorm_h sums)
+# -----------------------------------------------------------------------------------------
+
+@pytest.mark.default_mode_only
+def test_presplit_image_kernels_are_bit_identical_to_the_fp32_operand_kernels():
+    """include/gnm.h "the pre-split image": gnm_node_update_fwd_s3 = gnm_node_update_fwd + the three-part bf16 image of
+    h_out; gnm_node_proj_fwd_s3 / gnm_tn128_s3 copy that image where the fp32-operand kernels split the same rows in
+    every workgroup class.  Same parts, same MFMA order: P, gW5, gb5 bit for bit; the image reassembles h exactly."""
+    import ctypes as C
+    from gnnome_assembly_amd import engine, _lib
+    dev = _dev()
+    lib = _lib.load()
+    H = 128
+    rng = np.random.default_rng(21)
+    for N in (70001, 4096, 37):          # ragged last tile, whole tiles, fewer rows than one tile
+        z = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dev)
+        h_prev = torch.from_numpy((rng.standard_normal((N, H)) * 3).astype(np.float32)).to(dev)
+        stat = torch.from_numpy(rng.standard_normal((4, H)).astype(np.float32)).to(dev)
+        W5 = torch.from_numpy((rng.standard_normal((5 * H, H)) / 11).astype(np.float32)).to(dev)
+        b5 = torch.from_numpy(rng.standard_normal(5 * H).astype(np.float32)).to(dev)
+        gP = torch.from_numpy((rng.standard_normal((N, 5 * H)) * 1e-3).astype(np.float32)).to(dev)
+        st = engine._stream()
+        h0 = torch.empty(N, H, device=dev)
+        h1 = torch.empty(N, H, device=dev)
+        hs = torch.empty(N * 768, dtype=torch.uint8, device=dev)
+        engine._call("gnm_node_update_fwd", N, H, engine._ptr(z), engine._ptr(stat), engine._ptr(h_prev), engine._ptr(h0), st)
+        engine._call("gnm_node_update_fwd_s3", N, H, engine._ptr(z), engine._ptr(stat), engine._ptr(h_prev), engine._ptr(h1),
+                     engine._ptr(hs), st)
+        assert torch.equal(h0, h1)
+        assert torch.equal(engine.split_rows_s3(h0), hs)
+        parts = hs.view(torch.bfloat16).reshape(N, 3, H).float()
+        assert torch.equal((parts[:, 0] + parts[:, 1]) + parts[:, 2], h0), "hi + mid + lo must give h back exactly"
+        need = lib.gnm_rowtile_workspace_bytes(5 * H)
+        ws = engine.scratch(dev).ws(max(need, lib.gnm_tn128_workspace_bytes()))
+        P0 = torch.empty(N, 5 * H, device=dev)
+        P1 = torch.empty(N, 5 * H, device=dev)
+        engine._call("gnm_node_proj_fwd", N, H, 5 * H, engine._ptr(h0), engine._ptr(W5), engine._ptr(b5), engine._ptr(P0),
+                     engine._ptr(ws), need, st)
+        engine._call("gnm_node_proj_fwd_s3", N, H, 5 * H, engine._ptr(hs), engine._ptr(W5), engine._ptr(b5), engine._ptr(P1),
+                     engine._ptr(ws), need, st)
+        assert torch.equal(P0, P1), f"N={N}: projections from the image differ"
+        ref = h0.double() @ W5.double().t() + b5.double()
+        assert float((P1.double() - ref).norm() / ref.norm()) < 2e-6
+        sc = engine.scratch(dev)
+        needt = lib.gnm_tn128_workspace_bytes()
+        for ncg in (5, 3, 2):
+            g0, c0 = torch.empty(ncg * H, H, device=dev), torch.empty(ncg * H, device=dev)
+            g1, c1 = torch.empty(ncg * H, H, device=dev), torch.empty(ncg * H, device=dev)
+            engine.tn128(N, gP, 5 * H, ncg, h0, None, g0, c0, sc.partials, ws, needt)
+            engine.tn128(N, gP, 5 * H, ncg, h0, hs, g1, c1, sc.partials, ws, needt)
+            assert torch.equal(g0, g1) and torch.equal(c0, c1), f"N={N} ncg={ncg}: weight gradient from the image differs"
+        for occ in (3, 2):          # the two builds of the pre-split weight-gradient kernel
+            assert lib.gnm_debug_set_variant(b"tn_s3_occ", occ) == 0
+            g2, c2 = torch.empty(5 * H, H, device=dev), torch.empty(5 * H, device=dev)
+            engine.tn128(N, gP, 5 * H, 5, h0, hs, g2, c2, sc.partials, ws, needt)
+            ref = gP.double().t() @ h0.double()
+            assert float((g2.double() - ref).norm() / ref.norm()) < 2e-6
+        torch.cuda.synchronize()
+
+
+@pytest.mark.default_mode_only
+def test_fused_node_backward_kernels_match_the_separate_launches():
+    """gnm_tn128_bgrad = gnm_node_bgrad + gnm_tn128 over gB1h | gB2h (the groups it forms are written to gP for the
+    projection backward); gnm_node_proj_bwd_nn_stats = gnm_node_proj_bwd_nn + gnm_node_bwd_stats of the layer below.
+    Same expressions: gP columns and gh_in bit for bit, weight gradients / BatchNorm sums to summation order."""
+    import ctypes as C
+    from gnnome_assembly_amd import engine, _lib
+    dev = _dev()
+    lib = _lib.load()
+    H = 128
+    rng = np.random.default_rng(22)
+    f = lambda *sh, s=1.0: torch.from_numpy((rng.standard_normal(sh) * s).astype(np.float32)).to(dev)      # noqa: E731
+    for N, pitch2 in ((50021, True), (4096, False)):
+        UT, DT = f(N, 2 * H), f(N, 2 * H)
+        Ud, Td = (DT[:, :H], DT[:, H:]) if pitch2 else (DT[:, :H].contiguous(), DT[:, H:].contiguous())
+        stat_e, bstat_e, gamma_e = f(4, H).abs() + 0.1, f(2, H, s=0.1), f(H).abs() + 0.5
+        deg = rng.integers(0, 9, size=(2, N))
+        in_ptr = torch.from_numpy(np.concatenate(([0], np.cumsum(deg[0]))).astype(np.int32)).to(dev)
+        out_ptr = torch.from_numpy(np.concatenate(([0], np.cumsum(deg[1]))).astype(np.int32)).to(dev)
+        h, W5, gh_out, z = f(N, H), f(5 * H, H, s=0.09), f(N, H, s=1e-3), f(N, H)
+        stat_h = f(4, H)
+        hs = engine.split_rows_s3(h)
+        gP0 = f(N, 5 * H, s=1e-3)
+        gP1 = gP0.clone()
+        gP1[:, 3 * H:] = float("nan")          # the fused kernel must write every element of the two groups
+        st = engine._stream()
+        sc = engine.scratch(dev)
+        needt, needp = lib.gnm_tn128_workspace_bytes(), lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
+        ws = sc.ws(max(needt, needp))
+        # separate launches
+        engine._call("gnm_node_bgrad", N, H, engine._ptr(stat_e), engine._ptr(bstat_e), engine._ptr(gamma_e), engine._ptr(in_ptr),
+                     engine._ptr(out_ptr), engine._ptr(UT), engine._ptr(Ud), engine._ptr(Td), Ud.stride(0), engine._ptr(gP0), st)
+        gW0, gb0 = torch.empty(2 * H, H, device=dev), torch.empty(2 * H, device=dev)
+        engine.tn128(N, gP0[:, 3 * H:], 5 * H, 2, h, None, gW0, gb0, sc.partials, ws, needt)
+        for use_hs in (False, True):
+            gW1, gb1 = torch.empty(2 * H, H, device=dev), torch.empty(2 * H, device=dev)
+            gP1[:, 3 * H:] = float("nan")
+            engine._call("gnm_tn128_bgrad", N, H, engine._ptr(UT), engine._ptr(Ud), engine._ptr(Td), Ud.stride(0),
+                         engine._ptr(stat_e), engine._ptr(bstat_e), engine._ptr(gamma_e), engine._ptr(in_ptr), engine._ptr(out_ptr),
+                         engine._ptr(gP1), C.c_void_p(0) if use_hs else engine._ptr(h), engine._ptr(hs) if use_hs else C.c_void_p(0),
+                         engine._ptr(gW1), engine._ptr(gb1), engine._ptr(sc.partials), engine._ptr(ws), needt, st)
+            assert bool(torch.isfinite(gP1).all())
+            d = (gP1[:, 3 * H:] - gP0[:, 3 * H:]).abs().max().item()
+            assert d <= 1e-6 * gP0[:, 3 * H:].abs().max().item(), f"formed gB1h | gB2h differ from gnm_node_bgrad: {d}"
+            assert float((gW1.double() - gW0.double()).norm() / gW0.double().norm()) < 1e-6
+            assert float((gb1.double() - gb0.double()).norm() / gb0.double().norm()) < 1e-6
+        # projection backward with the BatchNorm_h sums of the layer below
+        gh0, gh1 = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+        engine._call("gnm_node_proj_bwd_nn", N, H, 5 * H, engine._ptr(gP0), engine._ptr(W5), engine._ptr(gh_out), engine._ptr(gh0),
+                     engine._ptr(ws), needp, st)
+        nb0 = C.c_int(0)
+        engine._call("gnm_node_bwd_stats", N, H, engine._ptr(z), engine._ptr(stat_h), engine._ptr(gh0), engine._ptr(sc.partials),
+                     C.byref(nb0), st)
+        b0, gg0, gbt0 = engine.bn_bwd_finalize(sc.partials, nb0.value, N, H, dev)
+        nb1 = C.c_int(0)
+        engine._call("gnm_node_proj_bwd_nn_stats", N, H, 5 * H, engine._ptr(gP0), engine._ptr(W5), engine._ptr(gh_out),
+                     engine._ptr(gh1), engine._ptr(z), engine._ptr(stat_h), engine._ptr(sc.partials), C.byref(nb1),
+                     engine._ptr(ws), needp, st)
+        b1, gg1, gbt1 = engine.bn_bwd_finalize(sc.partials, nb1.value, N, H, dev)
+        assert torch.equal(gh0, gh1)
+        for a_, b_ in ((b0, b1), (gg0, gg1), (gbt0, gbt1)):
+            assert float((a_.double() - b_.double()).abs().max()) <= 1e-6 * float(a_.double().abs().max()) + 1e-12
+        torch.cuda.synchronize()
+
+
+@pytest.mark.default_mode_only
+@pytest.mark.parametrize("ids", ["sorted", "shuffled"])
+def test_round5_node_side_schedule_matches_the_round4_schedule(ids):
+    """engine.PRESPLIT (opt-in) + engine.NODE_FUSED (default) against the round-4 schedule (fp32 operands everywhere, gnm_node_bgrad and
+    gnm_node_bwd_stats as launches of their own): the forward is bit-identical (the image holds the same three parts the
+    kernels compute), every gradient agrees to summation order, two runs are bit-identical, and each switch alone as well.
+    Also under lean activations (no side stream: the same launches back to back) bit for bit."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    model, src, dst, n, inp = _model_and_inputs(40000, 128, 4, 9, dev)
+    pe_np, e_np = inp["pe"], inp["e"]
+    if ids == "shuffled":
+        p = np.random.default_rng(6).permutation(n).astype(np.int32)
+        src, dst = p[src], p[dst]
+        pe_s = np.empty_like(pe_np)
+        pe_s[p] = pe_np
+        pe_np = pe_s
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    e, pe, y = torch.from_numpy(e_np).to(dev), torch.from_numpy(pe_np).to(dev), torch.from_numpy(inp["y"]).to(dev)
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+
+    def run(**opts):
+        with engine.options(**opts):
+            model.zero_grad(set_to_none=True)
+            s = model(g, None, e, pe)
+            loss = crit(s.squeeze(-1), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
+    s0, l0, g0 = run(PRESPLIT=False, NODE_FUSED=False)
+    s1, l1, g1 = run(PRESPLIT=True)
+    s2, l2, g2 = run(PRESPLIT=True)
+    assert torch.equal(s0, s1) and l0 == l1, "the pre-split image must not change the forward"
+    assert all(torch.equal(g1[k], g2[k]) for k in g1), "not run-to-run deterministic"
+    gmax = max(float(v.abs().max()) for v in g0.values())
+
+    def close(ga, gb, what):
+        bad = []
+        for k in ga:
+            a, b = ga[k].double(), gb[k].double()
+            r = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            if r > 2e-6 and float((a - b).abs().max()) > 1e-7 * gmax:
+                bad.append((k, r))
+        assert not bad, (what, bad)
+    close(g1, g0, "round 5 vs round 4")
+    _, _, g3 = run(PRESPLIT=True, NODE_FUSED=False)
+    assert all(torch.equal(g3[k], g0[k]) for k in g0), "the pre-split image alone must be bit-identical"
+    _, _, g4 = run(PRESPLIT=False, NODE_FUSED=True)
+    close(g4, g0, "NODE_FUSED alone")
+    _, _, g5 = run(PRESPLIT=True, PRESPLIT_L0=False)
+    assert all(torch.equal(g5[k], g1[k]) for k in g1), "layer 0 on fp32 operands must be bit-identical"
+    s6, _, g6 = run(PRESPLIT=True, ACTIVATIONS="lean")
+    assert torch.equal(s6, s1) and all(torch.equal(g6[k], g1[k]) for k in g1), "lean activations must be bit-identical"
+    _, _, g7 = run(PRESPLIT=True, TN_AT="now")
+    assert all(torch.equal(g7[k], g1[k]) for k in g1), "where the deferred weight-gradient kernel runs must not matter"
+    _, _, g8 = run()                                # the default: NODE_FUSED on fp32 operands
+    assert all(torch.equal(g8[k], g4[k]) for k in g4)
+    _, _, g9 = run(ACTIVATIONS="lean")
+    assert all(torch.equal(g9[k], g8[k]) for k in g8), "lean activations must be bit-identical (default schedule)"
+
+
+@pytest.mark.default_mode_only
+def test_full_size_gradients_match_the_oracle():
+    """Backward parity AT THE METRIC'S SIZE (BASELINE config 2: R = 750 k, N = 1.5 M, E = 7.54 M, H = 128, L = 8): the loss and
+    EVERY parameter gradient (826,033 values in 138 tensors) of one HIP training step against the fp64 autograd oracle
+    (oracle.bce_loss(oracle.model_forward(...)).backward() = the reference's loss.backward(), train.py:253-257), stored in
+    tests/golden/fullsize_grads_r750k.npz by tests/golden/make_golden_fullsize.py --grads (22 min on a 128-thread host).  Bar: the
+    same _grad_ok clauses as the small fixtures, minus the fp32-noise clause (no fp32 oracle run at this size): rel-L2 <= 2e-4 per
+    tensor or under the absolute floor; the tally is printed and written to gpurun_out/grad_parity_fullsize.txt.  Exercises what
+    the 1 k-read fixtures cannot: the two-sided backward sweep at one workgroup per CU, the plan's slot discipline over 7.5 M
+    rows, int64 offsets, the BatchNorm-backward sums over E and N.  Run twice: generator node ids, and shuffled ids (renumbered
+    by the index; parameter gradients do not depend on the numbering)."""
+    import gnnome_assembly_amd as G
+    dev = _dev()
+    R, H, L, seed = 750000, 128, 8, 0
+    zf = np.load(os.path.join(GOLDEN, "fullsize_grads_r750k.npz"))
+    model, src, dst, n, inp = _model_and_inputs(R, H, L, seed, dev)
+    E = int(src.size)
+    assert (int(zf["reads"]), int(zf["H"]), int(zf["L"]), int(zf["seed"]), int(zf["edges"])) == (R, H, L, seed, E)
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    e, y = torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(inp["y"]).to(dev)
+
+    def hip(src_, dst_, pe_np):
+        g = G.AssemblyGraph(src_, dst_, n).to(dev)
+        model.zero_grad(set_to_none=True)
+        s = model(g, None, e, torch.from_numpy(pe_np).to(dev))
+        loss = crit(s.squeeze(-1), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        out = loss.item(), {k: v.grad.detach().cpu().double().numpy() for k, v in model.named_parameters()}
+        del g, s, loss
+        torch.cuda.empty_cache()
+        return out
+    runs = {"generator ids": hip(src, dst, inp["pe"])}
+    p = np.random.default_rng(17).permutation(n).astype(np.int32)
+    pe_s = np.empty_like(inp["pe"])
+    pe_s[p] = inp["pe"]
+    runs["shuffled ids"] = hip(p[src], p[dst], pe_s)
+    gmax = max(float(zf["norm::" + k]) for k in runs["generator ids"][1])
+    lines, bad = [], []
+    for what, (loss, grads) in runs.items():
+        assert abs(loss - float(zf["loss"])) <= 1e-5 * abs(float(zf["loss"])), (what, loss, float(zf["loss"]))
+        tally = {"l2": 0, "floor": 0, "miss": 0}
+        worst = ("", 0.0)
+        for k, got in grads.items():
+            want = zf["grad::" + k].astype(np.float64)
+            assert got.shape == want.shape, k
+            r = rel_l2(got, want)
+            mx = float(np.abs(got - want).max())
+            clause = "l2" if r <= GRAD_L2 else "floor" if mx <= GRAD_ABS_FLOOR * max(gmax, 1.0) else "miss"
+            tally[clause] += 1
+            tally_clause(clause)
+            if clause == "l2" and r > worst[1]:
+                worst = (k, r)
+            if clause == "miss":
+                bad.append((what, k, r, mx))
+            lines.append(f"{what:14s} {k:34s} rel_l2={r:.3e} max_abs={mx:.3e} ref_norm={float(zf['norm::' + k]):.3e} {clause}")
+        head = (f"full size E={E} N={n} H={H} L={L} [{what}]: loss {loss:.9f} (oracle {float(zf['loss']):.9f}); {len(grads)} gradient "
+                f"tensors: {tally['l2']} within rel-L2 {GRAD_L2:g}, {tally['floor']} under the absolute floor, {tally['miss']} missed; "
+                f"worst rel-L2 among the former {worst[1]:.3e} ({worst[0]})")
+        print(head)
+        lines.insert(0, head)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "grad_parity_fullsize.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
     assert not bad, bad
 
 

@@ -223,3 +223,41 @@ def test_from_dgl_and_foreign_graph_wrapping():
     assert as_assembly_graph(dg) is w1 and as_assembly_graph(w1) is w1
     with pytest.raises(TypeError):
         as_assembly_graph(object())
+    # the reference's loops do g = g.to(device) every step (train.py:244,297): DGL hands back a NEW object each time -- the
+    # wrapper (host index, locality order, sweep plans) must be found again by the content of the edge list, not rebuilt
+    dg2 = dgl.DGLGraph(s.copy(), d.copy(), n)
+    dg2.edata["y"] = torch.zeros(s.size)
+    w2 = as_assembly_graph(dg2)
+    assert w2 is w1 and torch.equal(w2.edata["y"], dg2.edata["y"]), "same edge list: same wrapper, the caller's current features"
+    p = np.random.default_rng(0).permutation(s.size)
+    w3 = as_assembly_graph(dgl.DGLGraph(s[p], d[p], n))
+    assert w3 is not w1, "another edge-id order is another graph"
+    # an object that takes no attributes and no weak references is wrapped but never cached by id (ids are reused)
+
+    class Frozen:
+        __slots__ = ("s", "d", "n")
+
+        def __init__(self, s_, d_, n_):
+            self.s, self.d, self.n = s_, d_, n_
+
+        def edges(self):
+            return torch.from_numpy(self.s), torch.from_numpy(self.d)
+
+        def num_nodes(self):
+            return self.n
+
+        def num_edges(self):
+            return self.s.size
+    from gnnome_assembly_amd import graph as gmod
+    fz = Frozen(s, d, n)
+    assert as_assembly_graph(fz) is w1 and id(fz) not in gmod._WRAPPED
+
+
+def test_no_undefined_names_in_the_package():
+    """The HIP-only paths of the package never run in the build container: a name that is read without being bound anywhere
+    (a NameError on the GPU box) is caught here instead (tools/lint_names.py)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "lint_names.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -143,3 +143,25 @@ def test_high_degree_destination_crosses_tiles():
     assert served[100:200].sum() == 32          # 100 sources are open at once: 32 slots, the rest go to the fix list
     plan, served, outdeg = check_plan(src, dst, n, npb=300, nslots=64)
     assert served[100:200].sum() == 64
+
+
+def test_a_hub_beyond_the_32_bit_row_offsets_gets_no_plan():
+    """The sweep kernels reach a workgroup's rows through 32-bit buffer offsets (row x up to 1024 bytes): a node partition that
+    gives ONE workgroup more than 2^21 - 64 rows (a hub with millions of in-edges; the average share says nothing) cannot be
+    swept.  The builder reports it (return code 3 -> build_sweep_plan returns None) and the graph keeps the separate by-source
+    passes, instead of a plan whose kernels would drop or misplace stores."""
+    n, e = 64, (1 << 21) + 200
+    rng = np.random.default_rng(0)
+    src = rng.integers(1, n, size=e).astype(np.int32)
+    dst = np.zeros(e, np.int32)                       # every edge into node 0
+    dst[:100] = rng.integers(1, n, size=100)
+    order = np.argsort(dst, kind="stable")
+    isrc, idst = src[order], dst[order]
+    in_ptr = np.concatenate(([0], np.cumsum(np.bincount(idst, minlength=n)))).astype(np.int32)
+    h = {"isrc": isrc, "idst": idst, "in_ptr": in_ptr}
+    assert build_sweep_plan(h, n, 8) is None
+    # the same graph with a quarter of the edges is fine
+    keep = np.sort(rng.choice(e, e // 4, replace=False))
+    isrc, idst = isrc[keep], idst[keep]
+    in_ptr = np.concatenate(([0], np.cumsum(np.bincount(idst, minlength=n)))).astype(np.int32)
+    assert build_sweep_plan({"isrc": isrc, "idst": idst, "in_ptr": in_ptr}, n, 8) is not None

@@ -1,9 +1,13 @@
-"""Runs LAST (file name): the gradient tests pass a tensor on rel-L2 <= 2e-4 OR within 3x the reference's own fp32
-noise OR under an absolute floor OR (BatchNorm models) exact for the relu branches the device took.  This test makes
-the escapes visible and bounded: the per-test tally of which clause decided each tensor is written to
-gpurun_out/grad_clauses.{json,txt} (the committed copy: profiles/r03_grad_clauses.txt), and the suite FAILS when a test
-took more escapes -- anything but the plain rel-L2 bar -- than tests/golden/grad_clause_baseline.json allows.
-A kernel change that degrades a test from 0 to 10 escapes no longer stays green."""
+"""Runs LAST (file name): the gradient tests pass a tensor on rel-L2 <= 2e-4 against the fp64 oracle, OR -- BatchNorm models --
+EXACT (rel-L2 <= 5e-5) against the fp64 backward evaluated on the relu branches the device took ("branch_exact": a strict
+comparison without kink ambiguity, not an escape), OR under an absolute floor, OR -- LayerNorm models only, where there is no
+branch-exact oracle -- within 3x the reference's own fp32 noise.  Rounds 1-4 allowed the noise clause for every model and raised
+its budget when kernels changed ("a budget that is raised whenever the kernels change bounds nothing"); round 5
+removed it for BatchNorm models, which were the only ones that ever used it.
+This test makes what is left visible and bounded: the per-test tally of which clause decided each tensor is written to
+gpurun_out/grad_clauses.{json,txt} (committed copies under profiles/), and the suite FAILS when a test took more "noise" or
+"floor" escapes than tests/golden/grad_clause_baseline.json allows.  The baseline file is never edited in a commit that also
+touches a kernel."""
 import json
 import os
 
@@ -15,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASELINE = os.path.join(REPO, "tests", "golden", "grad_clause_baseline.json")
-ESCAPES = ("noise", "floor", "branch_exact")
+ESCAPES = ("noise", "floor")          # budgeted; "branch_exact" is tallied and reported, it is an exact comparison
 
 
 def test_gradient_escape_clauses_stay_within_the_committed_baseline():
@@ -25,7 +29,7 @@ def test_gradient_escape_clauses_stay_within_the_committed_baseline():
     os.makedirs(out, exist_ok=True)
     tally = {k: {c: int(n) for c, n in sorted(v.items()) if n} for k, v in sorted(GRAD_CLAUSES.items())}
     json.dump(tally, open(os.path.join(out, "grad_clauses.json"), "w"), indent=1)
-    cols = ("l2",) + ESCAPES + ("miss",)
+    cols = ("l2", "branch_exact") + ESCAPES + ("miss",)
     lines = [f"{'test':110s} " + " ".join(f"{c:>12s}" for c in cols)]
     for k, v in tally.items():
         lines.append(f"{k[-110:]:110s} " + " ".join(f"{v.get(c, 0):12d}" for c in cols))
