@@ -10,7 +10,7 @@
 //   rowtile_nt_k<EDGE>   t = e W3^T + b3 + B1h[src] + B2h[dst], BatchNorm column sums
 //                        (gated_gcn_full.py:113,120-122) -- replaces gemm + edge_t_stats;
 //                        node mode: P = h W5^T + b5 over the five 128-column groups (:107-112)
-//   edge_bwd_fused_k     gt = gamma*rstd*(gu - m1 - that*m2); ge_in = ge + gt W3;
+//   edge_bwd_fused32_k   gt = gamma*rstd*(gu - m1 - that*m2); ge_in = ge + gt W3;
 //                        gW3 += gt^T e_in; gb3 += sum gt   (autograd of :113,:122)
 //                        -- replaces edge_bwd_gt + two GEMMs + a column sum (9 -> 4 streams)
 //   rowtile_nn_acc_k / tn_colgroup_k   autograd of the 5-way node projection (:107-112)
@@ -193,8 +193,7 @@ struct MmB3 {
   static constexpr int kImgBytes = 3 * BIMG * 2;
   static constexpr bool kSplit = true;
   static constexpr size_t kPackBytes = (size_t)BKC * 3 * 64 * 16;
-  static constexpr int kTnBytes = 2 * 3 * (FH * (FTR + 8)) * 2;      // TN operands: two transposed split images
-  static __device__ __forceinline__ int row(int lrow, int it) { return 8 * lrow + it; }   // see stage_cols
+  static __device__ __forceinline__ int row(int lrow, int it) { return 8 * lrow + it; }
   struct Frag { bf16x8 w[BKC][3]; };
   static __device__ __forceinline__ void load_w(Frag& f, const void* Wp, int blk, int lane) {
     const bf16x8* p = reinterpret_cast<const bf16x8*>(Wp) + ((int64_t)blk * BKC * 3) * 64 + lane;
@@ -249,88 +248,6 @@ struct MmB3 {
   }
 };
 
-// ---- split TN: C[n][c] += sum_row A[row][n] B[row][c], both operands transposed into bf16 images ----
-// A thread of the coalesced tile image owns rows 8*lrow .. +7 x columns lc4 .. +3 (MmB3::row), i.e. for
-// each of its 4 columns 8 CONSECUTIVE contraction indices = one bf16x8 = one ds_write_b128 into the
-// column-major image T[s][slot][row], pitch TP = 72 (9 sixteen-byte units: 16 neighbouring slots hit 16
-// different bank groups).  Neighbouring lanes of the tile image are 4 columns apart, so column c is
-// kept in slot 32*(c & 3) + (c >> 2): the j-th write of lanes 0..31 then goes to 32 consecutive slots
-// (conflict-free; measured 2.5x faster than slot = column), and a fragment read of slots
-// 32*blk .. +31 is conflict-free too.  The price is only a permuted result: MFMA block blk, index i
-// stands for column 4*i + blk (tn_store_slab).
-constexpr int TP = FTR + 8;
-constexpr int TIMG = FH * TP;
-
-struct Split8 { bf16x4 hi[8], mid[8], lo[8]; };   // 8 rows x 4 columns, split
-
-__device__ __forceinline__ void split_rows(const float4 (&v)[8], Split8& s) {
-#pragma unroll
-  for (int it = 0; it < 8; ++it) split3(v[it], s.hi[it], s.mid[it], s.lo[it]);
-}
-__device__ __forceinline__ void stage_rows(void* img, int lrow, int lc4, const Split8& s) {
-  __bf16* b = reinterpret_cast<__bf16*>(img) + (8 * lrow) * BP + lc4;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    *reinterpret_cast<bf16x4*>(b + it * BP) = s.hi[it];
-    *reinterpret_cast<bf16x4*>(b + it * BP + BIMG) = s.mid[it];
-    *reinterpret_cast<bf16x4*>(b + it * BP + 2 * BIMG) = s.lo[it];
-  }
-}
-__device__ __forceinline__ void stage_cols(void* timg, int lrow, int lc4, const Split8& s) {
-  __bf16* b = reinterpret_cast<__bf16*>(timg) + (lc4 >> 2) * TP + 8 * lrow;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    bf16x8 h, m, l;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) { h[it] = s.hi[it][j]; m[it] = s.mid[it][j]; l[it] = s.lo[it][j]; }
-    *reinterpret_cast<bf16x8*>(b + j * 32 * TP) = h;
-    *reinterpret_cast<bf16x8*>(b + j * 32 * TP + TIMG) = m;
-    *reinterpret_cast<bf16x8*>(b + j * 32 * TP + 2 * TIMG) = l;
-  }
-}
-// this wave's 64 x 64 block (wn, wc) of the 128 x 128 result, contraction over the tile's 64 rows
-template <bool PIPE>
-__device__ __forceinline__ void mma_tn64_b3(const void* ta, const void* tb, floatx16 (&tn)[2][2], int wn, int wc,
-                                            int li, int lg) {
-  const __bf16* pa = reinterpret_cast<const __bf16*>(ta) + ((2 * wn) * 32 + li) * TP + 8 * lg;
-  const __bf16* pb = reinterpret_cast<const __bf16*>(tb) + ((2 * wc) * 32 + li) * TP + 8 * lg;
-  bf16x8 a[2][3], b[2][3];
-  auto load = [&](int kc, bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int s_ = 0; s_ < 3; ++s_) {
-        fa[x][s_] = *reinterpret_cast<const bf16x8*>(pa + s_ * TIMG + x * 32 * TP + 16 * kc);
-        fb[x][s_] = *reinterpret_cast<const bf16x8*>(pb + s_ * TIMG + x * 32 * TP + 16 * kc);
-      }
-  };
-  load(0, a, b);
-#pragma unroll
-  for (int kc = 0; kc < FTR / 16; ++kc) {
-    bf16x8 na[2][3], nb[2][3];
-    if (PIPE && kc + 1 < FTR / 16) load(kc + 1, na, nb);   // PIPE: next chunk's fragments under these MFMAs (+48 VGPRs)
-    if (!PIPE && kc > 0) load(kc, a, b);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t_ = 0; t_ < 6; ++t_) {
-      // (A part, B part): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-      const int sa = t_ == 0 ? 2 : (t_ == 2 || t_ == 3) ? 1 : 0;
-      const int sb = t_ == 1 ? 2 : (t_ == 2 || t_ == 4) ? 1 : 0;
-      mfb(tn[0][0], a[0][sa], b[0][sb]);
-      mfb(tn[0][1], a[0][sa], b[1][sb]);
-      mfb(tn[1][0], a[1][sa], b[0][sb]);
-      mfb(tn[1][1], a[1][sa], b[1][sb]);
-    }
-    if (PIPE && kc + 1 < FTR / 16) {
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) { a[x][s_] = na[x][s_]; b[x][s_] = nb[x][s_]; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 // this wave's 64 x 64 block of the TN result -> sl[n][c] (128 x 128, row-major)
 template <class MM>
 __device__ __forceinline__ void tn_store_slab(float* __restrict__ sl, const floatx16 (&tn)[2][2], int wn, int wc,
@@ -342,8 +259,8 @@ __device__ __forceinline__ void tn_store_slab(float* __restrict__ sl, const floa
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * lg;
-        const int n = MM::kSplit ? 4 * i + (2 * wn + a) : (2 * wn + a) * 32 + i;     // see stage_cols
-        const int c = MM::kSplit ? 4 * li + (2 * wc + b) : (2 * wc + b) * 32 + li;
+        const int n = (2 * wn + a) * 32 + i;
+        const int c = (2 * wc + b) * 32 + li;
         sl[n * FH + c] = tn[a][b][e];
       }
 }
@@ -521,8 +438,10 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
 
   if (tb0 < tb1) prefetch(tb0);
   if (tb0 < nfull) {
-    // throw-away stores behind the first prefetch (same addresses the first epilogue rewrites):
-    // they make the loop-entry scoreboard equal to the back edge's, see edge_bwd_fused_k
+    // throw-away stores behind the first prefetch (same addresses the first epilogue rewrites): hipcc merges the vector-memory
+    // scoreboard of the loop entry with that of the back edge and keeps the weaker guarantee -- without stores behind the first
+    // prefetch it would wait vmcnt(0) (= for the previous tile's stores) before the last prefetched row on EVERY iteration;
+    // these make both edges alike
 #pragma unroll
     for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * ldy + cgb * FH + lc4, f4(0.f));
     for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
@@ -617,93 +536,9 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nt_s3_k(
 // 32-row halves of the three bf16 images are two tile buffers, the fp32 output image is separate.
 // ------------------------------------------------------------------------------------------
 constexpr int ER3 = 32;
-__global__ __launch_bounds__(kBlock, 2) void edge_t32_b3_k(
-    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
-    const int32_t* __restrict__ idst, double* __restrict__ partials, int64_t tiles_per_block) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
-  __shared__ float os[ER3 * FP];
-  __shared__ int sd[2][2 * ER3];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lg = lane >> 5;
-  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  const int64_t ntiles = (M + ER3 - 1) / ER3;
-  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
-  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
-  const int64_t nfull = min(tb1, M / ER3);
-  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
-  const int64_t Mlast = M - 1;
-  const int32_t* const ibase = (lane & 32) ? idst : isrc;     // lanes 0-31: src of row lane, 32-63: dst of row lane-32
-
-  MmB3::Frag wf;
-  MmB3::load_w(wf, Wp, wave, lane);
-  const float4 b4 = ld4(bias + lc4);
-  float4 pre[2][4];
-  int pidx[2] = {0, 0};
-  auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
-    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) buf[it] = ld4_nt(X + clampi(r0 + lrow + 8 * it, Mlast) * FH + lc4);
-    idx = ibase[clampi(r0 + (lane & 31), Mlast)];
-  };
-  Stat4 st;
-  st.zero();
-  auto body = [&](auto tag, float4 (&buf)[4], int& idx, int64_t tile, int hb) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(tag)::value;
-    const int64_t r0 = tile * ER3;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * hb + lrow + 8 * it, lc4, buf[it]);
-    sd[hb][lane] = idx;
-    __syncthreads();
-    float4 g1[4], g2[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = lrow + 8 * it;
-      const int64_t s_ = sd[hb][row], d_ = sd[hb][ER3 + row];
-      g1[it] = ld4(P + s_ * (5 * FH) + 3 * FH + lc4);
-      g2[it] = ld4(P + d_ * (5 * FH) + 4 * FH + lc4);
-    }
-    prefetch(buf, idx, tile + 2);
-    floatx16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    mma32_b3(xraw, 32 * hb, wf, acc, li, lg);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) os[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + wave * 32 + li] = acc[e];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = lrow + 8 * it;
-      const int64_t grow = r0 + row;
-      const float4 v = ld4(os + row * FP + lc4) + b4 + g1[it] + g2[it];
-      if (FULL || grow < M) {
-        st4_nt(Y + grow * FH + lc4, v);
-        st.add_prod(v, v);
-      }
-    }
-  };
-  if (tb0 < tb1) {
-    prefetch(pre[0], pidx[0], tb0);
-    prefetch(pre[1], pidx[1], tb0 + 1);
-  }
-  int64_t tile = tb0;
-  for (; tile + 2 <= nfull; tile += 2) {
-    body(full_t{}, pre[0], pidx[0], tile, 0);
-    body(full_t{}, pre[1], pidx[1], tile + 1, 1);
-  }
-  // at most one more full tile and one ragged tile
-  int hb = 0;
-  for (; tile < tb1; ++tile, hb ^= 1) {
-    if (hb == 0) body(ragged_t{}, pre[0], pidx[0], tile, 0);
-    else body(ragged_t{}, pre[1], pidx[1], tile, 1);
-  }
-  __syncthreads();
-  block_stat_store<FH>(st, reinterpret_cast<double*>(xraw), partials, chunk);
-}
-
-// edge_t32_b3_k with the split / staging of tile k+1 issued inside the matrix phase of tile k (see edge_t32_h256p_k): same
-// arithmetic and summation order, bit-identical results.
+// (round 4: the split / staging of tile k+1 is issued inside the matrix phase of tile k, see edge_t32_h256p_k; the kernel that ran
+//  the phases one after the other -- 14.9 against 14.3 ms per step, bit-identical -- was removed in round 5, numbers in
+//  profiles/r04_ab_kernels.txt)
 __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
     int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
@@ -819,120 +654,10 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
 // ------------------------------------------------------------------------------------------
 constexpr int WH = 2 * FH;          // the wide hidden size
 constexpr int kBlockW = 512;
-__global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256_k(
-    int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
-    const int32_t* __restrict__ idst, double* __restrict__ partials, int nchunk, int64_t tiles_per_chunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MmB3::kImgBytes];   // [contraction half][hi|mid|lo][2 x 32 rows]
-  __shared__ float os[2 * ER3 * FP];                                                  // [contraction half][32 rows] partial results
-  __shared__ int sd[2][2 * ER3];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lg = lane >> 5;
-  const int cb = wave & 3, kh = wave >> 2;
-  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;
-  const int J = jj & 1, chunk = xcd * (nchunk / kXcds) + (jj >> 1);
-  const int64_t ntiles = (M + ER3 - 1) / ER3;
-  const int64_t tb0 = (int64_t)chunk * tiles_per_chunk;
-  const int64_t tb1 = min(ntiles, tb0 + tiles_per_chunk);
-  const int64_t nfull = min(tb1, M / ER3);
-  const int srow = tid >> 6, sc = (tid & 63) * 4;            // staging: 8 rows x 64 float4 per pass, 4 passes
-  unsigned char* const simg = xraw + (sc >> 7) * MmB3::kImgBytes;
-  const int slc4 = sc & (FH - 1);
-  const int erow = tid >> 5, ec4 = (tid & 31) * 4;           // epilogue: 16 rows x 32 float4 (this class's 128 columns), 2 passes
-  const int64_t Mlast = M - 1;
-  const int32_t* const ibase = (lane & 32) ? idst : isrc;    // lanes 0-31: src of row lane, 32-63: dst of row lane - 32
-
-  MmB3::Frag wf;
-  MmB3::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
-  const float4 b4 = ld4(bias + J * FH + ec4);
-  float4 pre[2][4];
-  int pidx[2] = {0, 0};
-  auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
-    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) buf[it] = ld4(X + clampi(r0 + srow + 8 * it, Mlast) * WH + sc);   // shared with class 1 - J through L2
-    idx = ibase[clampi(r0 + (lane & 31), Mlast)];
-  };
-  Stat4 st;
-  st.zero();
-  auto body = [&](auto tag, float4 (&buf)[4], int& idx, int64_t tile, int hb) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(tag)::value;
-    const int64_t r0 = tile * ER3;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) MmB3::stage(simg, 32 * hb + srow + 8 * it, slc4, buf[it]);
-    if (wave == 0) sd[hb][lane] = idx;
-    __syncthreads();
-    float4 g1[2], g2[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = erow + 16 * it;
-      const int64_t s_ = sd[hb][row], d_ = sd[hb][ER3 + row];
-      g1[it] = ld4(P + s_ * (5 * WH) + 3 * WH + J * FH + ec4);
-      g2[it] = ld4(P + d_ * (5 * WH) + 4 * WH + J * FH + ec4);
-    }
-    prefetch(buf, idx, tile + 2);
-    floatx16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    mma32_b3(xraw + kh * MmB3::kImgBytes, 32 * hb, wf, acc, li, lg);
-    float* const oh = os + kh * (ER3 * FP);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oh[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + cb * 32 + li] = acc[e];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = erow + 16 * it;
-      const int64_t grow = r0 + row;
-      const float4 v = (ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4)) + b4 + g1[it] + g2[it];
-      if (FULL || grow < M) {
-        st4_nt(Y + grow * WH + J * FH + ec4, v);
-        st.add_prod(v, v);
-      }
-    }
-  };
-  if (tb0 < tb1) {
-    prefetch(pre[0], pidx[0], tb0);
-    prefetch(pre[1], pidx[1], tb0 + 1);
-  }
-  int64_t tile = tb0;
-  for (; tile + 2 <= nfull; tile += 2) {
-    body(full_t{}, pre[0], pidx[0], tile, 0);
-    body(full_t{}, pre[1], pidx[1], tile + 1, 1);
-  }
-  int hb = 0;
-  for (; tile < tb1; ++tile, hb ^= 1) {
-    if (hb == 0) body(ragged_t{}, pre[0], pidx[0], tile, 0);
-    else body(ragged_t{}, pre[1], pidx[1], tile, 1);
-  }
-  // BatchNorm partial sums of this workgroup's 128 columns: lanes l and l ^ 32 hold the same columns, then 8 waves through LDS
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    st.a[i] += __shfl_xor(st.a[i], 32, 64);
-    st.b[i] += __shfl_xor(st.b[i], 32, 64);
-  }
-  double* red = reinterpret_cast<double*>(xraw);             // [8 waves][2][128]
-  if (lane < 32) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      red[(wave * 2 + 0) * FH + lane * 4 + i] = st.a[i];
-      red[(wave * 2 + 1) * FH + lane * 4 + i] = st.b[i];
-    }
-  }
-  __syncthreads();
-  if (tid < 2 * FH) {
-    double acc = 0.0;
-#pragma unroll
-    for (int w = 0; w < kBlockW / 64; ++w) acc += red[w * 2 * FH + tid];
-    partials[((size_t)chunk * 2 + (tid >> 7)) * WH + J * FH + (tid & (FH - 1))] = acc;
-  }
-}
-
-// edge_t32_h256_k with the split / staging of tile k+1 issued INSIDE the matrix phase of tile k: a wave's 48 MFMAs are one
-// dependent chain (62 cycles apiece on its own), which leaves the vector ALU idle -- the next tile's 4 rows per thread are
-// split and written to the OTHER half of the image set between the chunks of the chain, so that per tile only the epilogue
-// stays outside the matrix phase.  Same arithmetic, same summation order: bit-identical results.
+// The split / staging of tile k+1 is issued INSIDE the matrix phase of tile k: a wave's 48 MFMAs are one dependent chain (62 cycles
+// apiece on its own), which leaves the vector ALU idle -- the next tile's 4 rows per thread are split and written to the OTHER half
+// of the image set between the chunks of the chain, so that per tile only the epilogue stays outside the matrix phase (27.1 -> 24.5
+// ms per step against the kernel that ran the phases one after the other, bit-identical; that kernel was removed in round 5).
 __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
     int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
@@ -1154,154 +879,12 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
 }
 
 // ------------------------------------------------------------------------------------------
-// fused edge backward: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
+// fused edge backward, fp32-MFMA mode: gt prologue + NN (ge_in) + TN (gW3 slab) + column sum of gt
+// (the split mode runs edge_bwd_tr_k, gnm_tr.hip; the 64-row split kernel of round 1 -- 159 KB of LDS, one workgroup per CU,
+//  4.0-4.3 against 3.5 ms -- was removed in round 5)
 // ------------------------------------------------------------------------------------------
-template <class MM>
-__global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_k(
-    int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
-    const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
-    const void* __restrict__ Wp,                     // W3 packed NN
-    float* __restrict__ slab,                        // [grid][128][128] partial gW3
-    double* __restrict__ partials,                   // [grid][128]: per-workgroup column sums of gt
-    int64_t tiles_per_block) {
-  // fp32 mode:  [gt row image | e_in row image]                      (the gt image doubles as the NN operand)
-  // split mode: [gt split row images (NN) | gt transposed split | e_in transposed split]   = 159 KB
-  constexpr int kNnBytes = MM::kSplit ? MM::kImgBytes : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char raw[kNnBytes + MM::kTnBytes];
-  float* gs = reinterpret_cast<float*>(raw + kNnBytes);          // fp32 mode
-  float* es = gs + FTR * FP;
-  unsigned char* tg = raw + kNnBytes;                            // split mode
-  unsigned char* te = tg + MM::kTnBytes / 2;
-  float* os = reinterpret_cast<float*>(raw);                     // transposed output image (after the MFMAs)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lg = lane >> 5;
-  const int wn = wave >> 1, wc = wave & 1;
-  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  const int64_t ntiles = (E + FTR - 1) / FTR;
-  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
-  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
-  const int64_t nfull = min(tb1, E / FTR);
-  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
-  const int64_t Elast = E - 1;
-
-  // per-column constants of this thread's 4 columns: mu, rstd, scale, shift, m1, m2, c = gamma*rstd
-  const float4 mu = ld4(stat + lc4), rs = ld4(stat + FH + lc4), sc = ld4(stat + 2 * FH + lc4),
-               sh = ld4(stat + 3 * FH + lc4), m1 = ld4(bstat + lc4), m2 = ld4(bstat + FH + lc4),
-               cc = ld4(gamma + lc4) * rs;
-  typename MM::Frag wf;
-  MM::load_w(wf, Wp, wave, lane);
-  floatx16 tn[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
-  double cg0 = 0.0, cg1 = 0.0, cg2 = 0.0, cg3 = 0.0;   // column sums of gt for columns lc4..lc4+3
-
-  // ge / t / e_in rows of a tile are prefetched one tile ahead (96 VGPRs), under the MFMA phases
-  float4 pg[8], pt[8], pe_[8];
-  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
-    const int64_t r0 = tile * FTR;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int64_t o = clampi(r0 + MM::row(lrow, it), Elast) * FH + lc4;
-      pg[it] = ld4(ge + o);
-      pt[it] = ld4(t + o);
-      pe_[it] = ld4(e_in + o);
-    }
-  };
-
-  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(tag)::value;
-    const int64_t r0 = tile * FTR;
-    // ---- phase 0: gt tile and e_in tile into LDS ----
-    float4 gk[8];   // this tile's ge rows, kept for the residual add in the epilogue
-    {
-      float4 gtv[8], evv[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const bool ok = FULL || (r0 + MM::row(lrow, it) < E);
-        gk[it] = pg[it];
-        const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
-        float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
-        float4 ev = pe_[it];
-        if (!ok) { gt = f4(0.f); ev = f4(0.f); }
-        cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
-        gtv[it] = gt;
-        evv[it] = ev;
-      }
-      if (MM::kSplit) {
-        Split8 sp;
-        split_rows(gtv, sp);
-        stage_rows(raw, lrow, lc4, sp);
-        stage_cols(tg, lrow, lc4, sp);
-        split_rows(evv, sp);
-        stage_cols(te, lrow, lc4, sp);
-      } else {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          st4(gs + MM::row(lrow, it) * FP + lc4, gtv[it]);
-          st4(es + MM::row(lrow, it) * FP + lc4, evv[it]);
-        }
-      }
-    }
-    __syncthreads();
-    prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // in flight under the MFMAs below
-    // ---- MFMA phases: acc = gt W3 (this wave: output columns wave*32 .. +31) and
-    //      gW3[n][c] += sum_rows gt[row][n] e_in[row][c] (this wave: 64 x 64 block).  Split mode runs
-    //      the TN part first so that acc is not live across it (register budget). ----
-    floatx16 acc0, acc1;
-    if (MM::kSplit) mma_tn64_b3<false>(tg, te, tn, wn, wc, li, lg);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-    MM::mma(MM::kSplit ? (const void*)raw : (const void*)gs, wf, acc0, acc1, li, lg);
-    if (!MM::kSplit) mma_tn64(gs, es, tn, wn, wc, li, lg);
-    __syncthreads();   // operand images are dead: reuse the front of the buffer as the output image
-    acc_to_lds(os, acc0, acc1, wave, li, lg);
-    __syncthreads();
-    // ---- ge_in = ge + gt W3, whole 512-byte rows, one float4 per lane ----
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = MM::row(lrow, it);
-      const int64_t grow = r0 + row;
-      if (FULL || grow < E) st4(ge_out + grow * FH + lc4, ld4(os + row * FP + lc4) + gk[it]);
-    }
-    __syncthreads();   // the buffer is rewritten by the next tile's phase 0
-  };
-
-  if (tb0 < tb1) prefetch(tb0);
-  // hipcc merges the vector-memory scoreboard of the loop entry with that of the back edge and
-  // keeps the weaker guarantee: without stores behind the first prefetch it would wait vmcnt(0)
-  // (= for the previous tile's stores) before the last prefetched row on EVERY iteration.  Eight
-  // throw-away stores into this workgroup's slab (rewritten at the end) make both edges alike.
-#pragma unroll
-  for (int it = 0; it < 8; ++it) st4(slab + (size_t)chunk * FH * FH + (lrow + 8 * it) * FH + lc4, f4(0.f));
-  for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
-  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
-
-  // ---- write the partial gW3 slab and the column sums ----
-  float* sl = slab + (size_t)chunk * FH * FH;
-  tn_store_slab<MM>(sl, tn, wn, wc, li, lg);
-  // 8 row-slots (lrow) x 128 columns -> 128 column sums (the tile images are free now)
-  double* red = reinterpret_cast<double*>(raw);
-  red[lrow * FH + lc4 + 0] = cg0;
-  red[lrow * FH + lc4 + 1] = cg1;
-  red[lrow * FH + lc4 + 2] = cg2;
-  red[lrow * FH + lc4 + 3] = cg3;
-  __syncthreads();
-  if (tid < FH) {
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k * FH + tid];
-    partials[(size_t)chunk * FH + tid] = s;
-  }
-}
-
-// fp32 variant with 32-row tiles: 236 VGPRs and 37 KB of LDS, so TWO workgroups share a CU and one's
-// gt prologue / epilogue runs under the other's MFMAs (the 64-row kernel above holds 416 registers
-// and leaves the matrix pipe idle during those phases: 68 % busy).
+// 32-row tiles: 236 VGPRs and 37 KB of LDS, so TWO workgroups share a CU and one's gt prologue / epilogue runs under the
+// other's MFMAs (a 64-row kernel holds 416 registers and leaves the matrix pipe idle during those phases: 68 % busy).
 constexpr int FTR2 = 32;
 
 __global__ __launch_bounds__(kBlock, 2) void edge_bwd_fused32_k(
@@ -1428,7 +1011,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_fused32_k(
   };
   if (tb0 < tb1) prefetch(tb0);
 #pragma unroll
-  for (int it = 0; it < 4; ++it) st4(slab + (size_t)chunk * FH * FH + (lrow + 8 * it) * FH + lc4, f4(0.f));   // see edge_bwd_fused_k
+  for (int it = 0; it < 4; ++it) st4(slab + (size_t)chunk * FH * FH + (lrow + 8 * it) * FH + lc4, f4(0.f));   // scoreboard equalisation, see rowtile_nt_k
   for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
   if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
 
@@ -1507,7 +1090,7 @@ __global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void rowtile_nn_acc_k(
   if (tb0 < tb1) prefetch(tb0, 0);
   if (tb0 < nfull) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * FH + lc4, f4(0.f));   // see edge_bwd_fused_k
+    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * FH + lc4, f4(0.f));   // scoreboard equalisation, see rowtile_nt_k
     for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
   }
   if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
@@ -1882,15 +1465,15 @@ __global__ void pack_w3_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
 
 // slab[(cg*nslot + slot)][n][c] = sum over the slot's rows of A[row][cg*128+n] * B[row][c];
 // partials[(cg*nslot + slot)][128] = column sums of A[:, cg*128 ..]
+// (fp32-MFMA mode; the split mode runs tn_tr_k, gnm_tr.hip)
 template <class MM>
-__global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void tn_colgroup_k(
+__global__ __launch_bounds__(kBlock, 2) void tn_colgroup_k(
     int64_t M, const float* __restrict__ A, int64_t lda, int ncg, const float* __restrict__ B,
     float* __restrict__ slab, double* __restrict__ partials, int nslot, int64_t tiles_per_slot) {
+  static_assert(!MM::kSplit, "the split mode has its own weight-gradient kernel (tn_tr_k)");
   __shared__ __attribute__((aligned(16))) unsigned char raw[MM::kTnBytes];
-  float* as = reinterpret_cast<float*>(raw);             // fp32 mode: two row images
+  float* as = reinterpret_cast<float*>(raw);             // two row images
   float* bs = as + FTR * FP;
-  unsigned char* ta = raw;                               // split mode: two transposed images
-  unsigned char* tb = raw + MM::kTnBytes / 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -1913,8 +1496,6 @@ __global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void tn_colgroup_k(
       for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
   // loads only (no stores in the loop): clamped and branch-free, rows past the end are zeroed below.
-  // (Two tiles in flight were tried for split mode: hipcc then waits vmcnt(0) on the newer prefetch
-  // and the kernel gets slower; DEPTH stays 1.)
   constexpr int DEPTH = 1;
   float4 pa[DEPTH][8], pb[DEPTH][8];
   auto prefetch = [&](float4 (&qa)[8], float4 (&qb)[8], int64_t tile) __attribute__((always_inline)) {
@@ -1935,22 +1516,12 @@ __global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void tn_colgroup_k(
       if (!ok) qa[it] = f4(0.f);
       const float4 av = qa[it];
       c0 += (double)av.x; c1 += (double)av.y; c2 += (double)av.z; c3 += (double)av.w;
-      if (!MM::kSplit) {
-        st4(as + MM::row(lrow, it) * FP + lc4, av);
-        st4(bs + MM::row(lrow, it) * FP + lc4, qb[it]);
-      }
-    }
-    if (MM::kSplit) {
-      Split8 sp;
-      split_rows(qa, sp);
-      stage_cols(ta, lrow, lc4, sp);
-      split_rows(qb, sp);
-      stage_cols(tb, lrow, lc4, sp);
+      st4(as + MM::row(lrow, it) * FP + lc4, av);
+      st4(bs + MM::row(lrow, it) * FP + lc4, qb[it]);
     }
     __syncthreads();
     prefetch(qa, qb, tile + DEPTH);
-    if (MM::kSplit) mma_tn64_b3<true>(ta, tb, tn, wn, wc, li, lg);
-    else mma_tn64(as, bs, tn, wn, wc, li, lg);
+    mma_tn64(as, bs, tn, wn, wc, li, lg);
   };
   if (tb0 < tb1) {
 #pragma unroll
@@ -1977,130 +1548,6 @@ __global__ __launch_bounds__(kBlock, MM::kSplit ? 1 : 2) void tn_colgroup_k(
     for (int k = 0; k < 8; ++k) s_ += red[k * FH + tid];
     partials[(size_t)(cg * nslot + slot) * FH + tid] = s_;
   }
-}
-
-// Split-mode TN with 32-row tiles: 61 KB of LDS and < 256 VGPRs, so two workgroups share a CU and one's
-// split / transposition VALU work runs under the other's MFMAs (with 64-row tiles and one workgroup per
-// CU the matrix pipe was 26 % busy).  A thread owns rows 8*wave .. +7 x columns 2*lane, 2*lane+1 of both
-// operands (float2 loads, 512 B per row and wave); column c = 2*cp + j is kept in slot 64*j + cp, so the
-// two ds_write_b128 per operand and image go to 64 consecutive slots and a fragment read of slots
-// 32*blk .. +31 is conflict-free at pitch 40 (5 sixteen-byte units).  MFMA block blk, index i therefore
-// stands for column 64*(blk & 1) + 2*i + (blk >> 1).
-constexpr int TR3 = 32;                 // rows per tile
-constexpr int TP3 = TR3 + 8;            // bf16 pitch of a slot
-constexpr int TIMG3 = FH * TP3;         // elements per transposed image
-
-__device__ __forceinline__ int colmap32(int blk, int i) { return 64 * (blk & 1) + 2 * i + (blk >> 1); }
-
-__global__ __launch_bounds__(kBlock, 2) void tn_colgroup32_b3_k(
-    int64_t M, const float* __restrict__ A, int64_t lda, int ncg, const float* __restrict__ B,
-    float* __restrict__ slab, double* __restrict__ partials, int nslot, int64_t tiles_per_slot) {
-  __shared__ __attribute__((aligned(16))) __bf16 ta[3 * TIMG3];
-  __shared__ __attribute__((aligned(16))) __bf16 tb[3 * TIMG3];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lg = lane >> 5;
-  const int wn = wave >> 1, wc = wave & 1;
-  const int xcd = blockIdx.x % kXcds, jj = blockIdx.x / kXcds;      // see tn_colgroup_k
-  const int cg = jj % ncg, slot = xcd * (nslot / kXcds) + jj / ncg;
-  const int64_t ntiles = (M + TR3 - 1) / TR3;
-  const int64_t tb0 = (int64_t)slot * tiles_per_slot;
-  const int64_t tb1 = min(ntiles, tb0 + tiles_per_slot);
-  const int64_t Mlast = M - 1;
-  floatx16 tn[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
-  double c0 = 0.0, c1 = 0.0;            // column sums of A for columns 2*lane, 2*lane + 1
-  float2 pa[8], pb[8];
-  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
-    const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * TR3 + 8 * wave;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int64_t r = clampi(r0 + it, Mlast);
-      pa[it] = *reinterpret_cast<const float2*>(A + r * lda + cg * FH + 2 * lane);
-      pb[it] = *reinterpret_cast<const float2*>(B + r * FH + 2 * lane);
-    }
-  };
-  // 8 rows x 2 columns of one operand -> its three transposed images
-  auto stage = [&](__bf16* img, const float2 (&v)[8]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bf16x8 h, m, l;
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const float x = j ? v[it].y : v[it].x;
-        const __bf16 hh = (__bf16)x;
-        const float r1 = x - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        h[it] = hh;
-        m[it] = mm;
-        l[it] = (__bf16)(r1 - (float)mm);
-      }
-      __bf16* o = img + (64 * j + lane) * TP3 + 8 * wave;
-      *reinterpret_cast<bf16x8*>(o) = h;
-      *reinterpret_cast<bf16x8*>(o + TIMG3) = m;
-      *reinterpret_cast<bf16x8*>(o + 2 * TIMG3) = l;
-    }
-  };
-  if (tb0 < tb1) prefetch(tb0);
-  for (int64_t tile = tb0; tile < tb1; ++tile) {
-    const int64_t r0 = tile * TR3 + 8 * wave;
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      if (r0 + it >= M) pa[it] = make_float2(0.f, 0.f);
-      c0 += (double)pa[it].x;
-      c1 += (double)pa[it].y;
-    }
-    stage(ta, pa);
-    stage(tb, pb);
-    __syncthreads();
-    prefetch(tile + 1);
-    const __bf16* qa = ta + ((2 * wn) * 32 + li) * TP3 + 8 * lg;
-    const __bf16* qb = tb + ((2 * wc) * 32 + li) * TP3 + 8 * lg;
-#pragma unroll
-    for (int kc = 0; kc < TR3 / 16; ++kc) {
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) {
-          a[x][s_] = *reinterpret_cast<const bf16x8*>(qa + s_ * TIMG3 + x * 32 * TP3 + 16 * kc);
-          b[x][s_] = *reinterpret_cast<const bf16x8*>(qb + s_ * TIMG3 + x * 32 * TP3 + 16 * kc);
-        }
-#pragma unroll
-      for (int t_ = 0; t_ < 6; ++t_) {
-        const int sa = t_ == 0 ? 2 : (t_ == 2 || t_ == 3) ? 1 : 0;
-        const int sb = t_ == 1 ? 2 : (t_ == 2 || t_ == 4) ? 1 : 0;
-        mfb(tn[0][0], a[0][sa], b[0][sb]);
-        mfb(tn[0][1], a[0][sa], b[1][sb]);
-        mfb(tn[1][0], a[1][sa], b[0][sb]);
-        mfb(tn[1][1], a[1][sa], b[1][sb]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  float* sl = slab + (size_t)(cg * nslot + slot) * FH * FH;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = colmap32(2 * wn + a, (e & 3) + 8 * (e >> 2) + 4 * lg);
-        const int c = colmap32(2 * wc + b, li);
-        sl[n * FH + c] = tn[a][b][e];
-      }
-  __syncthreads();
-  double* red = reinterpret_cast<double*>(ta);          // [4 waves][128] doubles
-  red[wave * FH + 2 * lane] = c0;
-  red[wave * FH + 2 * lane + 1] = c1;
-  __syncthreads();
-  if (tid < FH) partials[(size_t)(cg * nslot + slot) * FH + tid] = red[tid] + red[FH + tid] + red[2 * FH + tid] + red[3 * FH + tid];
 }
 
 // out[i] = sum_b slab[b][i], fixed order -> deterministic
@@ -2158,31 +1605,17 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
                        double* partials, hipStream_t st);
 }
-static int g_tn_variant = 1;     // split mode: 1 = tn_tr_k (transpose reads), 0 = tn_colgroup32_b3_k (round 1)
-static int g_eb_variant = 1;     // split mode: 1 = edge_bwd_tr_k (16-row tiles, two workgroups per CU), 0 = edge_bwd_fused_k<MmB3>
+// kernel-generation switches for same-process A/B runs (gnm_debug_set_variant, GNM_VARIANTS).  Round 5 removed the generations
+// that had lost their A/B (the round-1 split-mode edge backward / weight gradient / VALU encoders, the unpipelined t kernels,
+// the role-split chained kernel): their numbers are in profiles/r02_ab_kernels.txt, r03_chain_phases.txt, r04_ab_*.txt.
+static int g_eb_variant = 1;     // edge_bwd_tr_k: 1 = LDS stash + pinned prefetch (default), 2 = registers, unpinned (within 1 %)
 namespace gnm {
 int eb_variant() { return g_eb_variant; }
-static int g_chain_variant = 0;  // chained edge backward: 0 = edge_bwd_chain_k (phases in lock step), 1 = edge_bwd_chain2_k (matrix / gather roles: 3 % slower)
-int chain_variant() { return g_chain_variant; }
-static int g_enc_bwd = 1;        // edge encoder backward: 1 = fp32-MFMA kernel, 0 = VALU kernel (round 1)
-int enc_bwd_variant() { return g_enc_bwd; }
-static int g_t_pipe = 1;         // H = 128 forward t kernel: 1 = edge_t32_b3p_k (next tile staged inside the matrix phase: 14.9 -> 14.3 ms per step; the same recipe
-                                 // bought nothing in the node projections: 11.6 ms either way), 0 = edge_t32_b3_k
-int t_pipe_variant() { return g_t_pipe; }
-static int g_wide_pipe = 1;      // H = 256 forward t kernel: 1 = next tile staged inside the matrix phase, 0 = phases one after the other
-static int g_enc_fwd = 1;        // edge encoder forward: 1 = fp32-MFMA kernel, 0 = VALU kernel
-int enc_fwd_variant() { return g_enc_fwd; }
 static int g_tn_s3_occ = 2;      // tn_tr_k with a pre-split B: built for 2 or 3 workgroups per CU
 int tn_s3_occ_variant() { return g_tn_s3_occ; }
 }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
-  if (what && !strcmp(what, "tn")) { g_tn_variant = v; return 0; }
   if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
-  if (what && !strcmp(what, "chain")) { g_chain_variant = v; return 0; }
-  if (what && !strcmp(what, "enc_bwd")) { g_enc_bwd = v; return 0; }
-  if (what && !strcmp(what, "enc_fwd")) { g_enc_fwd = v; return 0; }
-  if (what && !strcmp(what, "wide_pipe")) { g_wide_pipe = v; return 0; }
-  if (what && !strcmp(what, "t_pipe")) { g_t_pipe = v; return 0; }
   if (what && !strcmp(what, "tn_s3_occ")) { g_tn_s3_occ = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
@@ -2208,12 +1641,8 @@ static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, cons
   GNM_LAUNCH_CHECK("pack_w (NT)");
   if constexpr (MM::kSplit) {
     const int64_t ntiles = cdiv_(E, ER3);
-    const int grid = persistent_grid(ntiles, 8, occ_blocks<edge_t32_b3_k>());
-    if (t_pipe_variant())
-      hipLaunchKernelGGL(edge_t32_b3p_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
-                         partials, cdiv_(ntiles, grid));
-    else
-      hipLaunchKernelGGL(edge_t32_b3_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+    const int grid = persistent_grid(ntiles, 8, occ_blocks<edge_t32_b3p_k>());
+    hipLaunchKernelGGL(edge_t32_b3p_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
                        partials, cdiv_(ntiles, grid));
     GNM_LAUNCH_CHECK("edge_t_fused_fwd");
     *nblk_out = grid;
@@ -2242,12 +1671,8 @@ extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const f
     int nchunk = num_cus() / 2 / kXcds * kXcds;            // one 8-wave workgroup per CU, two classes per chunk
     if (nchunk < kXcds) nchunk = kXcds;
     if (nchunk > kMaxPartialBlocks) nchunk = kMaxPartialBlocks / kXcds * kXcds;
-    if (g_wide_pipe)
-      hipLaunchKernelGGL(edge_t32_h256p_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
-                         partials, nchunk, cdiv_(ntiles, nchunk));
-    else
-      hipLaunchKernelGGL(edge_t32_h256_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
-                         partials, nchunk, cdiv_(ntiles, nchunk));
+    hipLaunchKernelGGL(edge_t32_h256p_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                       partials, nchunk, cdiv_(ntiles, nchunk));
     GNM_LAUNCH_CHECK("edge_t_fused_fwd (256)");
     *nblk_out = nchunk;
     return 0;
@@ -2458,7 +1883,7 @@ static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const 
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
   int grid;
-  if (MM::kSplit && g_eb_variant >= 1) {
+  if constexpr (MM::kSplit) {
     grid = edge_bwd_tr_launch(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, ws, slab, partials, st);
     GNM_LAUNCH_CHECK("edge_bwd_fused (tr)");
     hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
@@ -2467,17 +1892,10 @@ static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const 
   }
   launch_pack<MM>(W3, FH, FH / 32, 1, ws, st);
   GNM_LAUNCH_CHECK("pack_w (NN)");
-  if constexpr (MM::kSplit) {
-    const int64_t ntiles = cdiv_(E, FTR);
-    grid = persistent_grid(ntiles, 4, occ_blocks<edge_bwd_fused_k<MM>>());
-    hipLaunchKernelGGL(edge_bwd_fused_k<MM>, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
-                       gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
-  } else {
-    const int64_t ntiles = cdiv_(E, FTR2);
-    grid = persistent_grid(ntiles, 8, occ_blocks<edge_bwd_fused32_k>());
-    hipLaunchKernelGGL(edge_bwd_fused32_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
-                       gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
-  }
+  const int64_t ntiles = cdiv_(E, FTR2);
+  grid = persistent_grid(ntiles, 8, occ_blocks<edge_bwd_fused32_k>());
+  hipLaunchKernelGGL(edge_bwd_fused32_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
+                     gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
   GNM_LAUNCH_CHECK("edge_bwd_fused");
   hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
   GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
@@ -2501,9 +1919,9 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
                         double* partials, float* slab, void* stream, int max_blocks_per_cu = 0, const void* Bs3 = nullptr,
                         const TnConv* cv = nullptr) {
   hipStream_t st = (hipStream_t)stream;
-  const bool tr = (g_matmul_mode && g_tn_variant == 1) || Bs3 || cv;
-  const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : g_matmul_mode ? TR3 : FTR);
-  int occ = tr ? tn_tr_occupancy(Bs3 != nullptr, cv != nullptr) : g_matmul_mode ? occ_blocks<tn_colgroup32_b3_k>() : occ_blocks<tn_colgroup_k<MmF32>>();
+  const bool tr = g_matmul_mode || Bs3 || cv;            // split mode: tn_tr_k (transpose reads); fp32-MFMA mode: tn_colgroup_k
+  const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : FTR);
+  int occ = tr ? tn_tr_occupancy(Bs3 != nullptr, cv != nullptr) : occ_blocks<tn_colgroup_k<MmF32>>();
   if (max_blocks_per_cu > 0 && occ > max_blocks_per_cu) occ = max_blocks_per_cu;    // the caller shares the CUs with another stream
   int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
@@ -2514,9 +1932,6 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
     tn_tr_launch(N, A, lda, ncg, Bs3, -1, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv);
   else if (tr)
     tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv);
-  else if (g_matmul_mode)
-    hipLaunchKernelGGL(tn_colgroup32_b3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
-                       nslot, cdiv_(ntiles, nslot));
   else
     hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
                        nslot, cdiv_(ntiles, nslot));

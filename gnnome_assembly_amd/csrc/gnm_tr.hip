@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
 
   if (tb0 < tb1) prefetch(tb0);
   // throw-away stores behind the first prefetch make the loop-entry scoreboard equal to the back edge's (counted
-  // vmcnt instead of vmcnt(0): see edge_bwd_fused_k in gnm_fused.hip), into a slab behind the gridDim.x result slabs
+  // vmcnt instead of vmcnt(0): see rowtile_nt_k in gnm_fused.hip), into a slab behind the gridDim.x result slabs
 #pragma unroll
   for (int it = 0; it < 2; ++it) st4(slab + (size_t)(gridDim.x + chunk) * SW * SW + (lrow + 8 * it) * SW + lc4, f4(0.f));
   for (int64_t tile = tb0; tile < nfull; ++tile) body(tile_tag<true>{}, tile);
@@ -431,7 +431,6 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
 }
 
 int eb_variant();   // gnm_fused.hip
-int chain_variant();
 size_t edge_bwd_tr_pack_bytes() { return (size_t)(SW / 16) * (SW / 32) * 3 * 64 * sizeof(bf16x8); }
 // returns the grid size (= number of slabs / partial rows written)
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
