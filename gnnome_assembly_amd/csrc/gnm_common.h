@@ -197,6 +197,35 @@ __device__ __forceinline__ void block_stat_store(Stat4& s, double* lds, double* 
   }
 }
 
+// out[i] = sum_b slab[b][i] for the 128 consecutive elements i0 .. i0+127 of this workgroup (256 threads), fixed order ->
+// deterministic.  `total` (elements per slab) is a multiple of 128.
+// Round 5: the weight-gradient kernels leave one [128,128] slab per workgroup (256-512 of them, 16-32 MB); the first version of
+// this reduction gave every output element ONE thread that walked all slabs in four chains -- 49 k threads, ~42 dependent rounds
+// of loads 64 KB apart: 0.44 ms per call, 24 calls per step = 10.6 ms of the 166 ms step (profiles/r04_kernel_stats.csv, 5.4 % of
+// the GPU time, hidden inside the tn / chained-kernel op times).  Here a workgroup covers 128 elements with 32 float4 lanes x 8
+// slab groups (each group walks every 8th slab in four chains, ~6 rounds), and LDS adds the 8 partial sums in a fixed order.
+__device__ __forceinline__ float4 slab_reduce_128(const float* __restrict__ slab, int nslab, int64_t total, int i0, float* red /* [8][128] */) {
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const float* p = slab + i0 + c * 4;
+  float4 a0 = f4(0.f), a1 = f4(0.f), a2 = f4(0.f), a3 = f4(0.f);
+  int b = r;
+  for (; b + 24 < nslab; b += 32) {
+    a0 += ld4_nt(p + (int64_t)b * total);
+    a1 += ld4_nt(p + (int64_t)(b + 8) * total);
+    a2 += ld4_nt(p + (int64_t)(b + 16) * total);
+    a3 += ld4_nt(p + (int64_t)(b + 24) * total);
+  }
+  for (; b < nslab; b += 8) a0 += ld4_nt(p + (int64_t)b * total);
+  st4(red + r * 128 + c * 4, (a0 + a1) + (a2 + a3));
+  __syncthreads();
+  float4 s = f4(0.f);
+  if (threadIdx.x < 32) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += ld4(red + k * 128 + c * 4);
+  }
+  return s;       // valid in threads 0-31: elements i0 + 4 c .. + 3
+}
+
 #endif  // __HIPCC__
 
 }  // namespace gnm

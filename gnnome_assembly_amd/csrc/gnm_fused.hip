@@ -1550,43 +1550,22 @@ __global__ __launch_bounds__(kBlock, 2) void tn_colgroup_k(
   }
 }
 
-// out[i] = sum_b slab[b][i], fixed order -> deterministic
-__global__ void slab_reduce_k(const float* __restrict__ slab, int nslab, int total, float* __restrict__ out) {
+// out[i] = sum_b slab[b][i], fixed order -> deterministic (gnm_common.h slab_reduce_128); grid (total / 128, batch) x 256 threads
+__global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ slab, int nslab, int total, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float red[8 * 128];
   slab += (size_t)blockIdx.y * nslab * total;       // blockIdx.y = batch: its own nslab slabs -> its own `total` outputs
   out += (size_t)blockIdx.y * total;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    // four independent chains (fixed order -> still deterministic): one chain of nslab dependent loads was
-    // the fixed cost that showed on small graphs
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* p = slab + i;
-    int b = 0;
-    for (; b + 3 < nslab; b += 4) {
-      a0 += p[(size_t)b * total];
-      a1 += p[(size_t)(b + 1) * total];
-      a2 += p[(size_t)(b + 2) * total];
-      a3 += p[(size_t)(b + 3) * total];
-    }
-    for (; b < nslab; ++b) a0 += p[(size_t)b * total];
-    out[i] = (a0 + a1) + (a2 + a3);
-  }
+  const int i0 = blockIdx.x * 128;
+  const float4 s_ = slab_reduce_128(slab, nslab, total, i0, red);
+  if (threadIdx.x < 32) st4(out + i0 + threadIdx.x * 4, s_);
 }
 
-// out[m * ldc + n] = sum_b slab[b][m][n] for one 128 x 128 block, fixed order -> deterministic
-__global__ void slab_reduce_ld_k(const float* __restrict__ slab, int nslab, float* __restrict__ out, int64_t ldc) {
-  constexpr int total = FH * FH;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* p = slab + i;
-    int b = 0;
-    for (; b + 3 < nslab; b += 4) {
-      a0 += p[(size_t)b * total];
-      a1 += p[(size_t)(b + 1) * total];
-      a2 += p[(size_t)(b + 2) * total];
-      a3 += p[(size_t)(b + 3) * total];
-    }
-    for (; b < nslab; ++b) a0 += p[(size_t)b * total];
-    out[(int64_t)(i / FH) * ldc + (i % FH)] = (a0 + a1) + (a2 + a3);
-  }
+// out[m * ldc + n] = sum_b slab[b][m][n] for one 128 x 128 block (a workgroup = one row m)
+__global__ __launch_bounds__(256) void slab_reduce_ld_k(const float* __restrict__ slab, int nslab, float* __restrict__ out, int64_t ldc) {
+  __shared__ __attribute__((aligned(16))) float red[8 * 128];
+  const int m = blockIdx.x;
+  const float4 s_ = slab_reduce_128(slab, nslab, FH * FH, m * FH, red);
+  if (threadIdx.x < 32) st4(out + (int64_t)m * ldc + threadIdx.x * 4, s_);
 }
 
 }  // namespace gnm
@@ -1804,7 +1783,7 @@ static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, flo
   }
   const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st);
   GNM_LAUNCH_CHECK("edge_bwd_chain");
-  hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3_hi);
+  hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3_hi);
   GNM_LAUNCH_CHECK("edge_bwd_chain slab reduce");
   *nblk_out = grid;
   return gnm_reduce_partials(partials_hi, grid, 1, FH, gb3_hi, stream) ? -3 : 0;
@@ -1886,7 +1865,7 @@ static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const 
   if constexpr (MM::kSplit) {
     grid = edge_bwd_tr_launch(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, ws, slab, partials, st);
     GNM_LAUNCH_CHECK("edge_bwd_fused (tr)");
-    hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
+    hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
     GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
     return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
   }
@@ -1897,7 +1876,7 @@ static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const 
   hipLaunchKernelGGL(edge_bwd_fused32_k, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e,
                      gamma_e, (const void*)ws, slab, partials, cdiv_(ntiles, grid));
   GNM_LAUNCH_CHECK("edge_bwd_fused");
-  hipLaunchKernelGGL(slab_reduce_k, dim3(64), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
+  hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
   GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");
   return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
 }
@@ -1937,7 +1916,7 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
                        nslot, cdiv_(ntiles, nslot));
   GNM_LAUNCH_CHECK("tn_colgroup");
   // one launch each for all column groups (same per-element summation order as one launch per group)
-  hipLaunchKernelGGL(slab_reduce_k, dim3(64, ncg), dim3(256), 0, st, (const float*)slab, nslot, FH * FH, gW);
+  hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128, ncg), dim3(256), 0, st, (const float*)slab, nslot, FH * FH, gW);
   if (reduce_partials_batched(partials, ncg, nslot, FH, gb, stream)) return -3;
   GNM_LAUNCH_CHECK("tn_colgroup reduce");
   return 0;
@@ -1987,7 +1966,7 @@ int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64
     double* partials = (double*)((char*)ws + (size_t)ncls * nslot * FH * FH * sizeof(float));
     tn_tr_launch(K, A, lda, ncga, B, ldb, ncgb, slab, partials, nslot, cdiv_(ntiles, nslot), st);
     for (int cls = 0; cls < ncls; ++cls)
-      hipLaunchKernelGGL(slab_reduce_ld_k, dim3(64), dim3(256), 0, st, (const float*)slab + (size_t)cls * nslot * FH * FH,
+      hipLaunchKernelGGL(slab_reduce_ld_k, dim3(FH), dim3(256), 0, st, (const float*)slab + (size_t)cls * nslot * FH * FH,
                          nslot, C + (int64_t)(cls / ncgb) * FH * ldc + (cls % ncgb) * FH, ldc);
     return hipGetLastError() == hipSuccess ? 1 : -2;
   }

@@ -330,23 +330,12 @@ __global__ __launch_bounds__(kBlock, PHT == 128 ? 2 : 1) void pred_bwd_k(
   }
 }
 
-// out[i] = sum_b slab[b][i], fixed order -> deterministic
-__global__ void pred_slab_reduce_k(const float* __restrict__ slab, int nslab, int total, float* __restrict__ out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    // four independent chains (fixed order -> still deterministic): one chain of nslab dependent loads was
-    // the fixed cost that showed on small graphs
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* p = slab + i;
-    int b = 0;
-    for (; b + 3 < nslab; b += 4) {
-      a0 += p[(size_t)b * total];
-      a1 += p[(size_t)(b + 1) * total];
-      a2 += p[(size_t)(b + 2) * total];
-      a3 += p[(size_t)(b + 3) * total];
-    }
-    for (; b < nslab; ++b) a0 += p[(size_t)b * total];
-    out[i] = (a0 + a1) + (a2 + a3);
-  }
+// out[i] = sum_b slab[b][i], fixed order -> deterministic (gnm_common.h slab_reduce_128); grid total / 128 x 256 threads
+__global__ __launch_bounds__(256) void pred_slab_reduce_k(const float* __restrict__ slab, int nslab, int total, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float red[8 * 128];
+  const int i0 = blockIdx.x * 128;
+  const float4 s_ = slab_reduce_128(slab, nslab, total, i0, red);
+  if (threadIdx.x < 32) st4(out + i0 + threadIdx.x * 4, s_);
 }
 
 }  // namespace gnm
@@ -407,7 +396,8 @@ static int predictor_fused_bwd_impl(int64_t E, float* hid, const float* gscore, 
   hipLaunchKernelGGL(pred_bwd_k<PHT>, dim3(grid), dim3(kBlock), 0, st, E, hid, gscore, perm, W2, e, (const float*)wp, ge,
                      slab, partials, cdivp(ntiles, grid));
   GNM_LAUNCH_CHECK("predictor_fused_bwd");
-  hipLaunchKernelGGL(pred_slab_reduce_k, dim3(32), dim3(256), 0, st, (const float*)slab, grid, PS * PHT, gW1e);
+  static_assert((PS * PHT) % 128 == 0, "slab_reduce_128 covers 128 elements per workgroup");
+  hipLaunchKernelGGL(pred_slab_reduce_k, dim3(PS * PHT / 128), dim3(256), 0, st, (const float*)slab, grid, PS * PHT, gW1e);
   GNM_LAUNCH_CHECK("predictor_fused_bwd slab reduce");
   // gsums[0:64] = gW2, [64:128] = gb1, [128] = gb2 (129..191: zeros)
   return gnm_reduce_partials(partials, grid, 3, PS, gsums, stream) ? -3 : 0;

@@ -578,7 +578,7 @@ TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
 TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
 # when the deferred weight-gradient kernel of layer i is launched: "next" = at the head of layer i-1's iteration (beside its
 # by-source pass / conversion), "now" = right after layer i's own by-source pass or conversion (beside nn(i), node(i-1))
-TN_AT = os.environ.get("GNM_TN_AT", "next")
+TN_AT = os.environ.get("GNM_TN_AT", "now")       # round 5 (NODE_FUSED): "now" 161.4 vs "next" 163.2 ms/step, profiles/r05_ab_tn_at.txt
 # "next" only: the deferred kernel in TWO launches sized to the two HBM-bound windows of an iteration -- the gB1h | gB2h column groups
 # beside this layer's conversion (node_bgrad), the gA1h | gA2h | gA3h groups AFTER this layer's nn (both matrix bound: side by side
 # they only take turns) beside the next layer's BatchNorm_h backward.  GNM_TN_SPLIT=0: one launch at the head of the iteration.
