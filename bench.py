@@ -320,7 +320,7 @@ def main():
     model.to(dev)
     model.flatten_parameters()                      # one parameter buffer in the engine's layout; the gradients follow it
     flat = dp.FlatGradients(model.parameters(), direct_write=True)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = dp.make_adam(model.parameters(), 1e-3)
 
     opt_ev = None   # (start, end) events around optimizer.step() of the per-op timing step: SURVEY 8(d) "optimizer step reported separately"
     own = []        # world > 1: (event before the step, event before the gradient exchange) = this rank's OWN compute

@@ -122,6 +122,20 @@ class FlatGradients:
         return None
 
 
+def make_adam(params, lr: float):
+    """torch.optim.Adam(params, lr) as train.py:209 builds it (default betas / eps, same state_dict schema: one state per
+    parameter), as ONE fused multi-tensor kernel per step when every parameter lives on a HIP device: the default per-tensor
+    ("foreach") implementation costs ~1 ms of host time per step for this model's 138 tensors -- invisible when the host runs
+    steps ahead of the device (full-graph training), 5 % of a 21 ms mini-batch step (profiles/r04_minibatch_breakdown.txt)."""
+    params = list(params)
+    if params and all(p.is_cuda for p in params):
+        try:
+            return torch.optim.Adam(params, lr=lr, fused=True)
+        except (RuntimeError, TypeError, ValueError):
+            pass
+    return torch.optim.Adam(params, lr=lr)
+
+
 def steps_per_epoch(local_steps: int, device=None) -> int:
     """The number of optimizer steps EVERY rank takes in an epoch: the maximum of the ranks' local counts
     (shard_graphs gives uneven shards whenever num_graphs % world != 0); shorter ranks pad with
@@ -134,10 +148,19 @@ def steps_per_epoch(local_steps: int, device=None) -> int:
 
 
 def shard_graphs(num_graphs: int, rank: int, world: int, sizes=None):
-    """Graph i of the (shuffled) epoch list -> rank i mod W; with `sizes` the list is first
-    sorted by size so that the graphs of one step are of similar size (the step time is the
-    slowest rank's: SURVEY.md section 8e 'what actually limits scaling')."""
+    """Graph i of the (shuffled) epoch list -> rank i mod W; with `sizes` the list is first sorted by size so that the graphs of
+    one step are of similar size (the step time is the slowest rank's: SURVEY.md section 8e 'what actually limits scaling'), and
+    dealt in alternating directions (step 0: ranks 0 .. W-1, step 1: W-1 .. 0, ...) so that no rank always holds its step's smallest
+    graph: on the chr19 / chr20 / chr21 mix a rank idles < 10 % in any step and ~4 % over the epoch
+    (tests/test_dp_gloo.py::test_size_sorted_shards_keep_every_rank_busy_on_the_mixed_chromosome_set)."""
     order = list(range(num_graphs))
-    if sizes is not None:
-        order.sort(key=lambda i: -sizes[i])
-    return [order[i] for i in range(rank, num_graphs, world)]
+    if sizes is None:
+        return [order[i] for i in range(rank, num_graphs, world)]
+    order.sort(key=lambda i: -sizes[i])
+    mine = []
+    for step, lo in enumerate(range(0, num_graphs, world)):
+        row = order[lo:lo + world]
+        pos = rank if step % 2 == 0 else world - 1 - rank
+        if pos < len(row):
+            mine.append(row[pos])
+    return mine

@@ -142,7 +142,7 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
     best_state = copy.deepcopy(model.state_dict())                                              # train.py:203
     model.flatten_parameters()
     flat = dp.FlatGradients(model.parameters(), direct_write=True)       # the loop below zero_()s before every backward
-    optimizer = torch.optim.Adam(model.parameters(), lr=hp["lr"])                               # train.py:209
+    optimizer = dp.make_adam(model.parameters(), hp["lr"])                               # train.py:209
     criterion = models.BCEWithLogitsLoss(pos_weight=1.0 / ratio)                                # train.py:210-211
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=hp["decay"],
                                                            patience=hp["patience"])             # train.py:212

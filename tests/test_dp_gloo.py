@@ -108,7 +108,7 @@ def test_size_sorted_shards_keep_every_rank_busy_on_the_mixed_chromosome_set():
     1 : 1.073 : 0.731 (evaluate.py:28-30: 61.7 / 66.2 / 45.1 Mb at the same coverage) and simulated replicas by a few per cent
     (load imbalance, not xGMI, is what limits scaling).  With shard_graphs(sizes=...) -- sort by size, deal
     round-robin -- the W graphs of every step are neighbours in the sorted list: every rank's idle fraction stays below 10 % in
-    every step and below 3 % over the epoch; dealt in dataset order the same set leaves ranks up to a third idle."""
+    every step and below 5 % over the epoch; dealt in dataset order the same set leaves ranks up to a third idle."""
     from gnnome_assembly_amd import dp
     rng = np.random.default_rng(5)
     world = 8
@@ -129,7 +129,7 @@ def test_size_sorted_shards_keep_every_rank_busy_on_the_mixed_chromosome_set():
     w_plain, e_plain = idle(False)
     print(f"idle fraction, worst rank and step / worst rank over the epoch: size-sorted {w_sorted:.3f} / {e_sorted:.3f}, "
           f"dataset order {w_plain:.3f} / {e_plain:.3f}")
-    assert w_sorted < 0.10 and e_sorted < 0.06
+    assert w_sorted < 0.10 and e_sorted < 0.05
     assert w_plain > 0.25
 
 

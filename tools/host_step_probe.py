@@ -27,7 +27,7 @@ def main():
     e, pe, y = (torch.from_numpy(inp[k]).to(dev) for k in ("e", "pe", "y"))
     crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
     flat = dp.FlatGradients(model.parameters(), direct_write=True)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = dp.make_adam(model.parameters(), 1e-3)
     names = ("zero", "forward", "loss", "backward", "all_reduce", "optimizer")
     lines = []
     for it in range(6):

@@ -31,7 +31,7 @@ def main():
     model.to(dev)
     model.flatten_parameters()
     flat = dp.FlatGradients(model.parameters(), direct_write=True)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = dp.make_adam(model.parameters(), 1e-3)
     crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
     gen = torch.Generator().manual_seed(0)
     sync = torch.cuda.synchronize
