@@ -75,6 +75,37 @@ def _branch_exact_or_fail(bad, exact, bgmax, what, floor=None):
                        f"relu branches the device took: {[(b, exact[b[0]]) for b in still]}")
 
 
+def _oracle_grads(z, sd, dtype, batch_norm=True):
+    from oracle import gatedgcn_oracle as orc
+    p = sd_to_torch(sd, dtype, requires_grad=True)
+    s = orc.model_forward(p, torch.from_numpy(z["src"]), torch.from_numpy(z["dst"]), int(z["n"]),
+                          torch.from_numpy(z["e_raw"]).to(dtype), torch.from_numpy(z["pe"]).to(dtype), batch_norm)
+    orc.bce_loss(s, torch.from_numpy(z["y"]).to(dtype), float(z["pos_weight"])).backward()
+    return {k: v.grad.double().numpy() for k, v in p.items()}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _report(rows, path=None):
+    txt = "\n".join(f"{name:28s} rel_l2={r:.3e} max_abs={m:.3e} ref_norm={n:.3e}" for name, r, m, n in rows)
+    print(txt)
+    os.makedirs("gpurun_out", exist_ok=True)
+    if path:
+        with open(os.path.join("gpurun_out", path), "w") as f:
+            f.write(txt + "\n")
+    return txt
+
+
+def _cmp(name, got, want, rows):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = want.detach().cpu().double().numpy() if torch.is_tensor(want) else np.asarray(want, np.float64)
+    assert got.shape == want.shape, f"{name}: {got.shape} vs {want.shape}"
+    rows.append((name, rel_l2(got, want), float(np.abs(got - want).max()), float(np.linalg.norm(want))))
+
+
 # -----------------------------------------------------------------------------------------
 # library / GEMM
 # -----------------------------------------------------------------------------------------

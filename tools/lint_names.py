@@ -32,8 +32,11 @@ def check(path):
 
 
 def main():
-    files = sys.argv[1:] or [os.path.join(REPO, "gnnome_assembly_amd", f) for f in sorted(os.listdir(os.path.join(REPO, "gnnome_assembly_amd")))
-                             if f.endswith(".py")] + [os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py")]
+    pkg = os.path.join(REPO, "gnnome_assembly_amd")
+    files = sys.argv[1:] or ([os.path.join(pkg, f) for f in sorted(os.listdir(pkg)) if f.endswith(".py")]
+                             + [os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py")]
+                             + [os.path.join(REPO, d, f) for d in ("tests", "tools") for f in sorted(os.listdir(os.path.join(REPO, d)))
+                                if f.endswith(".py")])
     rc = 0
     for f in files:
         for fn, line, name in check(f):
