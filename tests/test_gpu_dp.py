@@ -130,7 +130,7 @@ def test_bench_two_ranks_on_one_device(tmp_path):
 def test_train_loop_under_two_ranks_mixed_chromosomes(tmp_path):
     """BASELINE.json configs[3] in miniature, EXECUTED: gnnome_assembly_amd.train.train (the counterpart of the
     reference's loop, train.py:232-281,379-529) under world = 2 on the HIP path, three training graphs at
-    chr19 : chr20 : chr21 relative sizes (evaluate.py:28-30) sharded 2 + 1 (one padded step per epoch), one
+    chr19 : chr20 : chr21 relative sizes (evaluate.py:28-30) sharded 1 + 2 (one padded step per epoch), one
     validation graph on rank 0 only, two epochs, patience 0.  Checks: broadcast initial weights + matched collectives
     (replicas bit-equal after every epoch), the first exchanged gradient == mean of the oracle gradients of the two
     graphs of that step, identical validation losses / LR schedule / best epoch on both ranks, files from rank 0 only,
@@ -147,9 +147,10 @@ def test_train_loop_under_two_ranks_mixed_chromosomes(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
     j = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
     z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
-    # shards: size-sorted round robin of (chr19, chr20, chr21) = sizes (1, 1.073, 0.731): rank 0 [chr20, chr21], rank 1 [chr19]
-    assert j[0]["shard"] == [1, 2] and j[1]["shard"] == [0] and j[0]["valid_shard"] == [0] and j[1]["valid_shard"] == []
-    assert len(j[0]["step_graph"]) == 2 * epochs and len(j[1]["step_graph"]) == epochs      # rank 1 pads one step per epoch
+    # shards: size-sorted, dealt in alternating directions, of (chr19, chr20, chr21) = sizes (1, 1.073, 0.731): step 0 = (chr20, chr19)
+    # to ranks (0, 1), step 1 = (chr21) dealt from the other end: rank 0 [chr20], rank 1 [chr19, chr21]
+    assert j[0]["shard"] == [1] and j[1]["shard"] == [0, 2] and j[0]["valid_shard"] == [0] and j[1]["valid_shard"] == []
+    assert len(j[0]["step_graph"]) == epochs and len(j[1]["step_graph"]) == 2 * epochs      # rank 0 pads one step per epoch
     # replicas bit-equal after every epoch and at the end
     assert len(j[0]["epoch_hashes"]) == epochs and j[0]["epoch_hashes"] == j[1]["epoch_hashes"]
     assert np.array_equal(z[0]["final"], z[1]["final"]) and list(z[0]["order"]) == list(z[1]["order"])
