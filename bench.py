@@ -97,6 +97,11 @@ def op_model(op: str, N: int, E: int, H: int):
         "gnm_node_proj_fwd": (6 * nh, 2.0 * N * H * 5 * H),                # h in, P out
         "gnm_node_proj_bwd_nn": (7 * nh, 2.0 * N * H * 5 * H),             # gP, gh_out in; gh_in out
         "gnm_node_proj_bwd_tn": (6 * nh, 2.0 * N * H * 5 * H),             # gP, h_in in
+        # round 5 (engine.NODE_FUSED): node_bgrad in the operand load of the gB1h | gB2h weight gradient; node_bwd_stats of the layer
+        # below in the projection backward's epilogue; the other three column groups' weight gradient
+        "gnm_tn128_bgrad": (7 * nh, 2.0 * N * H * 2 * H),                  # Us, Ts, Ud, Td, h_in in; gB1h, gB2h out
+        "gnm_node_proj_bwd_nn_stats": (8 * nh, 2.0 * N * H * 5 * H),       # gP, gh_out, z(below) in; gh_in out
+        "gnm_tn128[3]": (4 * nh, 2.0 * N * H * 3 * H),                     # gz | gA2h | gA3h, h_in in
         "gnm_edge_encoder_fwd": (eh, 0.0),
         "gnm_edge_encoder_bwd": (eh, 0.0),
         "gnm_node_bwd_apply": (7 * nh, 0.0),                  # z, gh_out, inv_f, inv_b in; gz, Qf, Qb out
@@ -120,17 +125,19 @@ def op_model(op: str, N: int, E: int, H: int):
 # The committed PMC pass (tools/collect_traffic.sh + tools/traffic_summary.py): HBM bytes per kernel launch on
 # this workload.  PMC counters cannot be collected from inside this process, so the bench line carries the
 # number together with `traffic_source`; C-ABI op -> rocprof kernel name(s) of the op in each matmul mode.
-TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
 OP_KERNELS = {
-    "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_fused_k<MmB3>", "edge_bwd_tr_k"]},
+    "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_tr_k<3>", "edge_bwd_tr_k"]},
     "gnm_edge_bwd_chain": ["edge_bwd_chain_k"], "gnm_edge_bwd_chain_src": ["edge_bwd_chain_k"],
     "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true, true, 128>"], "gnm_node_bgrad": ["node_bgrad_k<128>"], "gnm_edge_bwd_top": ["edge_bwd_chain_k"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
     "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128, true>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
-    "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3p_k", "edge_t32_b3_k"]},
+    "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3p_k"]},
     "gnm_node_proj_fwd": {"f32": ["rowtile_nt_k<MmF32, false, 5>"], "bf16x3": ["rowtile_nt_k<MmB3, false, 1>"]},
     "gnm_node_proj_bwd_nn": {"f32": ["rowtile_nn_acc_k<MmF32>"], "bf16x3": ["rowtile_nn_group32_b3_k<4>"]},
-    "gnm_node_proj_bwd_tn": {"f32": ["tn_colgroup_k<MmF32>"], "bf16x3": ["tn_colgroup32_b3_k", "tn_tr_k"]},
+    "gnm_node_proj_bwd_tn": {"f32": ["tn_colgroup_k<MmF32>"], "bf16x3": ["tn_tr_k<false, false, 2>"]},
+    "gnm_tn128_bgrad": ["tn_tr_k<false, true, 2>"], "gnm_tn128[3]": ["tn_tr_k<false, false, 2>"],
+    "gnm_node_proj_bwd_nn_stats": ["rowtile_nn2_k<4>"],
     "gnm_node_bwd_apply": ["node_bwd_apply_k<128>"], "gnm_node_bwd_stats": ["node_bwd_stats_k<128>"],
     "gnm_node_update_fwd": ["node_update_fwd_k<128, true>"],
 }

@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -132,12 +134,33 @@ def induced_subgraph(graph: AssemblyGraph, node_mask: torch.Tensor) -> AssemblyG
     return sub
 
 
+def _graph_tensors(sub: AssemblyGraph):
+    """every device tensor a sub-graph owns: edges, index, sweep plans, features"""
+    out = [t for t in (sub._src_t, sub._dst_t, sub._nrank_t) if torch.is_tensor(t)]
+    for d in list(sub._dev_index.values()) + [p for p in sub._plans.values() if p] + [sub.ndata, sub.edata]:
+        out += [t for t in d.values() if torch.is_tensor(t)]
+    return out
+
+
+PREFETCH = os.environ.get("GNM_BATCH_PREFETCH", "1") != "0"
+
+
 class ClusterBatchLoader:
     """Iterates the mini-batches of one graph: `batch_size` clusters per batch, clusters shuffled when
-    `shuffle` (DataLoader(..., shuffle=True, drop_last=False)); yields induced subgraphs."""
+    `shuffle` (DataLoader(..., shuffle=True, drop_last=False)); yields induced subgraphs.
+
+    prefetch (default on a HIP device; GNM_BATCH_PREFETCH=0 turns it off): batch k+1 -- its induced sub-graph, its index and both
+    sweep plans -- is built on a SIDE stream while the caller's kernels of batch k run (the reference gets the same overlap from
+    DataLoader(num_workers=4), train.py:293).  Building a sub-graph ends in host synchronisations (torch.nonzero: the sub-graph's
+    sizes are launch arguments); on the caller's stream each of them waits for the whole previous training step and the device
+    then idles while the host issues the next one -- and the ~2 ms of index / plan kernels (one wave per sweep workgroup, latency
+    bound) sit on the critical path of a 21 ms step.  On the side stream the synchronisations wait for the small build kernels
+    only, which run in the gaps of the training kernels.  The caller's stream waits for the build's event before it touches the
+    batch; every tensor of the batch is handed over with record_stream, so the caching allocator does not recycle it under the
+    training kernels."""
 
     def __init__(self, graph: AssemblyGraph, part: np.ndarray, batch_size: int, shuffle: bool = True,
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, prefetch: Optional[bool] = None):
         if batch_size < 1:
             raise ValueError("batch_size must be >= 1")
         self.graph = graph
@@ -146,6 +169,8 @@ class ClusterBatchLoader:
         self.batch_size = batch_size
         self.shuffle = shuffle
         self.generator = generator
+        self.prefetch = (PREFETCH if prefetch is None else bool(prefetch)) and graph.device.type == "cuda"
+        self._side = None
 
     def __len__(self) -> int:
         return (self.num_parts + self.batch_size - 1) // self.batch_size
@@ -154,9 +179,42 @@ class ClusterBatchLoader:
         ids = torch.randperm(self.num_parts, generator=self.generator) if self.shuffle else torch.arange(self.num_parts)
         return [ids[i:i + self.batch_size] for i in range(0, self.num_parts, self.batch_size)]
 
+    def _build(self, ids: torch.Tensor) -> AssemblyGraph:
+        dev = self.graph.device
+        sel = torch.zeros(self.num_parts, dtype=torch.bool, device=dev)
+        sel[ids.to(dev)] = True
+        return induced_subgraph(self.graph, sel[self.part.long()])
+
     def __iter__(self) -> Iterator[AssemblyGraph]:
         dev = self.graph.device
-        for ids in self.batches():
-            sel = torch.zeros(self.num_parts, dtype=torch.bool, device=dev)
-            sel[ids.to(dev)] = True
-            yield induced_subgraph(self.graph, sel[self.part.long()])
+        batches = self.batches()
+        if not self.prefetch:
+            for ids in batches:
+                yield self._build(ids)
+            return
+        self.graph.index(dev)                       # the parent's index (cached) before anything runs on the side stream
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            side.wait_stream(main)                  # the parent graph's tensors are ready
+
+            def build(ids):
+                with torch.cuda.stream(side):
+                    sub = self._build(ids)
+                    sub.index(dev)
+                    if hasattr(sub, "sweep_plan"):
+                        sub.sweep_plan(dev, 1)
+                        sub.sweep_plan(dev, 2)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                for t in _graph_tensors(sub):
+                    t.record_stream(main)
+                return sub, ev
+            nxt = build(batches[0]) if batches else None
+            for k in range(len(batches)):
+                sub, ev = nxt
+                main.wait_event(ev)
+                yield sub                           # the caller issues batch k's kernels, then asks for the next batch:
+                nxt = build(batches[k + 1]) if k + 1 < len(batches) else None       # built while those kernels run

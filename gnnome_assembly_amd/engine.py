@@ -756,14 +756,14 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             _call("gnm_tn128_bgrad", N, H, _ptr(UT), _ptr(Ud), _ptr(Td), Ud.stride(0), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]), _ptr(gP),
                   _ptr(s.h_in) if s.hs_in is None else C.c_void_p(0), _ptr(s.hs_in), _ptr(g["W5"][3 * H:]), _ptr(g["b5"][3 * H:]),
-                  _ptr(sc.partials), _ptr(ws), need_t, st, tag="gnm_node_proj_bwd_tn")
+                  _ptr(sc.partials), _ptr(ws), need_t, st)
             del Ud, Td, Q
             UT = None
             if i > 0:
                 s_j = ensure(i - 1)[1]
                 nblk_h = C.c_int(0)
                 _call("gnm_node_proj_bwd_nn_stats", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(s_j.z),
-                      _ptr(s_j.stat_h), _ptr(sc.partials), C.byref(nblk_h), _ptr(ws), need_p, st, tag="gnm_node_proj_bwd_nn")
+                      _ptr(s_j.stat_h), _ptr(sc.partials), C.byref(nblk_h), _ptr(ws), need_p, st)
             else:
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
             if side is not None and TN_AT == "now":             # tn012(i) right away, beside node(i-1)'s [N,H] passes
@@ -774,7 +774,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                 pending = (gP, s.h_in, s.hs_in, g["W5"], g["b5"])
             else:       # no side stream (lean activations, per-op timing) or the last iteration: the same launch on this stream
                 tn128(N, gP, 5 * H, 3, s.h_in, s.hs_in, g["W5"], g["b5"], sc.partials if nblk_h is None else sc3.partials,
-                      sc.ws(max(need_p, need_f, need_t)) if nblk_h is None else sc3.ws(need_t), need_t, tag="gnm_node_proj_bwd_tn")
+                      sc.ws(max(need_p, need_f, need_t)) if nblk_h is None else sc3.ws(need_t), need_t, tag="gnm_tn128[3]")
         else:
             src_cap = 0
             if pending is not None:
