@@ -14,6 +14,7 @@ import contextlib
 import ctypes as C
 import functools
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -41,23 +42,31 @@ _OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC
                  "PRESPLIT", "PRESPLIT_L0", "NODE_FUSED")
 
 
+_options_lock = threading.RLock()
+
+
 @contextlib.contextmanager
 def options(**kw):
     """Temporarily change schedule switches of this module (FUSED, ACTIVATIONS, CHAIN, TN_SIDE, TN_SIDE_CAP, SRC_SIDE_CAP, TN_AT,
-    TWO_SIDED, TWO_SIDED_FWD) and restore them on exit, whatever happens inside:
+    TN_SPLIT, TWO_SIDED, TWO_SIDED_FWD, WIDE_FUSED, PRESPLIT, PRESPLIT_L0, NODE_FUSED) and restore them on exit, whatever happens
+    inside:
         with engine.options(TWO_SIDED=False, CHAIN=False): ...
-    The switches select between schedules that compute the same thing (tests and bench.py A/B them); they are process-wide,
-    read at call time by the thread that runs the pass -- one training loop per process, as everywhere on this path."""
+    The switches select between schedules that compute the same thing (tests and bench.py A/B them).  They are process-wide and
+    read at call time by the thread that runs the pass; the context holds a re-entrant lock for its whole body, so a second
+    thread that enters options() waits until the first has restored its values -- two threads can never see a mixture of each
+    other's settings (nested use by one thread is fine).  A pass that runs OUTSIDE any options() block sees whatever is current:
+    the supported pattern is one training loop per process (as everywhere on this path), switches set once at start-up."""
     bad = [k for k in kw if k not in _OPTION_NAMES]
     if bad:
         raise _lib.GnmError(f"engine.options: unknown switch {bad}; known: {_OPTION_NAMES}")
     g = globals()
-    old = {k: g[k] for k in kw}
-    try:
-        g.update(kw)
-        yield
-    finally:
-        g.update(old)
+    with _options_lock:
+        old = {k: g[k] for k in kw}
+        try:
+            g.update(kw)
+            yield
+        finally:
+            g.update(old)
 
 
 def set_activation_mode(mode: str) -> None:

@@ -1,10 +1,10 @@
 # Round artifacts on the GPU box (run through gpurun): everything that is copied into profiles/ afterwards.
-#   TAG=r04 tools/collect_round_artifacts.sh          (FAST=1: skip the full GPU test tier and the sweeps)
+#   TAG=r05 tools/collect_round_artifacts.sh          (FAST=1: skip the full GPU test tier and the sweeps)
 set -x
-T=${TAG:-r04}; O=gpurun_out/$T; mkdir -p $O
+T=${TAG:-r05}; O=gpurun_out/$T; mkdir -p $O
 if [ -z "$FAST" ]; then
   python -m pytest tests -q -m gpu > $O/gputest.log 2>&1; tail -3 $O/gputest.log
-  cp gpurun_out/logit_parity_fullsize.txt gpurun_out/rccl_smoke.log gpurun_out/grad_clauses.json $O/ 2>/dev/null
+  cp gpurun_out/logit_parity_fullsize.txt gpurun_out/grad_parity_fullsize.txt gpurun_out/rccl_smoke.log gpurun_out/grad_clauses.json gpurun_out/grad_clauses.txt gpurun_out/cabi_host_step.txt gpurun_out/dp2_train_config4.log $O/ 2>/dev/null
   python -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "test_model_matches_golden" 2>&1 | grep "logits rel_l2" > $O/logit_parity.txt
 fi
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
@@ -14,17 +14,24 @@ OUTDIR=traffic tools/collect_traffic.sh > $O/traffic.log 2>&1
 python tools/traffic_summary.py gpurun_out/traffic $O/traffic.json $(cat .git_head) > $O/traffic.txt 2>&1
 BENCH=1 tools/pmc_run.sh $T --no-alt-orders > $O/sq_pmc_bench.txt 2>&1
 python tools/minibatch_epoch.py > $O/minibatch.log 2>&1; cp gpurun_out/minibatch.json $O/ 2>/dev/null
+python tools/minibatch_breakdown.py > $O/minibatch_breakdown.txt 2>&1
 if [ -z "$FAST" ]; then
   OUTDIR=traffic_shuf EXTRA="--shuffle-nodes" tools/collect_traffic.sh > $O/traffic_shuf.log 2>&1
   python tools/traffic_summary.py gpurun_out/traffic_shuf $O/traffic_shuffled.json $(cat .git_head) > $O/traffic_shuffled.txt 2>&1
   for R in 110000 375000 500000 1000000; do python bench.py --reads $R --steps 5 --warmup 2 --no-cpu-baseline --no-alt-orders > $O/train_R$R.json 2>/dev/null; done
   for R in 750000 3000000; do python bench.py --reads $R --inference --steps 5 --warmup 2 --no-cpu-baseline > $O/infer_R$R.json 2>/dev/null; done
   python bench.py --hidden 256 --reads 375000 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-matmul --no-alt-orders > $O/h256.json 2>/dev/null
-  for m in "0 0 0" "1 0 0" "1 0 1" "1 1 1"; do set -- $m; GNM_WIDE_FUSED=$1 GNM_TWO_SIDED=$2 GNM_TWO_SIDED_FWD=$3 python bench.py --hidden 256 --reads 375000 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-matmul --no-alt-orders 2>/dev/null | python -c "
-import json,sys;b=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('H=256 wide_fused=$1 two_sided_bwd=$2 two_sided_fwd=$3', round(b['ms_per_step'],2), 'ms/step;', {k:round(v,2) for k,v in b['op_ms'].items() if v>5})" >> $O/h256_steps.txt; done
+  python bench.py --hidden 256 --layers 16 --reads 110000 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-matmul --no-alt-orders > $O/h256_l16.json 2>/dev/null
   python bench.py --shuffle-nodes --steps 10 --warmup 3 --no-cpu-baseline --no-alt-matmul > $O/bench_shuffled_nodes.json 2>/dev/null
   python tools/minibatch_epoch.py --shuffle-nodes > $O/minibatch_shuffled.log 2>&1; cp gpurun_out/minibatch_shuffled.json $O/ 2>/dev/null
-  for m in "1 1" "0 1" "1 0" "0 0"; do set -- $m; GNM_TWO_SIDED=$1 GNM_TWO_SIDED_FWD=$2 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt-matmul --no-alt-orders 2>/dev/null | python -c "
-import json,sys;b=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('two_sided_bwd=$1 two_sided_fwd=$2', round(b['ms_per_step'],2), 'ms/step;', {k:round(v,2) for k,v in b['op_ms'].items() if v>2.5})" >> $O/ab_two_sided.txt; done
+  # same-box A/B of the round-5 node-side switches against the round-4 schedule (three alternating runs)
+  B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt-matmul --no-alt-orders"
+  ab() { name=$1; shift; env "$@" $B 2>/dev/null | python -c "
+import json,sys;b=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$name', round(b['ms_per_step'],2), 'ms/step;', {k:round(v,2) for k,v in b['op_ms'].items() if v>3.0})" >> $O/ab_node_side_final.txt; }
+  for i in 1 2 3; do
+    ab "round 5 (NODE_FUSED, TN_AT=now)" GNM_X=1
+    ab "round-4 schedule (NODE_FUSED=0, TN_AT=next)" GNM_NODE_FUSED=0 GNM_TN_AT=next
+  done
+  ab "round 5 + PRESPLIT" GNM_PRESPLIT=1
 fi
 ls -la $O
