@@ -91,6 +91,10 @@ SIGNATURES = {
     "gnm_tn128_workspace_bytes": (_sz, []),
     "gnm_tn128": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_tn128_s3": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_compose_workspace_bytes": (_sz, [_i32]),
+    "gnm_compose_partials_doubles": (_sz, []),
+    "gnm_layer_forward": (_i32, [_p, _i32, _p, _p, _p, _p]),                          # struct pointers: see include/gnm.h
+    "gnm_stack_backward": (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_decode_build_adjacency": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p]),
     "gnm_decode_iteration": (_i64, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _i64, _p]),
     "gnm_reduce_partials": (_i32, [_p, _i32, _i32, _i32, _p, _p]),

@@ -467,6 +467,51 @@ int gnm_edge_feats_zscore(int64_t E, const float* overlap_length, const float* o
 int gnm_bce_fwd_bwd(int64_t E, const float* scores, const float* y, float pos_weight,
                     float* loss_out, float* gscore, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- composite entry points (ABI 5): the measured path's launch sequences behind one call each -------------------------
+ * For hosts that do not want to schedule the kernels themselves (a C++ trainer, a Go / Rust / Java binding).  Host code only:
+ * every arithmetic step is one of the entry points above, called in the order the Python engine calls them on ONE stream, so
+ * the results are the engine's bit for bit (tests/cabi/host_step.cpp runs both and compares).  H = 128, BatchNorm mode.  Memory
+ * stays the caller's: every output, intermediate and scratch buffer is passed in (device pointers unless noted).
+ *   gnm_layer_forward    GatedGCN_1d.forward (gated_gcn_full.py:99-157): projections, t + BatchNorm_e statistics, the
+ *                        two-sided gate sweep (or, without a forward plan, gate + by-source pass), BatchNorm_h, node update.
+ *   gnm_stack_backward   autograd of L stacked layers (processor.py:15-20 reversed; train.py:257): gh = dL/dh_out(L-1) (read),
+ *                        ge = dL/de_out(L-1), UPDATED IN PLACE to dL/de_in(0); gh_in = dL/dh_in(0); parameter gradients into
+ *                        gr[i].  The chained two-sided schedule (bf16x3 mode; needs the backward sweep plan).
+ * gnm_graph_view: the internal index (gnm_graph_build_index) and the sweep plans (gnm_graph_build_sweep_plan over
+ * gnm_sweep_partition(N, 2) for the forward, (N, 1) for the backward; fwd_sinfo == NULL: no forward plan).
+ * gnm_layer_state: a layer's inputs and everything its forward leaves for its backward (h_out / e_out of layer i are
+ * h_in / e_in of layer i+1).  gnm_scratch: partials* hold gnm_compose_partials_doubles() doubles each, ws / ws2 hold
+ * gnm_compose_workspace_bytes(H) bytes each (partials2, partials3, ws2: gnm_stack_backward only).                        */
+typedef struct gnm_graph_view {
+  int64_t N, E;
+  const int32_t *isrc, *idst, *in_ptr, *out_ptr, *out_pos, *out_dst;
+  const uint32_t *fwd_sinfo, *fwd_dinfo; int64_t fwd_nodes_per_block, fwd_nfix; const int32_t* fwd_fix_nodes;
+  const uint32_t* bwd_sinfo; int64_t bwd_nodes_per_block, bwd_nfix; const int32_t* bwd_fix_nodes;
+} gnm_graph_view;
+typedef struct gnm_layer_weights { const float *W5, *b5, *W3, *b3, *gamma_e, *beta_e, *gamma_h, *beta_h; } gnm_layer_weights;
+typedef struct gnm_layer_state {
+  const float *h_in, *e_in;                                   /* [N,H], [E,H] (internal edge order) */
+  float *P, *t, *e_out;                                       /* [N,5H], [E,H], [E,H] */
+  float *hf, *inv_f, *hb, *inv_b, *z, *h_out;                 /* [N,H] each */
+  float *stat_e, *stat_h;                                     /* [4,H] each */
+} gnm_layer_state;
+typedef struct gnm_layer_grads { float *gW5, *gb5, *gW3, *gb3, *g_gamma_e, *g_beta_e, *g_gamma_h, *g_beta_h; } gnm_layer_grads;
+typedef struct gnm_backward_work {
+  float* gP[2];                                               /* [N,5H] each */
+  float *Q, *UT, *DT;                                         /* [N,2H] each */
+  float* gh_tmp[2];                                           /* [N,H] each */
+  float* bstat_e[2];                                          /* [2,H] each */
+  float* bstat_h;                                             /* [2,H] */
+} gnm_backward_work;
+typedef struct gnm_scratch { double *partials, *partials2, *partials3; void* ws; size_t ws_bytes; void* ws2; size_t ws2_bytes; } gnm_scratch;
+size_t gnm_compose_workspace_bytes(int H);
+size_t gnm_compose_partials_doubles(void);
+int gnm_layer_forward(const gnm_graph_view* g, int H, const gnm_layer_weights* w, const gnm_layer_state* s, const gnm_scratch* sc,
+                      void* stream);
+int gnm_stack_backward(const gnm_graph_view* g, int H, int L, const gnm_layer_weights* w, const gnm_layer_state* s,
+                       const gnm_layer_grads* gr, const float* gh, float* ge, float* gh_in, const gnm_backward_work* wk,
+                       const gnm_scratch* sc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

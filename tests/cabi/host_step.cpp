@@ -10,6 +10,7 @@
 //   backward:    gnm_node_bwd_stats, gnm_bn_bwd_finalize, gnm_node_bwd_apply, gnm_edge_bwd_top, gnm_edge_bwd_src_fix,
 //                gnm_tn128_bgrad, gnm_node_proj_bwd_nn_stats, gnm_tn128, gnm_edge_bwd_chain_src, gnm_node_proj_bwd_nn,
 //                gnm_edge_bwd_fused
+//   and once more through the composite entry points gnm_layer_forward / gnm_stack_backward (bit-identical by construction).
 // The relu decisions of the backward are the DEVICE's (read back from t / z and the BatchNorm statistics): the network is
 // piecewise linear in them, so the fp64 gradients of those branches are the meaningful reference on a 3 k-node graph.
 //   hipcc --offload-arch=gfx950 -std=c++17 -I include tests/cabi/host_step.cpp -L gnnome_assembly_amd -lgnm
@@ -392,6 +393,61 @@ int main() {
   }
   check("gh_in(0)", to_host(d_ghin, (size_t)N * H), G[0].gh_in, 5e-5);
   check("ge_in(0)", edges_to_caller(d_ge), G[0].ge_in, 5e-5);
+  // ---- the same two layers through the COMPOSITE entry points (gnm_layer_forward x 2, gnm_stack_backward): one call per layer
+  //      forward, one for the whole backward; same kernels in the same order -> bit-identical to the explicit sequence above ----
+  {
+    gnm_graph_view gv{};
+    gv.N = N; gv.E = E; gv.isrc = d_isrc; gv.idst = d_idst; gv.in_ptr = d_inp; gv.out_ptr = d_outp; gv.out_pos = d_opos; gv.out_dst = d_odst;
+    gv.fwd_sinfo = plan[2].d_s; gv.fwd_dinfo = plan[2].d_d; gv.fwd_nodes_per_block = plan[2].npb; gv.fwd_nfix = plan[2].nfix; gv.fwd_fix_nodes = plan[2].d_fix;
+    gv.bwd_sinfo = plan[1].d_s; gv.bwd_nodes_per_block = plan[1].npb; gv.bwd_nfix = plan[1].nfix; gv.bwd_fix_nodes = plan[1].d_fix;
+    gnm_layer_weights W[2];
+    gnm_layer_state S[2];
+    gnm_layer_grads Gr[2];
+    for (int l = 0; l < 2; ++l) {
+      const DevLayer& d = L[l];
+      W[l] = gnm_layer_weights{d.W5, d.b5, d.W3, d.b3, d.gam_e, d.bet_e, d.gam_h, d.bet_h};
+      gnm_layer_state& q = S[l];
+      q.P = dev_alloc<float>((size_t)N * 5 * H); q.t = dev_alloc<float>((size_t)E * H); q.e_out = dev_alloc<float>((size_t)E * H);
+      q.hf = dev_alloc<float>((size_t)N * H); q.inv_f = dev_alloc<float>((size_t)N * H); q.hb = dev_alloc<float>((size_t)N * H);
+      q.inv_b = dev_alloc<float>((size_t)N * H); q.z = dev_alloc<float>((size_t)N * H); q.h_out = dev_alloc<float>((size_t)N * H);
+      q.stat_e = dev_alloc<float>(4 * H); q.stat_h = dev_alloc<float>(4 * H);
+      Gr[l] = gnm_layer_grads{dev_alloc<float>((size_t)5 * H * H), dev_alloc<float>(5 * H), dev_alloc<float>((size_t)H * H), dev_alloc<float>(H),
+                              dev_alloc<float>(H), dev_alloc<float>(H), dev_alloc<float>(H), dev_alloc<float>(H)};
+    }
+    S[0].h_in = L[0].h_in; S[0].e_in = L[0].e_in; S[1].h_in = S[0].h_out; S[1].e_in = S[0].e_out;
+    const size_t np2 = gnm_compose_partials_doubles(), wb2 = gnm_compose_workspace_bytes(H);
+    gnm_scratch sc{dev_alloc<double>(np2), dev_alloc<double>(np2), dev_alloc<double>(np2), dev_alloc<char>(wb2), wb2, dev_alloc<char>(wb2), wb2};
+    gnm_backward_work wk{};
+    wk.gP[0] = dev_alloc<float>((size_t)N * 5 * H); wk.gP[1] = dev_alloc<float>((size_t)N * 5 * H);
+    wk.Q = dev_alloc<float>((size_t)N * 2 * H); wk.UT = dev_alloc<float>((size_t)N * 2 * H); wk.DT = dev_alloc<float>((size_t)N * 2 * H);
+    wk.gh_tmp[0] = dev_alloc<float>((size_t)N * H); wk.gh_tmp[1] = dev_alloc<float>((size_t)N * H);
+    wk.bstat_e[0] = dev_alloc<float>(2 * H); wk.bstat_e[1] = dev_alloc<float>(2 * H); wk.bstat_h = dev_alloc<float>(2 * H);
+    float *c_gh = to_dev(gh_top), *c_ge = to_dev(to_internal(ge_top)), *c_ghin = dev_alloc<float>((size_t)N * H);
+    GNM_OK(gnm_layer_forward(&gv, H, &W[0], &S[0], &sc, st));
+    GNM_OK(gnm_layer_forward(&gv, H, &W[1], &S[1], &sc, st));
+    GNM_OK(gnm_stack_backward(&gv, H, 2, W, S, Gr, c_gh, c_ge, c_ghin, &wk, &sc, st));
+    HIP_OK(hipStreamSynchronize(st));
+    int diff = 0;
+    auto same = [&](const char* what, const float* a, const float* b, size_t n) {
+      const vf x = to_host(a, n), y = to_host(b, n);
+      size_t bad = 0;
+      for (size_t k = 0; k < n; ++k) bad += !(x[k] == y[k]);
+      if (bad) { std::printf("  composite %-22s differs in %zu of %zu elements  <-- FAIL\n", what, bad, n); ++diff; }
+    };
+    same("h_out(1)", S[1].h_out, L[1].h_out, (size_t)N * H);
+    same("e_out(1)", S[1].e_out, L[1].e_out, (size_t)E * H);
+    for (int l = 0; l < 2; ++l) {
+      same("gW5", Gr[l].gW5, L[l].gW5, (size_t)5 * H * H); same("gb5", Gr[l].gb5, L[l].gb5, 5 * H);
+      same("gW3", Gr[l].gW3, L[l].gW3, (size_t)H * H); same("gb3", Gr[l].gb3, L[l].gb3, H);
+      same("g bn_e.weight", Gr[l].g_gamma_e, L[l].g_gam_e, H); same("g bn_e.bias", Gr[l].g_beta_e, L[l].g_bet_e, H);
+      same("g bn_h.weight", Gr[l].g_gamma_h, L[l].g_gam_h, H); same("g bn_h.bias", Gr[l].g_beta_h, L[l].g_bet_h, H);
+    }
+    same("gh_in(0)", c_ghin, d_ghin, (size_t)N * H);
+    same("ge_in(0)", c_ge, d_ge, (size_t)E * H);
+    std::printf("composite entry points (gnm_layer_forward x 2 + gnm_stack_backward): %s the explicit launch sequence\n",
+                diff ? "DIFFER from" : "bit-identical to");
+    fails += diff;
+  }
   std::printf("C-ABI host, measured path: N=%lld E=%lld H=%d L=2: %d mismatches\n", (long long)N, (long long)E, H, fails);
   if (fails) { std::printf("FAIL\n"); return 1; }
   std::printf("OK\n");
