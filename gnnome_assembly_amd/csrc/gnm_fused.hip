@@ -1592,13 +1592,10 @@ namespace gnm {
 int eb_variant() { return g_eb_variant; }
 static int g_tn_s3_occ = 2;      // tn_tr_k with a pre-split B: built for 2 or 3 workgroups per CU
 int tn_s3_occ_variant() { return g_tn_s3_occ; }
-static int g_proj16 = 0;         // node projections: 1 = node_proj16_k (eight waves on 16-column blocks), 0 = rowtile_nt_k<MmB3, false, 1>
-int node_proj16_launch(int64_t N, int ncols, const float* h, const float* W, const float* b, float* Pout, void* ws, hipStream_t st);
 }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
   if (what && !strcmp(what, "tn_s3_occ")) { g_tn_s3_occ = v; return 0; }
-  if (what && !strcmp(what, "proj16")) { g_proj16 = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }
@@ -1715,11 +1712,6 @@ extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, co
   GNM_CHECK_ARG(H == FH, "node_proj_fwd: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(N > 0 && ncols == 5 * FH && h && W && b && Pout, "node_proj_fwd: bad argument (ncols must be 5*128)");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd: workspace too small");
-  if (g_matmul_mode && g_proj16) {
-    const int rc = node_proj16_launch(N, ncols, h, W, b, Pout, ws, (hipStream_t)stream);
-    GNM_LAUNCH_CHECK("node_proj_fwd (16-column blocks)");
-    return rc;
-  }
   return g_matmul_mode ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
                        : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
 }

@@ -977,149 +977,6 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   return grid;
 }
 
-// ------------------------------------------------------------------------------------------
-// node_proj16_k (round 5, an experiment behind gnm_debug_set_variant("proj16", 1)): the node projections P[:, cg] = h W5_cg^T + b5
-// (gated_gcn_full.py:107-112) with EIGHT waves per workgroup on 16-column blocks.  rowtile_nt_k<MmB3, false, 1> keeps a 32-column
-// weight block per wave (96 registers -> 256 VGPRs, two workgroups = two waves per SIMD) and its matrix pipe is 60 % busy: the
-// two waves of a SIMD fall into step (stage -> barrier -> MFMA -> barrier -> epilogue, both in the MFMA phase or both out of
-// it).  Here a wave owns 16 output columns (48 fragment registers, v_mfma_f32_16x16x32_bf16, four 16-row accumulators), so a
-// workgroup is 512 threads at < 128 registers and a SIMD holds FOUR waves of two workgroups; the tile image is the swizzled
-// row-major one of gnm_tr.h (no padding: 48 KB for three 64-row parts), read as in the NN half of edge_bwd_tr_k.
-// ------------------------------------------------------------------------------------------
-constexpr int PR16 = 64;                       // rows per tile
-constexpr int PIMG16 = PR16 * SPITCH;          // bytes per image (16 KB)
-constexpr int POP16 = SW + 4;                  // fp32 output image pitch (floats)
-
-// Wp[cb (16-column block)][kc][s][lane] (bf16x8): element j of lane (n = l & 15, g = l >> 4) =
-// part s of W[(16 cb + n) * ld + 32 kc + 8 g + j]      (y = x W^T: output column first)
-__global__ void pack_w3_nt16_k(const float* __restrict__ W, int64_t ld, int ncb, bf16x8* __restrict__ Wp) {
-  const int total = ncb * (SW / 32) * 64;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int lane = idx & 63, kc = (idx >> 6) % (SW / 32), cb = idx / (64 * (SW / 32));
-    const int n = lane & 15, g = lane >> 4;
-    bf16x8 hi, mid, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = W[(int64_t)(16 * cb + n) * ld + 32 * kc + 8 * g + j];
-      const __bf16 h = (__bf16)x;
-      const float r1 = x - (float)h;
-      const __bf16 m = (__bf16)r1;
-      hi[j] = h;
-      mid[j] = m;
-      lo[j] = (__bf16)(r1 - (float)m);
-    }
-    bf16x8* o = Wp + ((int64_t)(cb * (SW / 32) + kc) * 3) * 64 + lane;
-    o[0] = hi;
-    o[64] = mid;
-    o[128] = lo;
-  }
-}
-
-__global__ __launch_bounds__(512, 4) void node_proj16_k(int64_t M, const float* __restrict__ X, const bf16x8* __restrict__ Wp,
-                                                        const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
-                                                        int64_t tiles_per_block, int ncgs) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PIMG16];
-  float* os = reinterpret_cast<float*>(lds);                   // the fp32 output image overlays the parts after the MFMAs
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0 .. 7: output columns 16 wave .. + 15 of this class's group
-  const int xcd = blockIdx.x % kXcds, jb = blockIdx.x / kXcds;
-  const int cgb = jb % ncgs;
-  const int chunk = xcd * (gridDim.x / ncgs / kXcds) + jb / ncgs;
-  const int64_t ntiles = (M + PR16 - 1) / PR16;
-  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
-  const int64_t tb1 = tb0 + tiles_per_block < ntiles ? tb0 + tiles_per_block : ntiles;
-  const int64_t nfull = tb1 < M / PR16 ? tb1 : M / PR16;
-  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;             // coalesced tile image: 16 rows x 32 float4 per pass, 4 passes
-  const int64_t Mlast = M - 1;
-  W3Frag16 wf;
-  {
-    const bf16x8* p = Wp + ((int64_t)((cgb * 8 + wave) * (SW / 32)) * 3) * 64 + lane;
-#pragma unroll
-    for (int kc = 0; kc < SW / 32; ++kc)
-#pragma unroll
-      for (int s_ = 0; s_ < 3; ++s_) wf.w[kc][s_] = p[(kc * 3 + s_) * 64];
-  }
-  const int ni = lane & 15, ng = lane >> 4;
-  const int nnb = ni * SPITCH + ((((ni & 3) << 2) | (ng ^ (swz(ni) & 3))) << 4);    // see edge_bwd_tr_k
-  float4 pre[4];
-  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
-    const int64_t r0 = tile * PR16;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      int64_t r = r0 + lrow + 16 * it;
-      r = r < Mlast ? r : Mlast;
-      pre[it] = ld4(X + r * SW + lc4);
-    }
-  };
-  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(tag)::full;
-    __syncthreads();                 // the previous tile's epilogue is done with the output image
-#pragma unroll
-    for (int it = 0; it < 4; ++it) simg_stage(lds, PIMG16, lrow + 16 * it, lc4, pre[it]);
-    __syncthreads();
-    const int64_t r0 = tile * PR16;
-    prefetch(tile + 1 < tb1 ? tile + 1 : tile);
-    floatx4_acc acc[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = floatx4_acc{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < SW / 32; ++kc) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        bf16x8 fa[3];
-#pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_)
-          fa[s_] = *reinterpret_cast<const bf16x8*>(lds + s_ * PIMG16 + rb * 16 * SPITCH + (nnb ^ (kc << 6)));
-        mfb16s(acc[rb], fa[2], wf.w[kc][0]);
-        mfb16s(acc[rb], fa[0], wf.w[kc][2]);
-        mfb16s(acc[rb], fa[1], wf.w[kc][1]);
-        mfb16s(acc[rb], fa[1], wf.w[kc][0]);
-        mfb16s(acc[rb], fa[0], wf.w[kc][1]);
-        mfb16s(acc[rb], fa[0], wf.w[kc][0]);
-      }
-    }
-    __syncthreads();                 // every wave is done reading the parts
-    // C layout of the 16 x 16 MFMA: lane (n = l & 15, g = l >> 4) holds rows 4 g .. 4 g + 3 of column n
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) os[(16 * rb + 4 * ng + r) * POP16 + 16 * wave + ni] = acc[rb][r];
-    __syncthreads();
-    const float4 b4 = ld4(bias + cgb * SW + lc4);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = lrow + 16 * it;
-      const int64_t grow = r0 + row;
-      const float4 v = ld4(os + row * POP16 + lc4) + b4;
-      if (FULL || grow < M) st4(Y + grow * ldy + cgb * SW + lc4, v);
-    }
-  };
-  if (tb0 < tb1) prefetch(tb0);
-  if (tb0 < nfull) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) st4(Y + (tb0 * PR16 + lrow + 16 * it) * ldy + cgb * SW + lc4, f4(0.f));   // scoreboard equalisation, see rowtile_nt_k
-    for (int64_t tile = tb0; tile < nfull; ++tile) body(tile_tag<true>{}, tile);
-  }
-  if (nfull < tb1 && nfull >= tb0) body(tile_tag<false>{}, nfull);
-}
-
-// ws: ncols / 16 fragment blocks of pack_w3_nt16_k (same bytes as the 32-column packs)
-int node_proj16_launch(int64_t N, int ncols, const float* h, const float* W, const float* b, float* Pout, void* ws, hipStream_t st) {
-  const int ncg = ncols / SW;
-  hipLaunchKernelGGL(pack_w3_nt16_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)SW, ncols / 16, (bf16x8*)ws);
-  const int64_t ntiles = (N + PR16 - 1) / PR16;
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, node_proj16_k, 512, 0) != hipSuccess || occ < 1) occ = 2;
-  if (occ > 3) occ = 3;
-  int nslot = (num_cus() * occ) / ncg / kXcds * kXcds;
-  const int cap = (int)((ntiles + kXcds - 1) / kXcds * kXcds);
-  if (nslot > cap) nslot = cap;
-  if (nslot < kXcds) nslot = kXcds;
-  hipLaunchKernelGGL(node_proj16_k, dim3(nslot * ncg), dim3(512), 0, st, N, h, (const bf16x8*)ws, b, Pout, (int64_t)ncols,
-                     (ntiles + nslot - 1) / nslot, ncg);
-  return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
 int tn_tr_rows_per_tile() { return TRR; }
 // s3: the pre-split-B variant; built for two (208 registers) and for three (168, 14 spilled) workgroups per CU, A/B by GNM_VARIANTS
 int tn_s3_occ_variant();   // gnm_fused.hip
