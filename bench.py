@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--cpu-reads", type=int, default=75_000)
     ap.add_argument("--inference", action="store_true", help="forward only under no_grad (config 5)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
-    ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3"],
+    ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="fused-kernel matmul mode (default: GNM_MATMUL or the library default bf16x3); see include/gnm.h")
     ap.add_argument("--no-alt-matmul", action="store_true", help="skip the extra measurement in the other matmul mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores)")
@@ -162,7 +162,7 @@ def load_traffic(N, E, H, mode):
                           f"{sha} (re-run tools/collect_traffic.sh)")
     out = {}
     for op, ks in OP_KERNELS.items():
-        ks = ks[mode] if isinstance(ks, dict) else ks
+        ks = ks.get(mode, ks.get("bf16x3", [])) if isinstance(ks, dict) else ks
         hit = [d["per_launch"][k]["total_gb"] * 1e9 for k in ks if k in d["per_launch"]]
         if hit:
             out[op] = hit[0]
@@ -418,16 +418,18 @@ def main():
     alt = None
     mode = G._lib.get_matmul_mode()
     if args.matmul is None and H == 128 and not args.no_alt_matmul and not args.inference:
-        other = "f32" if mode == "bf16x3" else "bf16x3"
-        G._lib.set_matmul_mode(other)
-        step()
-        adt, aedges = timed_run(args.steps)
+        alt = []
+        for other in [m for m in ("f16x2", "bf16x3", "f32") if m != mode]:
+            G._lib.set_matmul_mode(other)
+            step()
+            adt, aedges = timed_run(args.steps)
+            alt.append({"matmul": other, "ms_per_step": adt / args.steps * 1e3, "value": aedges * args.steps / adt, "unit": "edges/s"})
         G._lib.set_matmul_mode(mode)
-        alt = {"matmul": other, "ms_per_step": adt / args.steps * 1e3, "value": aedges * args.steps / adt,
-               "unit": "edges/s",
-               "note": "f32: every contraction on v_mfma_f32_32x32x2_f32 (fp32 operands); bf16x3: fp32 operands split "
-                       "exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate.  Both modes pass the "
-                       "whole of tests/test_gpu_parity.py"}
+        alt[0]["note"] = ("f16x2: fp32 operands as two fp16 terms of a power-of-two multiple (22 significand bits), 3 MFMAs per product, in "
+                          "the node projections, the edge t kernel and the projection backward, bf16x3 in the rest; bf16x3: fp32 operands "
+                          "split exactly into 3 bf16 terms, 6 bf16 MFMAs per product; f32: every contraction on v_mfma_f32_32x32x2_f32.  "
+                          "fp32 accumulate in all three; all three pass the whole of tests/test_gpu_parity.py; distance to the fp64 oracle "
+                          "per mode: profiles/r05_f16x2_accuracy.txt")
         dbg("alt matmul run done")
     # the "lean" activation mode (engine.set_activation_mode): one step, for its time and its peak memory
     alt_act = None
@@ -468,7 +470,7 @@ def main():
     if rank == 0:
         tot = sum(t for _, t in ops.values())
         ranked = sorted(ops.items(), key=lambda kv: -kv[1][1])
-        mm_peak = BF16_MFMA_PEAK / 6 if mode == "bf16x3" else F32_MFMA_PEAK   # fp32-equivalent FLOP/s of the mode
+        mm_peak = BF16_MFMA_PEAK / 6 if mode == "bf16x3" else BF16_MFMA_PEAK / 3 if mode == "f16x2" else F32_MFMA_PEAK   # fp32-equivalent FLOP/s of the mode
         traffic, step_traffic, traffic_src = load_traffic(n, E, H, mode)
         if args.inference:
             step_traffic = None
@@ -509,7 +511,7 @@ def main():
                       else "GatedGCN edges/sec fwd only (inference)",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16x3 split products, f32 accumulate)" if mode == "bf16x3" else "f32", "data": "synthetic",
+            "dtype": {"bf16x3": "f32 (bf16x3 split products, f32 accumulate)", "f16x2": "f32 (f16x2 split products, f32 accumulate)"}.get(mode, "f32"), "data": "synthetic",
             "config": {"workload": f"synthetic chr19-scale assembly graph per GPU: R={R} reads, N={n} nodes, "
                                    f"E={E} edges, hidden={H}, layers={L}, BCE fwd+bwd + Adam"
                                    + (f", {backend_name} grad all-reduce" if dist_on else ""),

@@ -132,7 +132,7 @@ def load():
         raise GnmError(f"libgnm.so ABI version {v}, expected {ABI_VERSION} (rebuild: python __graft_entry__.py)")
     _lib = lib
     mode = os.environ.get("GNM_MATMUL", "").strip().lower()
-    if mode:                                     # matmul mode of the fused kernels (gnm.h); library default: bf16x3
+    if mode:                                     # matmul mode of the fused kernels (gnm.h); library default: f16x2
         if mode not in MATMUL_MODES:
             raise GnmError(f"GNM_MATMUL={mode!r}: expected one of {sorted(MATMUL_MODES)}")
         check(lib.gnm_set_matmul_mode(MATMUL_MODES[mode]), "gnm_set_matmul_mode")
@@ -142,18 +142,26 @@ def load():
     return lib
 
 
-MATMUL_MODES = {"f32": 0, "fp32": 0, "bf16x3": 1}
+MATMUL_MODES = {"f32": 0, "fp32": 0, "bf16x3": 1, "f16x2": 2}
+DEFAULT_MATMUL_MODE = "f16x2"
 
 
 def set_matmul_mode(mode: str) -> None:
-    """'bf16x3' (default: exact 3-way bf16 split, six bf16 MFMAs per product, fp32 accumulate) or 'f32' (fp32 MFMA)."""
+    """'f16x2' (default: two fp16 terms of a power-of-two multiple, 22 significand bits per operand, three MFMAs per product, in
+    the kernels that have it; bf16x3 in the rest), 'bf16x3' (exact 3-way bf16 split, six bf16 MFMAs per product, fp32
+    accumulate) or 'f32' (fp32 MFMA)."""
     if mode not in MATMUL_MODES:
         raise GnmError(f"matmul mode {mode!r}: expected one of {sorted(MATMUL_MODES)}")
     check(load().gnm_set_matmul_mode(MATMUL_MODES[mode]), "gnm_set_matmul_mode")
 
 
 def get_matmul_mode() -> str:
-    return "bf16x3" if load().gnm_get_matmul_mode() == 1 else "f32"
+    return ("f32", "bf16x3", "f16x2")[load().gnm_get_matmul_mode()]
+
+
+def split_mode() -> bool:
+    """True in the matmul modes that split fp32 operands into 16-bit terms (bf16x3, f16x2): the kernels built only for those."""
+    return load().gnm_get_matmul_mode() >= 1
 
 
 def check(rc: int, what: str = ""):

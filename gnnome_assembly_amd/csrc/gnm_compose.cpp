@@ -65,7 +65,7 @@ extern "C" int gnm_stack_backward(const gnm_graph_view* g, int H, int L, const g
                                   const gnm_layer_grads* gr, const float* gh, float* ge, float* gh_in,
                                   const gnm_backward_work* wk, const gnm_scratch* sc, void* stream) {
   GNM_TRY(check_common("stack_backward", g, H, sc));
-  GNM_CHECK_ARG(gnm_get_matmul_mode() == 1, "stack_backward: the chained schedule belongs to the bf16x3 matmul mode");
+  GNM_CHECK_ARG(gnm_get_matmul_mode() >= 1, "stack_backward: the chained schedule belongs to the split matmul modes");
   GNM_CHECK_ARG(L >= 1 && w && s && gr && gh && ge && gh_in && wk, "stack_backward: null argument");
   GNM_CHECK_ARG(g->bwd_sinfo && (g->bwd_nfix == 0 || g->bwd_fix_nodes), "stack_backward: needs the backward sweep plan "
                 "(gnm_graph_build_sweep_plan over gnm_sweep_partition(N, 1))");

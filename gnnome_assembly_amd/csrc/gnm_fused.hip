@@ -152,6 +152,7 @@ constexpr int BKC = FH / 16;        // 8 k-chunks of 16
 struct MmF32 {
   static constexpr int kImgBytes = FTR * FP * 4;
   static constexpr bool kSplit = false;
+  static constexpr bool kScaled = false;
   static constexpr size_t kPackBytes = (size_t)FKQ * 64 * 16;        // per 32-column weight block
   static constexpr int kTnBytes = 2 * FTR * FP * 4;                  // TN operands: two fp32 row images
   // tile row of the it-th float4 of thread-row lrow in the coalesced image
@@ -192,6 +193,7 @@ __device__ __forceinline__ void mfb(floatx16& acc, const bf16x8& a, const bf16x8
 struct MmB3 {
   static constexpr int kImgBytes = 3 * BIMG * 2;
   static constexpr bool kSplit = true;
+  static constexpr bool kScaled = false;
   static constexpr size_t kPackBytes = (size_t)BKC * 3 * 64 * 16;
   static __device__ __forceinline__ int row(int lrow, int it) { return 8 * lrow + it; }
   struct Frag { bf16x8 w[BKC][3]; };
@@ -247,6 +249,127 @@ struct MmB3 {
     }
   }
 };
+
+// MmH2 (gnm_set_matmul_mode(2), "f16x2"): two fp16 terms of a power-of-two multiple per operand, THREE MFMAs per product
+// (gnm_tr.h).  A tile row is scaled by its own largest magnitude when it is staged -- stage() returns 1 / s, the thread
+// that stages a row piece is the thread that stores the same piece of the result, so the factor stays in a register --
+// and a weight block carries the factors of its 32 output columns behind its fragments.
+struct MmH2 {
+  static constexpr int kImgBytes = 2 * BIMG * 2;
+  static constexpr bool kSplit = true;
+  static constexpr bool kScaled = true;
+  static constexpr size_t kFragBytes = (size_t)BKC * 2 * 64 * 16;
+  static constexpr size_t kPackBytes = kFragBytes + 32 * sizeof(float);     // + 1 / s of the block's 32 columns
+  struct Frag { h16x8 w[BKC][2]; };
+  static __device__ __forceinline__ void load_w(Frag& f, const void* Wp, int blk, int lane) {
+    const h16x8* p = reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(Wp) + (size_t)blk * kPackBytes) + lane;
+#pragma unroll
+    for (int c = 0; c < BKC; ++c)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) f.w[c][s] = p[(c * 2 + s) * 64];
+  }
+  // 1 / s of output columns c4 .. c4+3 of the 128-column group whose first block is blk0
+  static __device__ __forceinline__ float4 col_inv4(const void* Wp, int blk0, int c4) {
+    return ld4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Wp) + (size_t)(blk0 + (c4 >> 5)) * kPackBytes + kFragBytes) + (c4 & 31));
+  }
+  // called by all 32 lanes of a row together; returns the row's 1 / s
+  static __device__ __forceinline__ float stage(void* img, int row, int c4, const float4& v) {
+    float sc, inv;
+    h2_scale(row32_max_bits(max_abs4_bits(v)), sc, inv);
+    h16x4 hi, lo;
+    split2(v, sc, hi, lo);
+    _Float16* b = reinterpret_cast<_Float16*>(img) + row * BP + c4;
+    *reinterpret_cast<h16x4*>(b) = hi;
+    *reinterpret_cast<h16x4*>(b + BIMG) = lo;
+    return inv;
+  }
+  static __device__ __forceinline__ void mma(const void* img, const Frag& f, floatx16& acc0, floatx16& acc1,
+                                             int li, int lg) {
+    const _Float16* p0 = reinterpret_cast<const _Float16*>(img) + li * BP + 8 * lg;
+    const _Float16* p1 = p0 + 32 * BP;
+    h16x8 a0[2], a1[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      a0[s] = *reinterpret_cast<const h16x8*>(p0 + s * BIMG);
+      a1[s] = *reinterpret_cast<const h16x8*>(p1 + s * BIMG);
+    }
+#pragma unroll
+    for (int c = 0; c < BKC; ++c) {
+      h16x8 n0[2], n1[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        n0[s] = a0[s];
+        n1[s] = a1[s];
+        if (c + 1 < BKC) {
+          n0[s] = *reinterpret_cast<const h16x8*>(p0 + s * BIMG + 16 * (c + 1));
+          n1[s] = *reinterpret_cast<const h16x8*>(p1 + s * BIMG + 16 * (c + 1));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // smallest products first: lo*hi, hi*lo, hi*hi
+      mfh(acc0, a0[1], f.w[c][0]); mfh(acc1, a1[1], f.w[c][0]);
+      mfh(acc0, a0[0], f.w[c][1]); mfh(acc1, a1[0], f.w[c][1]);
+      mfh(acc0, a0[0], f.w[c][0]); mfh(acc1, a1[0], f.w[c][0]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { a0[s] = n0[s]; a1[s] = n1[s]; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// MM::stage for every policy: the row's 1 / s (1 where the policy does not scale)
+template <class MM>
+__device__ __forceinline__ float stage_row(void* img, int row, int c4, const float4& v) {
+  if constexpr (MM::kScaled) return MM::stage(img, row, c4, v);
+  else { MM::stage(img, row, c4, v); return 1.f; }
+}
+
+// ---- MmH2 in the row kernels whose contraction runs over SEVERAL 128-column groups (y = x W, K = ncg * 128) ----------
+// The accumulator of a row stays in registers across the groups, so its unit has to: a row keeps a REFERENCE exponent in
+// LDS that only grows (the largest magnitude of the row's groups so far); a group is staged in the unit of the new
+// reference, and the waves multiply the accumulator rows by 2^(old - new) <= 1 (exact) before they add the group's
+// products.  The weight's column factors are taken over the whole K (pack_w2_gen_k), one per output column.
+__device__ __forceinline__ void h2_stage_nn(void* img, int row, int c4, const float4& v, int* eref, float* fs, bool first,
+                                            bool writer) {
+  const unsigned mb = row32_max_bits(max_abs4_bits(v));
+  int e = (int)(mb >> 23) & 0xff;
+  e = e < 16 ? 16 : e;
+  const int eo = first ? e : *eref;          // every lane of the row reads before the row's writer stores (one wave)
+  const int en = e > eo ? e : eo;
+  if (writer) {
+    *eref = en;
+    const int fe = 127 + eo - en;
+    *fs = __int_as_float((fe < 0 ? 0 : fe) << 23);
+  }
+  h16x4 hi, lo;
+  split2(v, __int_as_float((268 - en) << 23), hi, lo);
+  _Float16* b = reinterpret_cast<_Float16*>(img) + row * BP + c4;
+  *reinterpret_cast<h16x4*>(b) = hi;
+  *reinterpret_cast<h16x4*>(b + BIMG) = lo;
+}
+// accumulator element e of lane (li, lg) is row (e & 3) + 8 (e >> 2) + 4 lg of the 32-row tile
+__device__ __forceinline__ void acc_rescale_rows(floatx16& acc, const float* fs, int lg) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 f = ld4(fs + 8 * q + 4 * lg);
+    acc[4 * q + 0] *= f.x; acc[4 * q + 1] *= f.y; acc[4 * q + 2] *= f.z; acc[4 * q + 3] *= f.w;
+  }
+}
+__device__ __forceinline__ float h2_ref_inv(int eref) { return __int_as_float((eref - 14) << 23); }
+
+__device__ __forceinline__ void mma32_h2(const void* img, int row0, const MmH2::Frag& f, floatx16& acc, int li, int lg) {
+  const _Float16* p0 = reinterpret_cast<const _Float16*>(img) + (row0 + li) * BP + 8 * lg;
+#pragma unroll
+  for (int c = 0; c < BKC; ++c) {
+    h16x8 a0[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a0[s] = *reinterpret_cast<const h16x8*>(p0 + s * BIMG + 16 * c);
+    mfh(acc, a0[1], f.w[c][0]);
+    mfh(acc, a0[0], f.w[c][1]);
+    mfh(acc, a0[0], f.w[c][0]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 // this wave's 64 x 64 block of the TN result -> sl[n][c] (128 x 128, row-major)
 template <class MM>
@@ -309,12 +432,47 @@ __global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int 
   }
 }
 
-static int g_matmul_mode = 1;   // 0: fp32 MFMA, 1: bf16x3 split (default since round 2: same parity bars, 2.7x the matrix rate)
+// f16x2 fragment pack: block cb = { h16x8 frag[c][s][lane] (s = hi/lo of W s_n), float inv[32] = 1 / s_n of its 32 output
+// columns }, s_n from the largest magnitude of the column's 128 weights (every thread of a column recomputes it: the weight
+// is 64 KB and sits in L2); element order as pack_w3_k
+__global__ void pack_w2_k(const float* __restrict__ W, int64_t ld, int ncb, int nn, unsigned char* __restrict__ Wp) {
+  const int total = ncb * BKC * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % BKC, cb = idx / (64 * BKC);
+    const int i = lane & 31, g = lane >> 5;
+    const int n = cb * 32 + i;
+    float m = 0.f;
+    for (int k = 0; k < FH; ++k) m = fmaxf(m, fabsf(nn ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k]));
+    float sc, inv;
+    h2_scale(__float_as_uint(m), sc, inv);
+    h16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * c + 8 * g + j;
+      const float x = (nn ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k]) * sc;
+      const _Float16 h = (_Float16)x;
+      hi[j] = h;
+      lo[j] = (_Float16)(x - (float)h);
+    }
+    unsigned char* blk = Wp + (size_t)cb * MmH2::kPackBytes;
+    h16x8* o = reinterpret_cast<h16x8*>(blk) + (c * 2) * 64 + lane;
+    o[0] = hi;
+    o[64] = lo;
+    if (c == 0 && g == 0) reinterpret_cast<float*>(blk + MmH2::kFragBytes)[i] = inv;
+  }
+}
+
+// 0: fp32 MFMA; 1: bf16x3 split (the default of rounds 2-4: same parity bars, 2.7x the matrix rate);
+// 2: f16x2 in the kernels that have it (MmH2: node projections, edge t, projection backward), bf16x3 in the rest -- the default
+//    since round 5: every fused step runs at the package power cap, three MFMAs per product instead of six is energy that comes
+//    back as time, and its results are no further from fp64 than those of mode 0 or 1 (profiles/r05_f16x2_accuracy.txt)
+static int g_matmul_mode = 2;
 constexpr size_t kPackBytesPerBlk = MmB3::kPackBytes;   // workspace sizing: the larger of the two
 
 template <class MM>
 static void launch_pack(const float* W, int64_t ld, int ncb, int nn, void* wp, hipStream_t st) {
-  if (MM::kSplit) hipLaunchKernelGGL(pack_w3_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (bf16x8*)wp);
+  if (MM::kScaled) hipLaunchKernelGGL(pack_w2_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (unsigned char*)wp);
+  else if (MM::kSplit) hipLaunchKernelGGL(pack_w3_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (bf16x8*)wp);
   else hipLaunchKernelGGL(pack_w_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (float*)wp);
 }
 
@@ -378,9 +536,10 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
   st.zero();
   auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(tag)::value;
+    float rsc[8];      // scaled policies: 1 / s of the rows this thread stages (and stores)
     __syncthreads();   // everyone is done with the previous tile's LDS images
 #pragma unroll
-    for (int it = 0; it < 8; ++it) MM::stage(xraw, lrow + 8 * it, lc4, pre[it]);
+    for (int it = 0; it < 8; ++it) rsc[it] = stage_row<MM>(xraw, lrow + 8 * it, lc4, pre[it]);
     if (EDGE && tid < 2 * FTR) sd[tid] = pre_idx;
     __syncthreads();
     const int64_t r0 = tile * FTR;
@@ -421,11 +580,15 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
       acc_to_lds(os, acc0, acc1, wave, li, lg);
       __syncthreads();
       const float4 b4 = ld4(bias + (cgb + cg) * FH + lc4);
+      float4 ci4 = f4(1.f);
+      if constexpr (MM::kScaled) ci4 = MM::col_inv4(Wp, (cgb + cg) * 4, lc4);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = lrow + 8 * it;
         const int64_t grow = r0 + row;
-        float4 v = ld4(os + row * FP + lc4) + b4;
+        float4 v = ld4(os + row * FP + lc4);
+        if constexpr (MM::kScaled) v = v * (ci4 * rsc[it]);      // exact: both factors are powers of two
+        v = v + b4;
         if (EDGE) v = v + g1[it] + g2[it];
         if (FULL || grow < M) {
           if (EDGE) st4_nt(Y + grow * ldy + (cgb + cg) * FH + lc4, v);
@@ -539,11 +702,14 @@ constexpr int ER3 = 32;
 // (round 4: the split / staging of tile k+1 is issued inside the matrix phase of tile k, see edge_t32_h256p_k; the kernel that ran
 //  the phases one after the other -- 14.9 against 14.3 ms per step, bit-identical -- was removed in round 5, numbers in
 //  profiles/r04_ab_kernels.txt)
+// MM = MmB3 (six MFMAs per product) or MmH2 (three; the row factors of a tile are made when it is staged, inside the matrix
+// phase of the tile before it, and used by the same thread in the tile's epilogue)
+template <class MM>
 __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
     int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
     const int32_t* __restrict__ idst, double* __restrict__ partials, int64_t tiles_per_block) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
   __shared__ float os[ER3 * FP];
   __shared__ int sd[2][2 * ER3];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -558,9 +724,12 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
   const int64_t Mlast = M - 1;
   const int32_t* const ibase = (lane & 32) ? idst : isrc;
 
-  MmB3::Frag wf;
-  MmB3::load_w(wf, Wp, wave, lane);
+  typename MM::Frag wf;
+  MM::load_w(wf, Wp, wave, lane);
   const float4 b4 = ld4(bias + lc4);
+  float4 ci4 = f4(1.f);
+  if constexpr (MM::kScaled) ci4 = MM::col_inv4(Wp, 0, lc4);
+  float rsc[2][4];                   // scaled policies: 1 / s of this thread's rows in tile buffer 0 / 1
   float4 pre[2][4];
   int pidx[2] = {0, 0};
   auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
@@ -585,7 +754,20 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
     floatx16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    {
+    if constexpr (MM::kScaled) {
+      const _Float16* p0 = reinterpret_cast<const _Float16*>(xraw) + (32 * hb + li) * BP + 8 * lg;
+#pragma unroll
+      for (int c = 0; c < BKC; ++c) {
+        h16x8 a0[2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) a0[s_] = *reinterpret_cast<const h16x8*>(p0 + s_ * BIMG + 16 * c);
+        mfh(acc, a0[1], wf.w[c][0]);
+        if (c < 4) rsc[hb ^ 1][c] = MM::stage(xraw, 32 * (hb ^ 1) + lrow + 8 * c, lc4, nbuf[c]);
+        mfh(acc, a0[0], wf.w[c][1]);
+        mfh(acc, a0[0], wf.w[c][0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
       const __bf16* p0 = reinterpret_cast<const __bf16*>(xraw) + (32 * hb + li) * BP + 8 * lg;
 #pragma unroll
       for (int c = 0; c < BKC; ++c) {
@@ -595,7 +777,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
         mfb(acc, a0[2], wf.w[c][0]);
         mfb(acc, a0[0], wf.w[c][2]);
         mfb(acc, a0[1], wf.w[c][1]);
-        if (c < 4) MmB3::stage(xraw, 32 * (hb ^ 1) + lrow + 8 * c, lc4, nbuf[c]);
+        if (c < 4) MM::stage(xraw, 32 * (hb ^ 1) + lrow + 8 * c, lc4, nbuf[c]);
         mfb(acc, a0[1], wf.w[c][0]);
         mfb(acc, a0[0], wf.w[c][1]);
         mfb(acc, a0[0], wf.w[c][0]);
@@ -612,7 +794,9 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
     for (int it = 0; it < 4; ++it) {
       const int row = lrow + 8 * it;
       const int64_t grow = r0 + row;
-      const float4 v = ld4(os + row * FP + lc4) + b4 + g1[it] + g2[it];
+      float4 v = ld4(os + row * FP + lc4);
+      if constexpr (MM::kScaled) v = v * (ci4 * rsc[hb][it]);      // exact: powers of two
+      v = v + b4 + g1[it] + g2[it];
       if (FULL || grow < M) {
         st4_nt(Y + grow * FH + lc4, v);
         st.add_prod(v, v);
@@ -623,7 +807,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_t32_b3p_k(
     prefetch(pre[0], pidx[0], tb0);
     prefetch(pre[1], pidx[1], tb0 + 1);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) MmB3::stage(xraw, lrow + 8 * it, lc4, pre[0][it]);
+    for (int it = 0; it < 4; ++it) rsc[0][it] = stage_row<MM>(xraw, lrow + 8 * it, lc4, pre[0][it]);
     sd[0][lane] = pidx[0];
     prefetch(pre[0], pidx[0], tb0 + 2);
     __syncthreads();
@@ -1171,13 +1355,15 @@ __global__ __launch_bounds__(kBlock, 1) void rowtile_nn_group_k(
 // The same with 32-row tiles: 26 KB of LDS and <= 256 VGPRs -> two workgroups per CU, so that the split
 // staging of one overlaps the MFMAs of the other.
 constexpr int NR3 = 32;
-template <int T>
+template <class MM, int T>
 __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
     int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, const void* __restrict__ Wp,
     const float* __restrict__ R, float* __restrict__ Y, int64_t groups_per_block) {
-  // the three bf16 images keep the 64-row layout of MmB3::stage; rows 0-31 / 32-63 are two tile buffers,
+  // the split images keep the 64-row layout of MM::stage; rows 0-31 / 32-63 are two tile buffers,
   // so a step needs ONE barrier (the next step stages into the half the slower waves are not reading)
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
+  __shared__ int eref[MM::kScaled ? T * NR3 : 1];                // MmH2: the rows' reference exponents (h2_stage_nn)
+  __shared__ __attribute__((aligned(16))) float fsc[MM::kScaled ? 2 * NR3 : 4];   // ... and the accumulator factors, per tile buffer
   float* xs = reinterpret_cast<float*>(xraw);                    // later: 32 x 132 fp32 output image
   static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1189,6 +1375,8 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
   const int64_t g1 = min(ngroups, g0 + groups_per_block);
   const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
   const int64_t Mlast = M - 1;
+  float4 ci4 = f4(1.f);
+  if constexpr (MM::kScaled) ci4 = MM::col_inv4(Wp, 0, lc4);      // the column factors span the whole K: block 0's serve every group
   // T steps (one whole column group of the row group) of rows in flight: a 32-row step of cheap MFMAs is
   // far shorter than the HBM latency.  pre[tl] always holds tile tl of the NEXT column group.
   float4 pre[T][4];
@@ -1210,15 +1398,25 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
     for (int cg = 0; cg < ncg; ++cg) {
-      MmB3::Frag wf;
-      MmB3::load_w(wf, Wp, cg * 4 + wave, lane);
+      typename MM::Frag wf;
+      MM::load_w(wf, Wp, cg * 4 + wave, lane);
 #pragma unroll
       for (int tl = 0; tl < T; ++tl) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        for (int it = 0; it < 4; ++it) {
+          const int row = lrow + 8 * it;
+          if constexpr (MM::kScaled) h2_stage_nn(xraw, 32 * (tl & 1) + row, lc4, pre[tl][it], eref + tl * NR3 + row, fsc + (tl & 1) * NR3 + row,
+                                                 cg == 0, (tid & 31) == 0);
+          else MM::stage(xraw, 32 * (tl & 1) + row, lc4, pre[tl][it]);
+        }
         __syncthreads();
         prefetch(pre[tl], g, cg + 1, tl);
-        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        if constexpr (MM::kScaled) {
+          if (cg > 0) acc_rescale_rows(acc[tl], fsc + (tl & 1) * NR3, lg);
+          mma32_h2(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        } else {
+          mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        }
       }
     }
 #pragma unroll
@@ -1235,7 +1433,9 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn_group32_b3_k(
       for (int it = 0; it < 4; ++it) {
         const int row = lrow + 8 * it;
         const int64_t grow = r0 + row;
-        if (grow < M) st4(Y + grow * FH + lc4, ld4(xs + row * FP + lc4) + rr[it]);
+        float4 v = ld4(xs + row * FP + lc4);
+        if constexpr (MM::kScaled) v = v * (ci4 * h2_ref_inv(eref[tl * NR3 + row]));
+        if (grow < M) st4(Y + grow * FH + lc4, v + rr[it]);
       }
     }
     __syncthreads();   // the output image overlays both tile buffers: done before the next group stages
@@ -1258,10 +1458,12 @@ struct Nn2Args {
   const float* z_lo; const float* stat_lo; double* partials;
 };
 
-template <int T>
+template <class MM, int T>
 __global__ __launch_bounds__(kBlock, 2) void rowtile_nn2_k(const Nn2Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
   __shared__ double sacc[8 * 2 * FH];      // [row slot 0..7][sum a | sum b][128 columns], one owner thread per entry
+  __shared__ int eref[MM::kScaled ? T * NR3 : 1];                // MmH2: as in rowtile_nn_group32_b3_k
+  __shared__ __attribute__((aligned(16))) float fsc[MM::kScaled ? 2 * NR3 : 4];
   float* xs = reinterpret_cast<float*>(xraw);
   static_assert(T % 2 == 0, "two tile buffers");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1275,6 +1477,8 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn2_k(const Nn2Args a) {
   const int64_t g1 = min(ngroups, g0 + a.groups_per_block);
   const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
   const int64_t Mlast = M - 1;
+  float4 ci4 = f4(1.f);
+  if constexpr (MM::kScaled) ci4 = MM::col_inv4(a.Wp, 0, lc4);
   const float* __restrict__ X = a.X;
   const int64_t ldx = a.ldx;
 #pragma unroll
@@ -1298,15 +1502,25 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn2_k(const Nn2Args a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
     for (int cg = 0; cg < ncg; ++cg) {
-      MmB3::Frag wf;
-      MmB3::load_w(wf, a.Wp, cg * 4 + wave, lane);
+      typename MM::Frag wf;
+      MM::load_w(wf, a.Wp, cg * 4 + wave, lane);
 #pragma unroll
       for (int tl = 0; tl < T; ++tl) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        for (int it = 0; it < 4; ++it) {
+          const int row = lrow + 8 * it;
+          if constexpr (MM::kScaled) h2_stage_nn(xraw, 32 * (tl & 1) + row, lc4, pre[tl][it], eref + tl * NR3 + row, fsc + (tl & 1) * NR3 + row,
+                                                 cg == 0, (tid & 31) == 0);
+          else MM::stage(xraw, 32 * (tl & 1) + row, lc4, pre[tl][it]);
+        }
         __syncthreads();
         prefetch(pre[tl], g, cg + 1, tl);
-        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        if constexpr (MM::kScaled) {
+          if (cg > 0) acc_rescale_rows(acc[tl], fsc + (tl & 1) * NR3, lg);
+          mma32_h2(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        } else {
+          mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        }
       }
     }
 #pragma unroll
@@ -1330,7 +1544,9 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn2_k(const Nn2Args a) {
       for (int it = 0; it < 4; ++it) {
         const int row = lrow + 8 * it;
         const int64_t grow = r0 + row;
-        const float4 v = ld4(xs + row * FP + lc4) + rr[it];
+        float4 v = ld4(xs + row * FP + lc4);
+        if constexpr (MM::kScaled) v = v * (ci4 * h2_ref_inv(eref[tl * NR3 + row]));
+        v = v + rr[it];
         if (grow < M) {
           st4(a.Y + grow * FH + lc4, v);
           const float4 gw = gate4(fma4(zz[it], sc, sh), v);      // node_bwd_stats_k's expressions
@@ -1460,6 +1676,36 @@ __global__ void pack_w3_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
     o[0] = hi;
     o[64] = mid;
     o[128] = lo;
+  }
+}
+
+// the same for MmH2 (block layout of pack_w2_k); a column's factor is taken over its WHOLE contraction (all ncg groups), so that
+// an accumulator that runs over the groups keeps one unit per column
+__global__ void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncls, int ncg, int nn, unsigned char* __restrict__ Wp) {
+  const int total = ncls * ncg * 4 * BKC * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % BKC, blk = idx / (64 * BKC);
+    const int wv = blk & 3, cg = (blk >> 2) % ncg, cls = (blk >> 2) / ncg;
+    const int i = lane & 31, g = lane >> 5;
+    const int64_t n = (int64_t)cls * FH + wv * 32 + i;
+    float m = 0.f;
+    for (int64_t k = 0; k < (int64_t)ncg * FH; ++k) m = fmaxf(m, fabsf(nn ? W[k * ld + n] : W[n * ld + k]));
+    float sc, inv;
+    h2_scale(__float_as_uint(m), sc, inv);
+    h16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = (int64_t)cg * FH + 16 * c + 8 * g + j;
+      const float x = (nn ? W[k * ld + n] : W[n * ld + k]) * sc;
+      const _Float16 h = (_Float16)x;
+      hi[j] = h;
+      lo[j] = (_Float16)(x - (float)h);
+    }
+    unsigned char* b = Wp + (size_t)blk * MmH2::kPackBytes;
+    h16x8* o = reinterpret_cast<h16x8*>(b) + (c * 2) * 64 + lane;
+    o[0] = hi;
+    o[64] = lo;
+    if (c == 0 && g == 0) reinterpret_cast<float*>(b + MmH2::kFragBytes)[i] = inv;
   }
 }
 
@@ -1605,7 +1851,7 @@ extern "C" int gnm_debug_set_variant(const char* what, int v) {
 extern "C" size_t gnm_rowtile_workspace_bytes(int ncols) { return (size_t)(ncols / 32) * kPackBytesPerBlk; }
 
 extern "C" int gnm_set_matmul_mode(int mode) {
-  GNM_CHECK_ARG(mode == 0 || mode == 1, "set_matmul_mode: mode %d (0 = fp32 MFMA, 1 = bf16x3 split)", mode);
+  GNM_CHECK_ARG(mode >= 0 && mode <= 2, "set_matmul_mode: mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = f16x2 split)", mode);
   g_matmul_mode = mode;
   return 0;
 }
@@ -1620,8 +1866,8 @@ static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, cons
   GNM_LAUNCH_CHECK("pack_w (NT)");
   if constexpr (MM::kSplit) {
     const int64_t ntiles = cdiv_(E, ER3);
-    const int grid = persistent_grid(ntiles, 8, occ_blocks<edge_t32_b3p_k>());
-    hipLaunchKernelGGL(edge_t32_b3p_k, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+    const int grid = persistent_grid(ntiles, 8, occ_blocks<edge_t32_b3p_k<MM>>());
+    hipLaunchKernelGGL(edge_t32_b3p_k<MM>, dim3(grid), dim3(kBlock), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
                        partials, cdiv_(ntiles, grid));
     GNM_LAUNCH_CHECK("edge_t_fused_fwd");
     *nblk_out = grid;
@@ -1657,8 +1903,9 @@ extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const f
     return 0;
   }
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(FH), "edge_t_fused_fwd: workspace too small");
-  return g_matmul_mode ? edge_t_fused_impl<MmB3>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream)
-                       : edge_t_fused_impl<MmF32>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream);
+  return g_matmul_mode == 2 ? edge_t_fused_impl<MmH2>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream)
+         : g_matmul_mode  ? edge_t_fused_impl<MmB3>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream)
+                          : edge_t_fused_impl<MmF32>(E, e_in, W3, b3, P, isrc, idst, t, partials, nblk_out, ws, stream);
 }
 
 // edge_bwd_gt + ge_out = ge + gt W3 at H = 256 (bf16x3 matmul mode), see edge_gt_nn_h256_k; ge_out != ge
@@ -1712,8 +1959,9 @@ extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, co
   GNM_CHECK_ARG(H == FH, "node_proj_fwd: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(N > 0 && ncols == 5 * FH && h && W && b && Pout, "node_proj_fwd: bad argument (ncols must be 5*128)");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd: workspace too small");
-  return g_matmul_mode ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
-                       : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
+  return g_matmul_mode == 2 ? node_proj_fwd_impl<MmH2>(N, ncols, h, W, b, Pout, ws, stream)
+         : g_matmul_mode  ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
+                          : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
 }
 
 // the same from the pre-split image of h (gnm_split_rows_s3 / gnm_node_update_fwd_s3): split matmul mode only
@@ -1752,7 +2000,7 @@ static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, flo
                                const uint32_t* sinfo, int64_t plan_nodes_per_block, float* UT_lo,
                                int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(H == FH, "edge_bwd_chain: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(g_matmul_mode == 1, "edge_bwd_chain: only built for the bf16x3 matmul mode");
+  GNM_CHECK_ARG(g_matmul_mode >= 1, "edge_bwd_chain: only built for the split matmul modes");
   GNM_CHECK_ARG(N > 0 && E > 0 && ge && ge_out && t_hi && e_mid && stat_hi && bstat_hi && gamma_hi && W3_hi && gW3_hi &&
                     gb3_hi && partials_hi && t_lo && stat_lo && P_lo && Q_lo && hf_lo && hb_lo && isrc && idst && in_ptr &&
                     gP_lo && Ud_lo && Td_lo && partials_lo && nblk_out && partials_hi != partials_lo,
@@ -2011,7 +2259,8 @@ static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* 
   const int ncg = ncols / FH;
   if constexpr (MM::kSplit) {        // W rows cg*128.. form the [k=128, c=128] block of group cg: ONE launch for all groups
     // (pack_w3_gen_k with one output class: k runs over the whole stacked weight, block (cg*4 + wv) as pack_w3_k lays it out)
-    hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
+    if constexpr (MM::kScaled) hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (unsigned char*)ws);
+    else hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
   } else {
     for (int cg = 0; cg < ncg; ++cg)
       launch_pack<MM>(W + (size_t)cg * FH * FH, FH, FH / 32, 1, (char*)ws + (size_t)cg * 4 * MM::kPackBytes, st);
@@ -2020,8 +2269,8 @@ static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* 
   if constexpr (MM::kSplit) {
     constexpr int T = 4;
     const int64_t ngroups = cdiv_(N, NR3 * T);
-    const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn_group32_b3_k<T>>());
-    hipLaunchKernelGGL((rowtile_nn_group32_b3_k<T>), dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
+    const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn_group32_b3_k<MM, T>>());
+    hipLaunchKernelGGL((rowtile_nn_group32_b3_k<MM, T>), dim3(grid), dim3(kBlock), 0, st, N, gP, (int64_t)ncols, ncg,
                        (const void*)ws, gh_out, gh_in, cdiv_(ngroups, grid));
   } else {
     const int64_t ntiles = cdiv_(N, FTR);
@@ -2041,8 +2290,9 @@ extern "C" int gnm_node_proj_bwd_nn(int64_t N, int H, int ncols, const float* gP
   GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && W && gh_out && gh_in, "node_proj_bwd_nn: bad argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_bwd_nn: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  return (g_matmul_mode ? node_proj_bwd_nn<MmB3>(N, ncols, gP, W, gh_out, gh_in, ws, st)
-                        : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st)) ? -2 : 0;
+  return (g_matmul_mode == 2 ? node_proj_bwd_nn<MmH2>(N, ncols, gP, W, gh_out, gh_in, ws, st)
+          : g_matmul_mode  ? node_proj_bwd_nn<MmB3>(N, ncols, gP, W, gh_out, gh_in, ws, st)
+                           : node_proj_bwd_nn<MmF32>(N, ncols, gP, W, gh_out, gh_in, ws, st)) ? -2 : 0;
 }
 
 // gnm_node_proj_bwd_nn with the BatchNorm_h backward sums of the layer below (gnm_node_bwd_stats over gh_in and z_lo) in its
@@ -2051,19 +2301,22 @@ extern "C" int gnm_node_proj_bwd_nn_stats(int64_t N, int H, int ncols, const flo
                                           float* gh_in, const float* z_lo, const float* stat_h_lo, double* partials,
                                           int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(H == FH, "node_proj_bwd_nn_stats: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(g_matmul_mode == 1, "node_proj_bwd_nn_stats: bf16x3 matmul mode only");
+  GNM_CHECK_ARG(g_matmul_mode >= 1, "node_proj_bwd_nn_stats: split matmul modes only");
   GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && gP && W && gh_out && gh_in && z_lo && stat_h_lo && partials && nblk_out,
                 "node_proj_bwd_nn_stats: bad argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_bwd_nn_stats: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int ncg = ncols / FH;
-  hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
+  const bool h2 = g_matmul_mode == 2;
+  if (h2) hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (unsigned char*)ws);
+  else hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
   GNM_LAUNCH_CHECK("pack_w (NN, node, stats)");
   constexpr int T = 4;
   const int64_t ngroups = cdiv_(N, NR3 * T);
-  const int grid = persistent_grid(ngroups, 1, occ_blocks<rowtile_nn2_k<T>>());
+  const int grid = persistent_grid(ngroups, 1, h2 ? occ_blocks<rowtile_nn2_k<MmH2, T>>() : occ_blocks<rowtile_nn2_k<MmB3, T>>());
   const Nn2Args a{N, gP, (int64_t)ncols, ncg, (const void*)ws, gh_out, gh_in, cdiv_(ngroups, grid), z_lo, stat_h_lo, partials};
-  hipLaunchKernelGGL(rowtile_nn2_k<T>, dim3(grid), dim3(kBlock), 0, st, a);
+  if (h2) hipLaunchKernelGGL((rowtile_nn2_k<MmH2, T>), dim3(grid), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((rowtile_nn2_k<MmB3, T>), dim3(grid), dim3(kBlock), 0, st, a);
   *nblk_out = grid;
   GNM_LAUNCH_CHECK("node_proj_bwd_nn_stats");
   return 0;
@@ -2108,7 +2361,7 @@ extern "C" int gnm_tn128_bgrad(int64_t M, int H, const float* UT, const float* U
                                const int32_t* out_ptr, float* gP, const float* B, const void* Bs, float* out, float* colsum,
                                double* partials, void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(H == FH, "tn128_bgrad: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(g_matmul_mode == 1, "tn128_bgrad: bf16x3 matmul mode only");
+  GNM_CHECK_ARG(g_matmul_mode >= 1, "tn128_bgrad: split matmul modes only");
   GNM_CHECK_ARG(M > 0 && UT && Ud && Td && (ud_pitch == H || ud_pitch == 2 * H) && stat_e && bstat_e && gamma_e && in_ptr &&
                     out_ptr && gP && (!B != !Bs) && out && colsum && partials, "tn128_bgrad: bad argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128_bgrad: workspace too small");

@@ -55,6 +55,57 @@ __device__ __forceinline__ void split3f(const float4& v, bf16x4& hi, bf16x4& mid
   }
 }
 
+// ---- f16x2: fp32 operands as TWO fp16 terms of a power-of-two multiple (round 5) ----------------------------------
+// The package power cap, not HBM or the matrix peak, sets the duration of every kernel that feeds the matrix cores
+// (profiles/r05_power.txt): the energy of a contraction is what has to shrink.  x s = h1 + h2 + r with h1 = fp16(x s),
+// h2 = fp16(x s - h1), |r| <= 2^-22 |x s| (2 x 11 significand bits), and a product needs THREE MFMAs (h1 w1, h1 w2,
+// h2 w1; the dropped h2 w2 <= 2^-22 |x w|) instead of the six of bf16x3.  s is a power of two that puts the largest
+// magnitude of the operand's ROW (or of a weight's output column) into [2^14, 2^15): the fp16 exponent range then holds
+// both terms of every element down to 2^-17 of that maximum at full width (smaller elements keep an absolute error of
+// 2^-25 / s, i.e. 2^-39 of the maximum), nothing overflows, and multiplying the fp32 accumulator by 1 / s is exact.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+// max over the 32 consecutive lanes that hold one 128-float row, on the BIT PATTERNS of non-negative floats (ordered as
+// unsigned integers; no NaN canonicalisation between the steps): four v_max_u32 with a DPP operand, then the other 16-lane
+// row through gfx950's v_permlane16_swap
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned row32_max_bits(unsigned m) {
+  m = dpp_max_u32<0xB1>(m);      // quad_perm [1,0,3,2]
+  m = dpp_max_u32<0x4E>(m);      // quad_perm [2,3,0,1]
+  m = dpp_max_u32<0x141>(m);     // row_half_mirror: the other quad of the 8
+  m = dpp_max_u32<0x140>(m);     // row_mirror: the other 8 of the 16
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x2_ sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);   // (rows 0 0 2 2, rows 1 1 3 3)
+  return sw.x > sw.y ? sw.x : sw.y;
+}
+__device__ __forceinline__ unsigned max_abs4_bits(const float4& v) {
+  return __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+// s = 2^(14 - floor(log2 m)), inv = 1 / s; magnitudes below 2^-111 (and zero rows) share s = 2^125
+__device__ __forceinline__ void h2_scale(unsigned mbits, float& s, float& inv) {
+  int e = (int)(mbits >> 23) & 0xff;
+  e = e < 16 ? 16 : e;
+  s = __int_as_float((268 - e) << 23);
+  inv = __int_as_float((e - 14) << 23);
+}
+__device__ __forceinline__ void split2(const float4& v, float s, h16x4& hi, h16x4& lo) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const _Float16 h = (_Float16)x[j];
+    hi[j] = h;
+    lo[j] = (_Float16)(x[j] - (float)h);     // the difference is exact in fp32
+  }
+}
+__device__ __forceinline__ void mfh(floatx16& acc, const h16x8& a, const h16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+
 // one float4 of row r, columns c .. c+3 -> the three images of a tile (image s at img + s * img_bytes)
 __device__ __forceinline__ void simg_stage(unsigned char* img, int img_bytes, int r, int c, const float4& v) {
   bf16x4 hi, mid, lo;

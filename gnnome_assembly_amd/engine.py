@@ -351,7 +351,7 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk, hs_in=None):
             _call("gnm_node_proj_fwd", N, H, 5 * H, _ptr(h_in), _ptr(prm.W5), _ptr(prm.b5), _ptr(P), _ptr(ws), need, st)
         _call("gnm_edge_t_fused_fwd", E, H, _ptr(e_in), _ptr(prm.W3), _ptr(prm.b3), _ptr(P), _ptr(idx["isrc"]),
               _ptr(idx["idst"]), _ptr(t), _ptr(sc.partials), C.byref(nblk), _ptr(ws), need, st)
-    elif H == 256 and FUSED and WIDE_FUSED and e_in.shape[1] == H and _lib.get_matmul_mode() == "bf16x3":
+    elif H == 256 and FUSED and WIDE_FUSED and e_in.shape[1] == H and _lib.split_mode():
         # the reference's default width: projections through the split-mode GEMM, t + BatchNorm partials in one pass
         # (a workgroup keeps one 128-column half of W3 stationary in eight waves)
         gemm(NT, h_in, prm.W5, P, bias=prm.b5)
@@ -534,7 +534,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             ws = sc.ws(need)
             _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need, st)
-        elif H == 256 and FUSED and WIDE_FUSED and residual and Hin == H and _lib.get_matmul_mode() == "bf16x3":
+        elif H == 256 and FUSED and WIDE_FUSED and residual and Hin == H and _lib.split_mode():
             # the reference's default width: gt and ge_in = ge_tot + gt W3 from one pass, gt kept for the weight-gradient GEMM
             gt = torch.empty(E, H, **f32)
             ge_in = torch.empty(E, H, **f32)
@@ -654,7 +654,7 @@ def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, hs: Opti
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
-    return CHAIN and FUSED and H == 128 and batch_norm and _lib.get_matmul_mode() == "bf16x3"
+    return CHAIN and FUSED and H == 128 and batch_norm and _lib.split_mode()
 
 
 def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tensor], L: int, saved: List[LayerSaved],

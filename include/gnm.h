@@ -291,16 +291,24 @@ int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const f
  * ws: gnm_rowtile_workspace_bytes(ncols) / gnm_node_proj_bwd_workspace_bytes(ncols) /
  *     gnm_edge_bwd_fused_workspace_bytes().  partials: the BatchNorm partials buffer.      */
 size_t gnm_rowtile_workspace_bytes(int ncols);
-/* How the fused kernels multiply a fp32 tile by a fp32 weight block (process-wide, default 1):
+/* How the fused kernels multiply a fp32 tile by a fp32 weight block (process-wide, default 2):
  *   0  v_mfma_f32_32x32x2_f32 -- fp32 operands on the matrix cores;
  *   1  "bf16x3": each fp32 operand is split EXACTLY into three bf16 terms (3 x 8 = 24 significand
  *      bits) and the product is formed from six v_mfma_f32_32x32x16_bf16 (all partial products
- *      above 2^-24 |x w|), accumulated in fp32 -- fp32-class accuracy at 8/6 x 2 the MFMA rate.
+ *      above 2^-24 |x w|), accumulated in fp32;
+ *   2  "f16x2" (round 5): x s = h1 + h2 with two fp16 terms (2 x 11 = 22 significand bits) of a
+ *      POWER-OF-TWO multiple -- s puts the largest magnitude of the operand's row (of a weight's
+ *      output column) at 2^14, so nothing overflows or leaves the fp16 exponent range, and the fp32
+ *      accumulator is multiplied by the exact 1 / s afterwards -- and THREE v_mfma_f32_32x32x16_f16
+ *      per product (h1 w1, h1 w2, h2 w1), accumulated in fp32.  In node_proj_fwd, edge_t_fused_fwd
+ *      (H = 128) and node_proj_bwd_nn(_stats); every other split-mode kernel runs as in mode 1.
+ *      The step runs at the package power cap: half the matrix instructions come back as time;
+ *      distance to fp64 per mode: profiles/r05_f16x2_accuracy.txt (mode 2 <= mode 1 <= mode 0).
  * Applies to the NT / NN contractions of edge_t_fused_fwd, node_proj_fwd/bwd, edge_bwd_fused.   */
 int gnm_debug_set_variant(const char* what, int v);   /* A/B switches between kernel generations (tests, tools) */
 int gnm_set_matmul_mode(int mode);
 int gnm_get_matmul_mode(void);
-/* H = 128 in both matmul modes; H = 256 (the reference's default dim_latent, hyperparameters.py:8) in the bf16x3 mode: a
+/* H = 128 in every matmul mode; H = 256 (the reference's default dim_latent, hyperparameters.py:8) in the split modes (1, 2; bf16x3 arithmetic): a
  * workgroup of eight waves keeps one 128-column half of W3 stationary, the two halves of the contraction meet in LDS
  * (ws >= gnm_rowtile_workspace_bytes(5 * H)).                                    gated_gcn_full.py:113,120-122 */
 int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,

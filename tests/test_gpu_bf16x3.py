@@ -21,7 +21,7 @@ def bf16x3_mode():
     _lib.set_matmul_mode("bf16x3")
     assert _lib.get_matmul_mode() == "bf16x3"
     yield
-    _lib.set_matmul_mode("bf16x3")      # the library default
+    _lib.set_matmul_mode(_lib.DEFAULT_MATMUL_MODE)
 
 
 def test_mode_switch_is_validated():

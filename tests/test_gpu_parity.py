@@ -18,18 +18,20 @@ from helpers import GOLDEN, load_case, sd_to_torch, rel_l2, assert_parity, tally
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+@pytest.fixture(autouse=True, params=["f16x2", "bf16x3", "f32"])
 def matmul_mode(request):
-    """Every test of this file runs under BOTH matmul modes of the fused kernels (include/gnm.h):
-    "bf16x3" -- the library default, the mode bench.py's `value` is measured in -- and the fp32-MFMA
-    mode.  Tests that never reach a fused kernel are marked `mode_independent` and run once."""
+    """Every test of this file runs under ALL THREE matmul modes of the fused kernels (include/gnm.h):
+    "f16x2" -- the library default, the mode bench.py's `value` is measured in: two fp16 terms of a power-of-two
+    multiple, three MFMAs per product, in the kernels that have it --, "bf16x3" (the exact three-term split, six MFMAs
+    per product; the default of rounds 2-4) and the fp32-MFMA mode.  Tests that never reach a fused kernel are marked
+    `mode_independent` and run once."""
     from gnnome_assembly_amd import _lib
-    if request.param == "f32" and (request.node.get_closest_marker("mode_independent")
-                                   or request.node.get_closest_marker("default_mode_only")):
+    if request.param != _lib.DEFAULT_MATMUL_MODE and (request.node.get_closest_marker("mode_independent")
+                                                      or request.node.get_closest_marker("default_mode_only")):
         pytest.skip("runs once (does not depend on the matmul mode, or too large to run twice)")
     _lib.set_matmul_mode(request.param)
     yield request.param
-    _lib.set_matmul_mode("bf16x3")
+    _lib.set_matmul_mode(_lib.DEFAULT_MATMUL_MODE)
 
 GRAD_L2 = 2e-4          # norm-relative bar for one parameter-gradient tensor (fp32 vs fp64 oracle)
 GRAD_ABS_FLOOR = 2e-7   # gradients that are analytically zero (biases in front of a BatchNorm)
@@ -1160,13 +1162,14 @@ def test_chained_backward_matches_the_layer_by_layer_backward():
 # round 5: the node side (pre-split image of h, fused conversion / BatchNorm_h sums)
 # -----------------------------------------------------------------------------------------
 
-@pytest.mark.default_mode_only
-def test_presplit_image_kernels_are_bit_identical_to_the_fp32_operand_kernels():
+def test_presplit_image_kernels_are_bit_identical_to_the_fp32_operand_kernels(matmul_mode):
     """include/gnm.h "the pre-split image": gnm_node_update_fwd_s3 = gnm_node_update_fwd + the three-part bf16 image of
     h_out; gnm_node_proj_fwd_s3 / gnm_tn128_s3 copy that image where the fp32-operand kernels split the same rows in
     every workgroup class.  Same parts, same MFMA order: P, gW5, gb5 bit for bit; the image reassembles h exactly."""
     import ctypes as C
     from gnnome_assembly_amd import engine, _lib
+    if matmul_mode != "bf16x3":
+        pytest.skip("the pre-split image holds the three bf16 terms of the bf16x3 mode")
     dev = _dev()
     lib = _lib.load()
     H = 128
@@ -1509,7 +1512,17 @@ def test_two_sided_forward_sweep_matches_the_separate_passes(ids):
         rr = float((a - b).norm() / b.norm().clamp_min(1e-30))
         if rr > GRAD_L2 and float((a - b).abs().max()) > 1e-6 * gmax:
             bad.append((k, rr))
-    assert not bad, bad
+    if bad:
+        # a forward that moved by 1e-6 takes other relu branches at a few elements; a tensor that then differs by more than the
+        # plain bar must be the EXACT gradient of its own branches under BOTH schedules (fp64 backward on the device's branches,
+        # rel-L2 <= BRANCH_L2) -- the bar the oracle tests hold such a tensor to, not a wider one
+        from gnnome_assembly_amd import synth
+        sd = synth.synth_state_dict(128, 4, 11)
+        for two_sided in (False, True):
+            with engine.options(TWO_SIDED_FWD=two_sided):
+                brows, bgmax = _branch_exact_rows(src, dst, n, e_np, pe_np, inp["y"], float(inp["pos_weight"]), sd, 4, dev)
+            tally_clause("miss", len(bad))          # moved to "branch_exact" by the call below, or the test fails
+            _branch_exact_or_fail(bad, {r_[0]: r_ for r_ in brows}, bgmax, f"TWO_SIDED_FWD={two_sided}", floor=0.0)
 
 
 @pytest.mark.default_mode_only
@@ -1766,7 +1779,7 @@ def test_bench_line_contract(tmp_path):
         assert k in r, k
     assert r["unit"] == "edges/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1
     assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
-    assert r["dtype"] == "f32 (bf16x3 split products, f32 accumulate)" and r["config"]["matmul"] == "bf16x3"
+    assert r["dtype"] == "f32 (f16x2 split products, f32 accumulate)" and r["config"]["matmul"] == "f16x2"
     assert r["data"] == "synthetic" and "workload" in r["config"]
     assert abs(r["value"] - r["config"]["edges"] / (r["ms_per_step"] / 1e3)) <= 1e-6 * r["value"]
     rf = r["roofline"]                 # the step against the HBM roofline, per-kernel table inside
@@ -1785,7 +1798,7 @@ def test_bench_line_contract(tmp_path):
             assert 0 < k["mfma"]["frac"] < 1.0
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s" and cb["sample"]
-    assert r["alt_matmul"]["matmul"] == "f32" and r["alt_matmul"]["value"] > 0
+    assert [a["matmul"] for a in r["alt_matmul"]] == ["bf16x3", "f32"] and all(a["value"] > 0 for a in r["alt_matmul"])
     assert "1/" in cb["sample"]                      # the sample states its ratio to the GPU workload
 
 

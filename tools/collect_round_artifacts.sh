@@ -7,11 +7,13 @@ if [ -z "$FAST" ]; then
   cp gpurun_out/logit_parity_fullsize.txt gpurun_out/grad_parity_fullsize.txt gpurun_out/rccl_smoke.log gpurun_out/grad_clauses.json gpurun_out/grad_clauses.txt gpurun_out/cabi_host_step.txt gpurun_out/dp2_train_config4.log $O/ 2>/dev/null
   python -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "test_model_matches_golden" 2>&1 | grep "logits rel_l2" > $O/logit_parity.txt
 fi
-python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 HEAD=45 tools/kernel_stats.sh $T python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-matmul --no-alt-orders > $O/ks.txt 2>&1
 cp $(find gpurun_out/prof_$T -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 OUTDIR=traffic tools/collect_traffic.sh > $O/traffic.log 2>&1
 python tools/traffic_summary.py gpurun_out/traffic $O/traffic.json $(cat .git_head) > $O/traffic.txt 2>&1
+# the bench line is taken AFTER the PMC pass so that its roofline.traffic is this tree's own (bench.py checks the csrc hash)
+cp $O/traffic.json profiles/${T}_traffic.json
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 BENCH=1 tools/pmc_run.sh $T --no-alt-orders > $O/sq_pmc_bench.txt 2>&1
 python tools/minibatch_epoch.py > $O/minibatch.log 2>&1; cp gpurun_out/minibatch.json $O/ 2>/dev/null
 python tools/minibatch_breakdown.py > $O/minibatch_breakdown.txt 2>&1
