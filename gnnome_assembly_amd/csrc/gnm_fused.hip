@@ -1822,9 +1822,9 @@ static inline int64_t cdiv_(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 namespace gnm {   // gnm_tr.hip: the split-mode TN kernel on swizzled row-major images + transpose reads
 int tn_tr_rows_per_tile();
-int tn_tr_occupancy(bool s3 = false, bool conv = false);
+int tn_tr_occupancy(bool s3 = false, bool conv = false, bool h2 = false);
 void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B, int64_t ldb, int ncgb, float* slab,
-                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv = nullptr);
+                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv = nullptr, bool h2 = false);
 size_t edge_bwd_tr_pack_bytes();
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
@@ -2148,7 +2148,8 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
   hipStream_t st = (hipStream_t)stream;
   const bool tr = g_matmul_mode || Bs3 || cv;            // split mode: tn_tr_k (transpose reads); fp32-MFMA mode: tn_colgroup_k
   const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : FTR);
-  int occ = tr ? tn_tr_occupancy(Bs3 != nullptr, cv != nullptr) : occ_blocks<tn_colgroup_k<MmF32>>();
+  const bool h2 = g_matmul_mode == 2 && !Bs3;            // f16x2 (tn_tr_k<., ., ., true>); the pre-split image holds bf16x3 terms
+  int occ = tr ? tn_tr_occupancy(Bs3 != nullptr, cv != nullptr, h2) : occ_blocks<tn_colgroup_k<MmF32>>();
   if (max_blocks_per_cu > 0 && occ > max_blocks_per_cu) occ = max_blocks_per_cu;    // the caller shares the CUs with another stream
   int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
@@ -2158,7 +2159,7 @@ static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const f
   if (Bs3)
     tn_tr_launch(N, A, lda, ncg, Bs3, -1, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv);
   else if (tr)
-    tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv);
+    tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv, h2);
   else
     hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
                        nslot, cdiv_(ntiles, nslot));
@@ -2183,7 +2184,7 @@ static bool gemm_b3_shape_ok(int mode, int64_t M, int64_t N, int64_t K) {
 }
 static int gemm_b3_tn_slots(int64_t rows, int ncls) {
   const int64_t ntiles = cdiv_(rows, tn_tr_rows_per_tile());
-  int nslot = (num_cus() * tn_tr_occupancy()) / ncls;
+  int nslot = (num_cus() * tn_tr_occupancy(false, false, g_matmul_mode == 2)) / ncls;
   if (nslot > kMaxPartialBlocks / ncls) nslot = kMaxPartialBlocks / ncls;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
   nslot = nslot / kXcds * kXcds;
@@ -2212,7 +2213,7 @@ int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64
     const int64_t ntiles = cdiv_(K, tn_tr_rows_per_tile());
     float* slab = (float*)ws;
     double* partials = (double*)((char*)ws + (size_t)ncls * nslot * FH * FH * sizeof(float));
-    tn_tr_launch(K, A, lda, ncga, B, ldb, ncgb, slab, partials, nslot, cdiv_(ntiles, nslot), st);
+    tn_tr_launch(K, A, lda, ncga, B, ldb, ncgb, slab, partials, nslot, cdiv_(ntiles, nslot), st, nullptr, g_matmul_mode == 2);
     for (int cls = 0; cls < ncls; ++cls)
       hipLaunchKernelGGL(slab_reduce_ld_k, dim3(FH), dim3(256), 0, st, (const float*)slab + (size_t)cls * nslot * FH * FH,
                          nslot, C + (int64_t)(cls / ncgb) * FH * ldc + (cls % ncgb) * FH, ldc);

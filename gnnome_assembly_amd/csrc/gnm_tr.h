@@ -106,6 +106,13 @@ __device__ __forceinline__ void mfh(floatx16& acc, const h16x8& a, const h16x8& 
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 }
 
+// biased exponent of the largest magnitude of a row (clamped like h2_scale: zero rows count as 2^-111)
+__device__ __forceinline__ int h2_row_exp(const float4& v) {
+  const int e = (int)(row32_max_bits(max_abs4_bits(v)) >> 23) & 0xff;
+  return e < 16 ? 16 : e;
+}
+__device__ __forceinline__ float pow2_biased(int be) { return __int_as_float((be < 0 ? 0 : be > 254 ? 254 : be) << 23); }   // 2^(be - 127); 0 below the range
+
 // one float4 of row r, columns c .. c+3 -> the three images of a tile (image s at img + s * img_bytes)
 __device__ __forceinline__ void simg_stage(unsigned char* img, int img_bytes, int r, int c, const float4& v) {
   bf16x4 hi, mid, lo;
@@ -114,6 +121,15 @@ __device__ __forceinline__ void simg_stage(unsigned char* img, int img_bytes, in
   *reinterpret_cast<bf16x4*>(p) = hi;
   *reinterpret_cast<bf16x4*>(p + img_bytes) = mid;
   *reinterpret_cast<bf16x4*>(p + 2 * img_bytes) = lo;
+}
+
+// f16x2: one float4 times the power of two sc -> the two images of a tile
+__device__ __forceinline__ void simg_stage_h2(unsigned char* img, int img_bytes, int r, int c, const float4& v, float sc) {
+  h16x4 hi, lo;
+  split2(v, sc, hi, lo);
+  unsigned char* p = img + simg_off(r, c);
+  *reinterpret_cast<h16x4*>(p) = hi;
+  *reinterpret_cast<h16x4*>(p + img_bytes) = lo;
 }
 
 // the exact fp32 values back out of the three images (hi + mid is exact in fp32, + lo gives x)
@@ -175,6 +191,10 @@ __device__ __forceinline__ bf16x8 simg_col_frag2(const unsigned char* img, int b
     f[4 + j] = b[j];
   }
   return f;
+}
+
+__device__ __forceinline__ h16x8 simg_col_frag_h(const unsigned char* img, int k0, int c0, int lane) {
+  return __builtin_bit_cast(h16x8, simg_col_frag(img, k0, c0, lane));     // the transpose read moves 16-bit elements, whatever they hold
 }
 
 typedef float floatx4_acc __attribute__((ext_vector_type(4)));

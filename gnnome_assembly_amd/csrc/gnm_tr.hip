@@ -26,7 +26,21 @@ constexpr int TRIMG = TRR * SPITCH;         // bytes per image (8 KB)
 // gP[:, 3H:5H] for the kernel that multiplies gP by W5 right behind this one: the elementwise launch in between (6 [N,H]
 // streams, 0.87 ms per layer) is gone.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-template <bool BS3, bool CONV, int OCC>
+// H2: the binades a row that lies d = R - P below the reference gives up on its A side (the B side gives up d - da)
+__device__ __forceinline__ int h2_tn_da(int R, int P) { const int d = R - P; return d > 0 ? (d > 200 ? 100 : d >> 1) : 0; }
+// H2 (round 5, gnm_set_matmul_mode(2)): the f16x2 form of gnm_tr.h -- three MFMAs per product, two images per operand.  A TN
+// contraction runs over the tile's ROWS, so the unit of the products must be ONE for all rows that meet in an accumulator:
+//   A row r is staged as A_r 2^(4 - EA_r - da), B row r as B_r 2^(4 - R + EA_r + da),
+// R = the REFERENCE exponent of this workgroup: the largest EA + EB of any row so far; d = R - (EA_r + EB_r) >= 0 is what the row
+// lies below it and da = d / 2 -- every product carries 2^(8 - R), a row AT the reference has both operands' largest
+// magnitudes at 2^4, a row below it gives up d / 2 binades on either side: down to 2^-36 of the largest row product met both
+// terms of its largest elements stay in the normal range (full width), from there the row fades out gradually and is gone at
+// 2^-56 -- far below what the fp32 sum it is added to resolves.  A row ABOVE R (da = 0) has room for 2^10 before the fp16
+// range ends.  R is known without a barrier: the row owners leave EA + EB in LDS when they stage, after the
+// staging barrier every wave takes the tile's maximum of them -- the same number in every wave -- and the accumulators
+// move to the new unit (one exact multiplication) after the tile's MFMAs.  Only a tile with a row more than 2^10 above R
+// (the first tile; a jump of three decades between neighbouring tiles) is staged again with its own maximum as R.
+template <bool BS3, bool CONV, int OCC, bool H2 = false>
 __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* __restrict__ A, int64_t lda, int ncg,
                                                      const void* __restrict__ Bv, int64_t ldb, int ncgb,
                                                      float* __restrict__ slab, double* __restrict__ partials, int nslot,
@@ -100,10 +114,17 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
       }
     }
   };
+  static_assert(!(H2 && BS3), "the pre-split image holds bf16x3 terms");
+  constexpr int kNoRef = -100000;            // H2: no row met yet (every row of the first tile lies above it)
+  int Rref = kNoRef;                         // H2: reference exponent (unbiased EA + EB), the same in every thread
+  int* const rexp = reinterpret_cast<int*>(lds + 2 * TRIMG);   // H2: [32] EA + EB of the tile's rows, [32] = "a row lies above R + 10"
+                                                               //     (the third A image of the bf16x3 layout, unused here)
+  if constexpr (H2) { if (tid == 0) rexp[TRR] = 0; }
   if (tb0 < tb1) prefetch(tb0);
   for (int64_t tile = tb0; tile < tb1; ++tile) {
     const int64_t r0 = tile * TRR;
     __syncthreads();                          // the previous tile's fragment reads are done
+    int rowa[H2 ? 4 : 1];                     // H2: EA of this thread's rows (a tile staged again needs them)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       if constexpr (CONV) {
@@ -115,8 +136,20 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
       }
       if (r0 + lrow + 8 * it >= M) pa[it] = f4(0.f);      // rows past the end contribute nothing
       c0 += (double)pa[it].x; c1 += (double)pa[it].y; c2 += (double)pa[it].z; c3 += (double)pa[it].w;
-      simg_stage(ia, TRIMG, lrow + 8 * it, lc4, pa[it]);
-      if constexpr (!BS3) simg_stage(ib, TRIMG, lrow + 8 * it, lc4, pb[it]);
+      if constexpr (H2) {
+        const int ea = h2_row_exp(pa[it]) - 127, eb = h2_row_exp(pb[it]) - 127;
+        rowa[it] = ea;
+        if ((tid & 31) == 0) {
+          rexp[lrow + 8 * it] = ea + eb;
+          if (ea + eb > Rref + 10) rexp[TRR] = 1;
+        }
+        const int da = h2_tn_da(Rref, ea + eb);
+        simg_stage_h2(ia, TRIMG, lrow + 8 * it, lc4, pa[it], pow2_biased(127 + 4 - ea - da));
+        simg_stage_h2(ib, TRIMG, lrow + 8 * it, lc4, pb[it], pow2_biased(127 + 4 - Rref + ea + da));
+      } else {
+        simg_stage(ia, TRIMG, lrow + 8 * it, lc4, pa[it]);
+        if constexpr (!BS3) simg_stage(ib, TRIMG, lrow + 8 * it, lc4, pb[it]);
+      }
     }
     if constexpr (BS3) {
 #pragma unroll
@@ -126,7 +159,66 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
       }
     }
     __syncthreads();
+    int Rnext = Rref;
+    if constexpr (H2) {
+      // the tile's largest EA + EB: lane l holds row l & 31's, the maximum over the wave is the same number in every wave
+      int m = rexp[lane & 31];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) { const int x = __shfl_xor(m, o); m = x > m ? x : m; }
+      const bool redo = rexp[TRR] != 0;       // (uniform: written before the barrier)
+      if (redo) {                             // rare: the tile is staged again in the unit of its own maximum
+        const float f = pow2_biased(127 + (Rref == kNoRef ? -127 : Rref - m));      // the accumulators so far move to it (<= 1, exact)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tn[a][b][e] *= f;
+        Rref = m;
+        __syncthreads();                      // every wave has read the flag and the exponents
+        if (tid == 0) rexp[TRR] = 0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int da = h2_tn_da(Rref, rexp[lrow + 8 * it]);
+          simg_stage_h2(ia, TRIMG, lrow + 8 * it, lc4, pa[it], pow2_biased(127 + 4 - rowa[it] - da));
+          simg_stage_h2(ib, TRIMG, lrow + 8 * it, lc4, pb[it], pow2_biased(127 + 4 - Rref + rowa[it] + da));
+        }
+        __syncthreads();
+      }
+      Rnext = m > Rref ? m : Rref;
+    }
     prefetch(tile + 1);                       // in flight under the MFMAs
+    if constexpr (H2) {
+#pragma unroll
+      for (int kc = 0; kc < TRR / 16; ++kc) {
+        h16x8 a[2][2], b[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            a[x][s] = simg_col_frag_h(ia + s * TRIMG, 16 * kc, (2 * wn + x) * 32, lane);
+            b[x][s] = simg_col_frag_h(ib + s * TRIMG, 16 * kc, (2 * wc + x) * 32, lane);
+          }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {         // lo*hi, hi*lo, hi*hi
+          const int sa = t == 0 ? 1 : 0, sb = t == 1 ? 1 : 0;
+          mfh(tn[0][0], a[0][sa], b[0][sb]);
+          mfh(tn[0][1], a[0][sa], b[1][sb]);
+          mfh(tn[1][0], a[1][sa], b[0][sb]);
+          mfh(tn[1][1], a[1][sa], b[1][sb]);
+        }
+      }
+      if (Rnext != Rref) {                    // the next tile is staged in the unit of the new reference
+        const float f = pow2_biased(127 + Rref - Rnext);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tn[a][b][e] *= f;
+        Rref = Rnext;
+      }
+    } else {
 #pragma unroll
     for (int kc = 0; kc < TRR / 16; ++kc) {
       bf16x8 a[2][3], b[2][3];
@@ -145,6 +237,16 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
         mfb16(tn[1][1], a[1][b3_pa(t)], b[1][b3_pb(t)]);
       }
     }
+    }
+  }
+  if constexpr (H2) {                         // out of the products' unit 2^(8 - R)
+    const float f = Rref == kNoRef ? 0.f : pow2_biased(127 + Rref - 8);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tn[a][b][e] *= f;
   }
   // C / D layout of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   float* sl = slab + (size_t)(cls * nslot + slot) * SW * SW;
@@ -980,16 +1082,24 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
 int tn_tr_rows_per_tile() { return TRR; }
 // s3: the pre-split-B variant; built for two (208 registers) and for three (168, 14 spilled) workgroups per CU, A/B by GNM_VARIANTS
 int tn_s3_occ_variant();   // gnm_fused.hip
-int tn_tr_occupancy(bool s3, bool conv) {
+int tn_tr_occupancy(bool s3, bool conv, bool h2) {
+  if (h2 && !s3) return conv ? occ_blocks<tn_tr_k<false, true, 2, true>>() : occ_blocks<tn_tr_k<false, false, 2, true>>();
   if (conv) return s3 ? occ_blocks<tn_tr_k<true, true, 2>>() : occ_blocks<tn_tr_k<false, true, 2>>();
   if (!s3) return occ_blocks<tn_tr_k<false, false, 2>>();
   return tn_s3_occ_variant() == 3 ? occ_blocks<tn_tr_k<true, false, 3>>() : occ_blocks<tn_tr_k<true, false, 2>>();
 }
-// ldb < 0: B is the pre-split image (ncgb = 1);  cv: the A operand is formed from raw sums (ncg = 2, ncgb = 1)
+// ldb < 0: B is the pre-split image (ncgb = 1);  cv: the A operand is formed from raw sums (ncg = 2, ncgb = 1);
+// h2: the f16x2 form (fp32 B operand only)
 void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B, int64_t ldb, int ncgb, float* slab,
-                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv) {
+                  double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv, bool h2) {
   const TnConv none{};
-  if (cv && ldb < 0)
+  if (h2 && ldb >= 0 && cv)
+    hipLaunchKernelGGL((tn_tr_k<false, true, 2, true>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, 1, slab,
+                       partials, nslot, tiles_per_slot, *cv);
+  else if (h2 && ldb >= 0)
+    hipLaunchKernelGGL((tn_tr_k<false, false, 2, true>), dim3(nslot * ncg * ncgb), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, ncgb,
+                       slab, partials, nslot, tiles_per_slot, none);
+  else if (cv && ldb < 0)
     hipLaunchKernelGGL((tn_tr_k<true, true, 2>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, (int64_t)0, 1, slab,
                        partials, nslot, tiles_per_slot, *cv);
   else if (cv)

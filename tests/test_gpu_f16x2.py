@@ -1,0 +1,199 @@
+"""The "f16x2" matmul mode (include/gnm.h: gnm_set_matmul_mode(2), the library default since round 5): fp32 operands as two
+fp16 terms of a POWER-OF-TWO multiple, three MFMAs per product.  The whole of tests/test_gpu_parity.py runs under it (the
+autouse `matmul_mode` fixture there); this file holds what is specific to it -- the scaling.  Every kernel that has the mode is
+driven with operands that would leave the fp16 exponent range under a fixed scale (rows, elements, column groups and weight
+columns spread over many decades, gradients of 1e-7, zero rows, a row 1e12 above all others, magnitudes that jump by 1e8 from
+one tile to the next) and must stay as close to an fp64 evaluation as the fp32-MFMA mode does: rel-L2 <= 2e-6 and no worse
+than 1.5x the fp32 mode's + 1e-7, componentwise |err| <= 4e-6 (|x| |W| + |other terms|) where the kernel scales per row, finite
+everywhere."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+H = 128
+
+
+@pytest.fixture(autouse=True)
+def restore_mode():
+    from gnnome_assembly_amd import _lib
+    yield
+    _lib.set_matmul_mode(_lib.DEFAULT_MATMUL_MODE)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _weights(rng, rows, cols, axis):
+    W = (rng.standard_normal((rows, cols)) / 11).astype(np.float32)
+    for i, f in ((7, 0.0), (9, 1e-20), (11, 1e5)):            # a zero, a tiny and a huge output column
+        sl = [slice(None)] * 2
+        sl[axis] = i
+        W[tuple(sl)] *= f
+    return W
+
+
+def _check(name, run, ref, scale, cw_bar=4e-6):
+    from gnnome_assembly_amd import _lib
+    res = {}
+    for mode in ("f32", "f16x2"):
+        _lib.set_matmul_mode(mode)
+        o = run().astype(np.float64)
+        assert np.isfinite(o).all(), f"{name} [{mode}]: non-finite output"
+        res[mode] = (rel_l2(o, ref), float(np.max(np.abs(o - ref) / np.maximum(scale, 1e-300))))
+    (r32, c32), (r16, c16) = res["f32"], res["f16x2"]
+    print(f"{name}: rel_l2 f16x2={r16:.2e} f32={r32:.2e}  cw f16x2={c16:.2e} f32={c32:.2e}")
+    assert r16 <= 2e-6 and r16 <= 1.5 * r32 + 1e-7, (name, r16, r32)
+    if cw_bar is not None:
+        assert c16 <= cw_bar, (name, c16, c32)
+
+
+def test_mode_is_the_default_and_switchable():
+    from gnnome_assembly_amd import _lib
+    assert _lib.DEFAULT_MATMUL_MODE == "f16x2" and _lib.load().gnm_get_matmul_mode() == 2 and _lib.split_mode()
+    _lib.set_matmul_mode("bf16x3")
+    assert _lib.get_matmul_mode() == "bf16x3" and _lib.split_mode()
+    _lib.set_matmul_mode("f32")
+    assert not _lib.split_mode()
+
+
+@pytest.mark.parametrize("case", ["normal", "rows", "elements", "zero_rows", "tiny"])
+def test_node_projections_scale_per_row(case):
+    """gnm_node_proj_fwd: P = h W5^T + b5; a row's factor comes from its own largest magnitude (gnm_fused.hip MmH2::stage)."""
+    from gnnome_assembly_amd import _lib, engine
+    dev, lib = _dev(), _lib.load()
+    rng = np.random.default_rng(1)
+    N = 20011                                            # ragged last tile
+    hn = {"normal": lambda: rng.standard_normal((N, H)),
+          "rows": lambda: rng.standard_normal((N, H)) * np.exp(rng.uniform(-30, 30, (N, 1))),
+          "elements": lambda: rng.standard_normal((N, H)) * np.exp(rng.uniform(-12, 12, (N, H))),
+          "zero_rows": lambda: rng.standard_normal((N, H)) * (rng.random((N, 1)) < 0.5),
+          "tiny": lambda: rng.standard_normal((N, H)) * 1e-30}[case]().astype(np.float32)
+    Wn, bn = _weights(rng, 5 * H, H, 0), (rng.standard_normal(5 * H) * (0.0 if case == "tiny" else 1.0)).astype(np.float32)
+    h, W5, b5 = (torch.from_numpy(a).to(dev) for a in (hn, Wn, bn))
+    ref = hn.astype(np.float64) @ Wn.astype(np.float64).T + bn
+    scale = np.abs(hn).astype(np.float64) @ np.abs(Wn).astype(np.float64).T + np.abs(bn)
+
+    def run():
+        need = lib.gnm_rowtile_workspace_bytes(5 * H)
+        ws = engine.scratch(dev).ws(need)
+        out = torch.empty(N, 5 * H, device=dev)
+        engine._call("gnm_node_proj_fwd", N, H, 5 * H, engine._ptr(h), engine._ptr(W5), engine._ptr(b5), engine._ptr(out), engine._ptr(ws), need,
+                     engine._stream())
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    _check(f"node_proj_fwd [{case}]", run, ref, scale, cw_bar=None if case == "tiny" else 4e-6)   # tiny: products below the fp32 range in every mode
+
+
+@pytest.mark.parametrize("case", ["normal", "rows", "elements"])
+def test_edge_t_kernel_scales_per_row(case):
+    """gnm_edge_t_fused_fwd: t = e W3^T + b3 + B1h[src] + B2h[dst]; the row factors are made one tile ahead, inside the matrix phase
+    of the tile before (edge_t32_b3p_k<MmH2>)."""
+    from gnnome_assembly_amd import _lib, engine
+    dev, lib = _dev(), _lib.load()
+    rng = np.random.default_rng(2)
+    E, Nn = 50021, 9973
+    en = {"normal": lambda: rng.standard_normal((E, H)),
+          "rows": lambda: rng.standard_normal((E, H)) * np.exp(rng.uniform(-30, 30, (E, 1))),
+          "elements": lambda: rng.standard_normal((E, H)) * np.exp(rng.uniform(-12, 12, (E, H)))}[case]().astype(np.float32)
+    Wn, bn = _weights(rng, H, H, 0), rng.standard_normal(H).astype(np.float32)
+    Pn = rng.standard_normal((Nn, 5 * H)).astype(np.float32)
+    src, dst = rng.integers(0, Nn, E).astype(np.int32), np.sort(rng.integers(0, Nn, E)).astype(np.int32)
+    e, W3, b3, Pt, s_, d_ = (torch.from_numpy(a).to(dev) for a in (en, Wn, bn, Pn, src, dst))
+    g1, g2 = Pn[src, 3 * H:4 * H].astype(np.float64), Pn[dst, 4 * H:5 * H].astype(np.float64)
+    ref = en.astype(np.float64) @ Wn.astype(np.float64).T + bn + g1 + g2
+    scale = np.abs(en).astype(np.float64) @ np.abs(Wn).astype(np.float64).T + np.abs(bn) + np.abs(g1) + np.abs(g2)
+
+    def run():
+        need = lib.gnm_rowtile_workspace_bytes(H)
+        ws = engine.scratch(dev).ws(need)
+        out = torch.empty(E, H, device=dev)
+        nb = C.c_int(0)
+        engine._call("gnm_edge_t_fused_fwd", E, H, engine._ptr(e), engine._ptr(W3), engine._ptr(b3), engine._ptr(Pt), engine._ptr(s_), engine._ptr(d_),
+                     engine._ptr(out), engine._ptr(engine.scratch(dev).partials), C.byref(nb), engine._ptr(ws), need, engine._stream())
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    _check(f"edge_t_fused_fwd [{case}]", run, ref, scale)
+
+
+@pytest.mark.parametrize("case", ["normal", "tiny_grads", "rows", "groups_apart", "groups_rising", "zero_groups"])
+@pytest.mark.parametrize("stats", [False, True])
+def test_projection_backward_keeps_one_unit_across_the_column_groups(case, stats):
+    """gnm_node_proj_bwd_nn(_stats): gh_in = gh_out + gP W5 -- the accumulator of a row runs over five 128-column groups of gP
+    whose magnitudes differ; the row's reference exponent only grows and the accumulator follows it (h2_stage_nn)."""
+    from gnnome_assembly_amd import _lib, engine
+    dev, lib = _dev(), _lib.load()
+    rng = np.random.default_rng(3)
+    N = 20011
+    rep = lambda a: np.repeat(a, H, axis=1)  # noqa: E731
+    gPn = {"normal": lambda: rng.standard_normal((N, 5 * H)),
+           "tiny_grads": lambda: rng.standard_normal((N, 5 * H)) * 1e-7,
+           "rows": lambda: rng.standard_normal((N, 5 * H)) * np.exp(rng.uniform(-25, 5, (N, 1))),
+           "groups_apart": lambda: rng.standard_normal((N, 5 * H)) * rep(10.0 ** rng.integers(-6, 1, (N, 5))),
+           "groups_rising": lambda: rng.standard_normal((N, 5 * H)) * rep(np.tile(np.array([1e-12, 1e-6, 1.0, 1e6, 1e12]), (N, 1))),
+           "zero_groups": lambda: rng.standard_normal((N, 5 * H)) * rep(rng.random((N, 5)) < 0.5)}[case]().astype(np.float32)
+    Wn = _weights(rng, 5 * H, H, 1)
+    ghn = (rng.standard_normal((N, H)) * np.abs(gPn).max(1, keepdims=True) * 0.1).astype(np.float32)
+    zn = rng.standard_normal((N, H)).astype(np.float32)
+    statn = np.stack([np.zeros(H), np.ones(H), np.ones(H), np.zeros(H)]).astype(np.float32)
+    gP, W5, gh, z, stat = (torch.from_numpy(a).to(dev) for a in (gPn, Wn, ghn, zn, statn))
+    ref = gPn.astype(np.float64) @ Wn.astype(np.float64) + ghn
+    scale = np.abs(gPn).astype(np.float64) @ np.abs(Wn).astype(np.float64) + np.abs(ghn)
+
+    def run():
+        need = lib.gnm_rowtile_workspace_bytes(5 * H)
+        ws = engine.scratch(dev).ws(need)
+        out = torch.empty(N, H, device=dev)
+        if stats and _lib.split_mode():
+            nb = C.c_int(0)
+            engine._call("gnm_node_proj_bwd_nn_stats", N, H, 5 * H, engine._ptr(gP), engine._ptr(W5), engine._ptr(gh), engine._ptr(out), engine._ptr(z),
+                         engine._ptr(stat), engine._ptr(engine.scratch(dev).partials), C.byref(nb), engine._ptr(ws), need, engine._stream())
+        else:
+            engine._call("gnm_node_proj_bwd_nn", N, H, 5 * H, engine._ptr(gP), engine._ptr(W5), engine._ptr(gh), engine._ptr(out), engine._ptr(ws), need,
+                         engine._stream())
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    _check(f"node_proj_bwd_nn{'_stats' if stats else ''} [{case}]", run, ref, scale)
+
+
+@pytest.mark.parametrize("case", ["normal", "rows", "rising", "falling", "jumps", "giant_row", "zero_rows", "elements"])
+def test_weight_gradient_kernel_keeps_one_unit_across_rows(case):
+    """gnm_tn128: gW[cg] = A[:, cg]^T h -- the contraction runs over the ROWS, whose magnitudes differ (tn_tr_k<., ., ., true>: a
+    reference exponent per workgroup that only grows, a tile with a row far above it is staged again).  `jumps`: 1e8 between
+    neighbouring 1000-row stretches (the staged-again path, over and over); `giant_row`: one row 1e12 above all others --
+    the other rows' share of an entry stays resolved down to 2^-36 of the giant row's product, where the fp32 sum itself
+    resolves 2^-24."""
+    from gnnome_assembly_amd import _lib, engine
+    dev, lib = _dev(), _lib.load()
+    rng = np.random.default_rng(4)
+    N = 100003
+    col = lambda v: np.asarray(v)[:, None]  # noqa: E731
+    An, hn = {"normal": lambda: (rng.standard_normal((N, 3 * H)) * 1e-5, rng.standard_normal((N, H))),
+              "rows": lambda: (rng.standard_normal((N, 3 * H)) * np.exp(rng.uniform(-30, 0, (N, 1))),
+                               rng.standard_normal((N, H)) * np.exp(rng.uniform(-3, 3, (N, 1)))),
+              "rising": lambda: (rng.standard_normal((N, 3 * H)) * col(10.0 ** np.linspace(-20, 0, N)), rng.standard_normal((N, H))),
+              "falling": lambda: (rng.standard_normal((N, 3 * H)) * col(10.0 ** np.linspace(0, -20, N)), rng.standard_normal((N, H))),
+              "jumps": lambda: (rng.standard_normal((N, 3 * H)) * col(10.0 ** (8 * ((np.arange(N) // 1000) % 3))), rng.standard_normal((N, H))),
+              "giant_row": lambda: (rng.standard_normal((N, 3 * H)) * col(np.where(np.arange(N) == N // 2, 1e12, 1.0)), rng.standard_normal((N, H))),
+              "zero_rows": lambda: (rng.standard_normal((N, 3 * H)) * (rng.random((N, 1)) < 0.5), rng.standard_normal((N, H)) * (rng.random((N, 1)) < 0.7)),
+              "elements": lambda: (rng.standard_normal((N, 3 * H)) * np.exp(rng.uniform(-12, 12, (N, 3 * H))),
+                                   rng.standard_normal((N, H)) * np.exp(rng.uniform(-12, 12, (N, H))))}[case]()
+    An, hn = An.astype(np.float32), hn.astype(np.float32)
+    A, h = torch.from_numpy(An).to(dev), torch.from_numpy(hn).to(dev)
+    ref = np.concatenate([An[:, c * H:(c + 1) * H].astype(np.float64).T @ hn.astype(np.float64) for c in range(3)])
+    scale = np.concatenate([np.abs(An[:, c * H:(c + 1) * H]).astype(np.float64).T @ np.abs(hn).astype(np.float64) for c in range(3)])
+
+    def run():
+        sc = engine.scratch(dev)
+        need = lib.gnm_tn128_workspace_bytes()
+        gW, gb = torch.empty(3 * H, H, device=dev), torch.empty(3 * H, device=dev)
+        engine.tn128(N, A, 3 * H, 3, h, None, gW, gb, sc.partials, sc.ws(need), need)
+        torch.cuda.synchronize()
+        return gW.cpu().numpy()
+    _check(f"tn128 [{case}]", run, ref, scale, cw_bar=4e-6)

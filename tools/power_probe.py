@@ -20,12 +20,26 @@ sys.path.insert(0, REPO)
 
 
 def hwmon_files():
+    """(power file, shader-clock file) of the GPU torch calls cuda:0 -- the box's sysfs lists every card of the node, so the card is
+    matched by PCI address; without a match: the first card that has both files."""
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:
+        pass
+    found = []
     for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
         p = [os.path.join(d, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(d, n))]
         f = os.path.join(d, "freq1_input")
         if p and os.path.exists(f):
-            return p[0], f
-    return None, None
+            found.append((os.path.realpath(os.path.dirname(os.path.dirname(d))), p[0], f))
+    for dev, p, f in found:
+        if want and dev.endswith(want):
+            return p, f
+    if want and found:
+        print(f"power_probe: no card at PCI {want} among {[x[0][-12:] for x in found]}; using the first", file=sys.stderr)
+    return (found[0][1], found[0][2]) if found else (None, None)
 
 
 class Sampler(threading.Thread):
