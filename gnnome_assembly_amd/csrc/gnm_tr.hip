@@ -33,10 +33,10 @@ __device__ __forceinline__ int h2_tn_da(int R, int P) { const int d = R - P; ret
 //   A row r is staged as A_r 2^(4 - EA_r - da), B row r as B_r 2^(4 - R + EA_r + da),
 // R = the REFERENCE exponent of this workgroup: the largest EA + EB of any row so far; d = R - (EA_r + EB_r) >= 0 is what the row
 // lies below it and da = d / 2 -- every product carries 2^(8 - R), a row AT the reference has both operands' largest
-// magnitudes at 2^4, a row below it gives up d / 2 binades on either side: down to 2^-36 of the largest row product met both
-// terms of its largest elements stay in the normal range (full width), from there the row fades out gradually and is gone at
-// 2^-56 -- far below what the fp32 sum it is added to resolves.  A row ABOVE R (da = 0) has room for 2^10 before the fp16
-// range ends.  R is known without a barrier: the row owners leave EA + EB in LDS when they stage, after the
+// magnitudes at 2^4 (22 bits each), a row below it gives up d / 2 binades on either side: its operands are held to 2^-25
+// absolute = 2^-(29 - d/2) of their largest magnitude, its products to 2^-(28 + d/2) of the largest row product met -- always
+// below the 2^-24 the fp32 accumulator resolves -- and it is gone at d = 56.  A row ABOVE R (da = 0) has room for 2^10 before
+// the fp16 range ends.  R is known without a barrier: the row owners leave EA + EB in LDS when they stage, after the
 // staging barrier every wave takes the tile's maximum of them -- the same number in every wave -- and the accumulators
 // move to the new unit (one exact multiplication) after the tile's MFMAs.  Only a tile with a row more than 2^10 above R
 // (the first tile; a jump of three decades between neighbouring tiles) is staged again with its own maximum as R.
