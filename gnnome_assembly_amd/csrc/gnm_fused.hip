@@ -1578,12 +1578,14 @@ __global__ __launch_bounds__(kBlock, 2) void rowtile_nn2_k(const Nn2Args a) {
 // workgroups of a row chunk sit on one XCD (workgroup b runs on XCD b % 8) and read the same X rows through its L2.
 // R may be Y (ge = ge + gt W3 in place): a thread reads its R elements before it stores the same Y elements.
 // ------------------------------------------------------------------------------------------
-template <int T>
+template <class MM, int T>
 __global__ __launch_bounds__(kBlock, 2) void gemm_rows_b3_k(
     int64_t M, const float* __restrict__ X, int64_t ldx, int ncg, int ncls, const void* __restrict__ Wp,
     const float* __restrict__ bias, const float* R, int64_t ldr, int relu, float* Y, int64_t ldy, int nchunk,
     int64_t groups_per_chunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[MM::kImgBytes];
+  __shared__ int eref[MM::kScaled ? T * NR3 : 1];                // MmH2: as in rowtile_nn_group32_b3_k
+  __shared__ __attribute__((aligned(16))) float fsc[MM::kScaled ? 2 * NR3 : 4];
   float* xs = reinterpret_cast<float*>(xraw);
   static_assert(T % 2 == 0, "two-deep prefetch assumes an even group size");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1596,6 +1598,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_rows_b3_k(
   const int64_t g1 = min(ngroups, g0 + groups_per_chunk);
   const int lrow = tid >> 5, lc4 = (tid & 31) * 4;
   const int64_t Mlast = M - 1;
+  float4 ci4 = f4(1.f);
+  if constexpr (MM::kScaled) ci4 = MM::col_inv4(Wp, cls * ncg * 4, lc4);    // the class's column factors span its whole K
   float4 pre[T][4];
   auto prefetch = [&](float4 (&buf)[4], int64_t g, int cg, int tl) __attribute__((always_inline)) {
     if (cg >= ncg) { cg = 0; g = g + 1 < g1 ? g + 1 : g; }
@@ -1615,15 +1619,25 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_rows_b3_k(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tl][e] = 0.f;
     for (int cg = 0; cg < ncg; ++cg) {
-      MmB3::Frag wf;
-      MmB3::load_w(wf, Wp, (cls * ncg + cg) * 4 + wave, lane);
+      typename MM::Frag wf;
+      MM::load_w(wf, Wp, (cls * ncg + cg) * 4 + wave, lane);
 #pragma unroll
       for (int tl = 0; tl < T; ++tl) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) MmB3::stage(xraw, 32 * (tl & 1) + lrow + 8 * it, lc4, pre[tl][it]);
+        for (int it = 0; it < 4; ++it) {
+          const int row = lrow + 8 * it;
+          if constexpr (MM::kScaled) h2_stage_nn(xraw, 32 * (tl & 1) + row, lc4, pre[tl][it], eref + tl * NR3 + row, fsc + (tl & 1) * NR3 + row,
+                                                 cg == 0, (tid & 31) == 0);
+          else MM::stage(xraw, 32 * (tl & 1) + row, lc4, pre[tl][it]);
+        }
         __syncthreads();
         prefetch(pre[tl], g, cg + 1, tl);
-        mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        if constexpr (MM::kScaled) {
+          if (cg > 0) acc_rescale_rows(acc[tl], fsc + (tl & 1) * NR3, lg);
+          mma32_h2(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        } else {
+          mma32_b3(xraw, 32 * (tl & 1), wf, acc[tl], li, lg);
+        }
       }
     }
 #pragma unroll
@@ -1642,7 +1656,9 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_rows_b3_k(
       for (int it = 0; it < 4; ++it) {
         const int row = lrow + 8 * it;
         const int64_t grow = r0 + row;
-        float4 v = ld4(xs + row * FP + lc4) + rr[it];
+        float4 v = ld4(xs + row * FP + lc4);
+        if constexpr (MM::kScaled) v = v * (ci4 * h2_ref_inv(eref[tl * NR3 + row]));
+        v = v + rr[it];
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         if (grow < M) st4(Y + grow * ldy + cls * FH + lc4, v);
       }
@@ -1680,16 +1696,24 @@ __global__ void pack_w3_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
 }
 
 // the same for MmH2 (block layout of pack_w2_k); a column's factor is taken over its WHOLE contraction (all ncg groups), so that
-// an accumulator that runs over the groups keeps one unit per column
+// an accumulator that runs over the groups keeps one unit per column: col_amax_k leaves the columns' largest magnitudes behind
+// the fragment blocks (the workspace is sized for the larger bf16x3 blocks), pack_w2_gen_k reads them
+__global__ void col_amax_k(const float* __restrict__ W, int64_t ld, int ncols, int64_t K, int nn, float* __restrict__ amax) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= ncols) return;
+  float m = 0.f;
+  for (int64_t k = 0; k < K; ++k) m = fmaxf(m, fabsf(nn ? W[k * ld + n] : W[(int64_t)n * ld + k]));
+  amax[n] = m;
+}
 __global__ void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncls, int ncg, int nn, unsigned char* __restrict__ Wp) {
   const int total = ncls * ncg * 4 * BKC * 64;
+  const float* amax = reinterpret_cast<const float*>(Wp + (size_t)ncls * ncg * 4 * MmH2::kPackBytes);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63, c = (idx >> 6) % BKC, blk = idx / (64 * BKC);
     const int wv = blk & 3, cg = (blk >> 2) % ncg, cls = (blk >> 2) / ncg;
     const int i = lane & 31, g = lane >> 5;
     const int64_t n = (int64_t)cls * FH + wv * 32 + i;
-    float m = 0.f;
-    for (int64_t k = 0; k < (int64_t)ncg * FH; ++k) m = fmaxf(m, fabsf(nn ? W[k * ld + n] : W[n * ld + k]));
+    const float m = amax[n];
     float sc, inv;
     h2_scale(__float_as_uint(m), sc, inv);
     h16x8 hi, lo;
@@ -1707,6 +1731,13 @@ __global__ void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
     o[64] = lo;
     if (c == 0 && g == 0) reinterpret_cast<float*>(b + MmH2::kFragBytes)[i] = inv;
   }
+}
+
+static void launch_pack_w2_gen(const float* W, int64_t ld, int ncls, int ncg, int nn, void* ws, hipStream_t st) {
+  static_assert(MmB3::kPackBytes - MmH2::kPackBytes >= FH * sizeof(float), "the column maxima fit behind the f16x2 blocks");
+  float* amax = reinterpret_cast<float*>((unsigned char*)ws + (size_t)ncls * ncg * 4 * MmH2::kPackBytes);
+  hipLaunchKernelGGL(col_amax_k, dim3((ncls * FH + 255) / 256), dim3(256), 0, st, W, ld, ncls * FH, (int64_t)ncg * FH, nn, amax);
+  hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, W, ld, ncls, ncg, nn, (unsigned char*)ws);
 }
 
 // slab[(cg*nslot + slot)][n][c] = sum over the slot's rows of A[row][cg*128+n] * B[row][c];
@@ -2221,16 +2252,20 @@ int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64
   }
   if (!al(C, ldc) || (resid && !al(resid, ldr)) || (bias && (uintptr_t)bias % 16 != 0)) return 0;
   const int ncls = (int)(N / FH), ncg = (int)(K / FH);
-  hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, B, ldb, ncls, ncg, mode == GNM_GEMM_NN ? 1 : 0,
-                     (bf16x8*)ws);
+  const bool h2 = g_matmul_mode == 2;
+  if (h2) launch_pack_w2_gen(B, ldb, ncls, ncg, mode == GNM_GEMM_NN ? 1 : 0, ws, st);
+  else hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, B, ldb, ncls, ncg, mode == GNM_GEMM_NN ? 1 : 0,
+                          (bf16x8*)ws);
   constexpr int T = 4;
   const int64_t ngroups = cdiv_(M, NR3 * T);
-  int nchunk = (num_cus() * occ_blocks<gemm_rows_b3_k<T>>()) / ncls;
+  int nchunk = (num_cus() * (h2 ? occ_blocks<gemm_rows_b3_k<MmH2, T>>() : occ_blocks<gemm_rows_b3_k<MmB3, T>>())) / ncls;
   if ((int64_t)nchunk > ngroups) nchunk = (int)ngroups;
   nchunk = nchunk / kXcds * kXcds;
   if (nchunk < kXcds) nchunk = kXcds;
-  hipLaunchKernelGGL((gemm_rows_b3_k<T>), dim3(nchunk * ncls), dim3(kBlock), 0, st, M, A, lda, ncg, ncls, (const void*)ws,
-                     bias, resid, ldr, relu, C, ldc, nchunk, cdiv_(ngroups, nchunk));
+  if (h2) hipLaunchKernelGGL((gemm_rows_b3_k<MmH2, T>), dim3(nchunk * ncls), dim3(kBlock), 0, st, M, A, lda, ncg, ncls, (const void*)ws,
+                             bias, resid, ldr, relu, C, ldc, nchunk, cdiv_(ngroups, nchunk));
+  else hipLaunchKernelGGL((gemm_rows_b3_k<MmB3, T>), dim3(nchunk * ncls), dim3(kBlock), 0, st, M, A, lda, ncg, ncls, (const void*)ws,
+                          bias, resid, ldr, relu, C, ldc, nchunk, cdiv_(ngroups, nchunk));
   return hipGetLastError() == hipSuccess ? 1 : -2;
 }
 // the same TN product plus the column sums of A (a Linear's bias gradient beside its weight gradient): tn_tr_k keeps them
@@ -2260,7 +2295,7 @@ static int node_proj_bwd_nn(int64_t N, int ncols, const float* gP, const float* 
   const int ncg = ncols / FH;
   if constexpr (MM::kSplit) {        // W rows cg*128.. form the [k=128, c=128] block of group cg: ONE launch for all groups
     // (pack_w3_gen_k with one output class: k runs over the whole stacked weight, block (cg*4 + wv) as pack_w3_k lays it out)
-    if constexpr (MM::kScaled) hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (unsigned char*)ws);
+    if constexpr (MM::kScaled) launch_pack_w2_gen(W, (int64_t)FH, 1, ncg, 1, ws, st);
     else hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
   } else {
     for (int cg = 0; cg < ncg; ++cg)
@@ -2309,7 +2344,7 @@ extern "C" int gnm_node_proj_bwd_nn_stats(int64_t N, int H, int ncols, const flo
   hipStream_t st = (hipStream_t)stream;
   const int ncg = ncols / FH;
   const bool h2 = g_matmul_mode == 2;
-  if (h2) hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (unsigned char*)ws);
+  if (h2) launch_pack_w2_gen(W, (int64_t)FH, 1, ncg, 1, ws, st);
   else hipLaunchKernelGGL(pack_w3_gen_k, dim3(4 * ncg), dim3(256), 0, st, W, (int64_t)FH, 1, ncg, 1, (bf16x8*)ws);
   GNM_LAUNCH_CHECK("pack_w (NN, node, stats)");
   constexpr int T = 4;

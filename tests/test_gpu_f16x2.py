@@ -197,3 +197,44 @@ def test_weight_gradient_kernel_keeps_one_unit_across_rows(case):
         torch.cuda.synchronize()
         return gW.cpu().numpy()
     _check(f"tn128 [{case}]", run, ref, scale, cw_bar=4e-6)
+
+
+@pytest.mark.parametrize("kind", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("case", ["normal", "rows", "groups_apart"])
+def test_general_gemm_route_of_the_wide_models(kind, case):
+    """gnm_gemm_f32 in the shapes of a hidden-256 model (the reference's default width): NT [M,256] x [1280,256]^T and NN
+    [M,1280] x [1280,256] through gemm_rows_b3_k<MmH2> (the row reference over 2 / 10 column groups, the weight's column
+    factors over its whole K), TN [M,256]^T [M,256] through tn_tr_k<., ., ., true> with (A group, B group) classes."""
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    rng = np.random.default_rng(6)
+    M = 20011 if kind != "TN" else 40000
+    K, N = {"NT": (256, 1280), "NN": (1280, 256), "TN": (M, 256)}[kind]
+    rows = M
+    cols = K if kind != "TN" else 256
+    Xn = {"normal": lambda: rng.standard_normal((rows, cols)),
+          "rows": lambda: rng.standard_normal((rows, cols)) * np.exp(rng.uniform(-25, 5, (rows, 1))),
+          "groups_apart": lambda: rng.standard_normal((rows, cols)) * np.repeat(10.0 ** rng.integers(-6, 1, (rows, cols // H)), H, axis=1)}[case]()
+    Xn = Xn.astype(np.float32)
+    if kind == "NT":
+        Wn = _weights(rng, N, K, 0)
+        ref = Xn.astype(np.float64) @ Wn.astype(np.float64).T
+        scale = np.abs(Xn).astype(np.float64) @ np.abs(Wn).astype(np.float64).T
+        mode, shape = engine.NT, (M, N)
+    elif kind == "NN":
+        Wn = _weights(rng, K, N, 1)
+        ref = Xn.astype(np.float64) @ Wn.astype(np.float64)
+        scale = np.abs(Xn).astype(np.float64) @ np.abs(Wn).astype(np.float64)
+        mode, shape = engine.NN, (M, N)
+    else:
+        Wn = (rng.standard_normal((M, 256)) * np.exp(rng.uniform(-3, 3, (M, 1)))).astype(np.float32)      # B[K, N]: the other row operand
+        ref = Xn.astype(np.float64).T @ Wn.astype(np.float64)
+        scale = np.abs(Xn).astype(np.float64).T @ np.abs(Wn).astype(np.float64)
+        mode, shape = engine.TN, (256, 256)
+    X, W = torch.from_numpy(Xn).to(dev), torch.from_numpy(Wn).to(dev)
+
+    def run():
+        out = engine.gemm(mode, X, W, torch.empty(*shape, device=dev))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    _check(f"gemm {kind} [{case}]", run, ref, scale)
