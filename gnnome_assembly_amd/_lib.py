@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNM_LIBRARY") or os.path.join(_HERE, "libgnm.so")   # GNM_LIBRARY: A/B against another build (tools)
 
 _lib = None
-ABI_VERSION = 5     # GNM_ABI_VERSION of include/gnm.h
+ABI_VERSION = 6     # GNM_ABI_VERSION of include/gnm.h
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -41,9 +41,6 @@ SIGNATURES = {
     "gnm_edge_gate_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_node_agg_src_fwd": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
     "gnm_node_update_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p]),
-    "gnm_s3_bytes": (_sz, [_i64, _i32]),
-    "gnm_split_rows_s3": (_i32, [_i64, _i32, _p, _p, _p]),
-    "gnm_node_update_fwd_s3": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
     "gnm_node_bwd_stats": (_i32, [_i64, _i32, _p, _p, _p, _p, _pi, _p]),
     "gnm_node_bwd_apply": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_bwd_dst": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p]),
@@ -62,13 +59,12 @@ SIGNATURES = {
     "gnm_edge_t_fused_fwd": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),
     "gnm_edge_bwd_gt_nn": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_fwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
-    "gnm_node_proj_fwd_s3": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_workspace_bytes": (_sz, [_i32]),
     "gnm_node_proj_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_nn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_node_proj_bwd_tn": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _i32, _p]),
     "gnm_node_proj_bwd_nn_stats": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _pi, _p, _sz, _p]),
-    "gnm_tn128_bgrad": (_i32, [_i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_tn128_bgrad": (_i32, [_i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_bwd_chain": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_pi, _p, _sz, _p]),
     "gnm_edge_bwd_chain_src": (_i32, [_i64, _i64, _i32] + [_p] * 24 + [_p, _i64, _p] + [_pi, _p, _sz, _p]),
     "gnm_edge_bwd_top": (_i32, [_i64, _i64, _i32] + [_p] * 15 + [_p, _i64, _p, _pi, _p, _sz, _p]),
@@ -90,7 +86,6 @@ SIGNATURES = {
     "gnm_predictor_fused_bwd": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_tn128_workspace_bytes": (_sz, []),
     "gnm_tn128": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
-    "gnm_tn128_s3": (_i32, [_i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_compose_workspace_bytes": (_sz, [_i32]),
     "gnm_compose_partials_doubles": (_sz, []),
     "gnm_layer_forward": (_i32, [_p, _i32, _p, _p, _p, _p]),                          # struct pointers: see include/gnm.h

@@ -93,7 +93,7 @@ extern "C" int gnm_stack_backward(const gnm_graph_view* g, int H, int L, const g
     float* const bstat_e = wk->bstat_e[i & 1];
     GNM_TRY(gnm_bn_bwd_finalize(sc->partials, nblk, E, H, bstat_e, gr[i].g_gamma_e, gr[i].g_beta_e, stream));
     // gB1h | gB2h formed from the raw sums in the operand load of their weight gradient, written to gP for the projection backward
-    GNM_TRY(gnm_tn128_bgrad(N, H, wk->UT, Ud, Td, udp, s[i].stat_e, bstat_e, w[i].gamma_e, g->in_ptr, g->out_ptr, gP, s[i].h_in, nullptr,
+    GNM_TRY(gnm_tn128_bgrad(N, H, wk->UT, Ud, Td, udp, s[i].stat_e, bstat_e, w[i].gamma_e, g->in_ptr, g->out_ptr, gP, s[i].h_in,
                             gr[i].gW5 + (size_t)3 * H * H, gr[i].gb5 + 3 * H, sc->partials, sc->ws, sc->ws_bytes, stream));
     float* const gh_next = i == 0 ? gh_in : wk->gh_tmp[i & 1];
     if (i > 0)      // + the BatchNorm_h backward sums of the layer below in the epilogue

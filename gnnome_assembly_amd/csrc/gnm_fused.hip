@@ -617,82 +617,6 @@ __global__ __launch_bounds__(kBlock, ((MM::kSplit && !EDGE && NCG == 1) || (EDGE
 }
 
 // ------------------------------------------------------------------------------------------
-// Node projections from the PRE-SPLIT image of h (round 5; gnm_layer.hip "the pre-split image"):
-//   P[:, cg*128 + c] = h W5_cg^T + b5       rowtile_nt_k<MmB3, false, 1> without its split staging
-// The five column-group classes of a row chunk each staged the same 64 x 128 tile of h with 8 split3 per thread
-// (~320 of the ~420 VALU instructions of a tile, against 96 MFMAs per wave: the kernel's matrix pipe was ~60 % busy and
-// its vector ALU the rest).  Here the three bf16 images arrive as they are from HBM (768 bytes per row, written by the
-// kernel that produced h) and go to LDS as twelve 16-byte copies per thread; the MFMA phase, its fragment order and
-// the epilogue are the old kernel's, so P is bit-identical.
-// ------------------------------------------------------------------------------------------
-constexpr int S3P = 3 * FH;      // bf16 elements per row of the split image [hi 128 | mid 128 | lo 128]
-typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kBlock, 2) void rowtile_nt_s3_k(
-    int64_t M, const __bf16* __restrict__ Xs, const void* __restrict__ Wp, const float* __restrict__ bias,
-    float* __restrict__ Y, int64_t ldy, int64_t tiles_per_block, int ncgs) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[MmB3::kImgBytes];   // three [64][BP] bf16 images
-  float* xs = reinterpret_cast<float*>(xraw);                                    // reused as the fp32 output image
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lg = lane >> 5;
-  // the ncgs workgroups of a row chunk sit on one XCD and share the image rows in its L2 (as rowtile_nt_k)
-  const int xcd = blockIdx.x % kXcds, jb = blockIdx.x / kXcds;
-  const int cgb = jb % ncgs;
-  const int chunk = xcd * (gridDim.x / ncgs / kXcds) + jb / ncgs;
-  const int64_t ntiles = (M + FTR - 1) / FTR;
-  const int64_t tb0 = (int64_t)chunk * tiles_per_block;
-  const int64_t tb1 = min(ntiles, tb0 + tiles_per_block);
-  const int64_t nfull = min(tb1, M / FTR);
-  const int lrow = tid >> 5, lc4 = (tid & 31) * 4;   // this thread's slot in the coalesced fp32 output image
-  const int r16 = tid >> 4, slot = tid & 15;         // ... and in the copy of the split image: piece j = rows 16 (j / 3) + r16,
-  const int64_t Mlast = M - 1;                       //     part j % 3, 16-byte slot `slot` (a wave reads 4 rows x 256 bytes)
-
-  MmB3::Frag wf;
-  MmB3::load_w(wf, Wp, cgb * 4 + wave, lane);
-
-  u32x4_ pre[12];
-  auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
-    const int64_t r0 = tile * FTR;
-#pragma unroll
-    for (int j = 0; j < 12; ++j)
-      pre[j] = *reinterpret_cast<const u32x4_*>(Xs + clampi(r0 + 16 * (j / 3) + r16, Mlast) * S3P + (j % 3) * FH + slot * 8);
-  };
-  auto body = [&](auto tag, int64_t tile) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(tag)::value;
-    __syncthreads();   // everyone is done with the previous tile's output image
-#pragma unroll
-    for (int j = 0; j < 12; ++j)
-      *reinterpret_cast<u32x4_*>(xraw + (j % 3) * (BIMG * 2) + (16 * (j / 3) + r16) * (BP * 2) + slot * 16) = pre[j];
-    __syncthreads();
-    const int64_t r0 = tile * FTR;
-    prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // next tile's image rows, in flight under the MFMAs
-    floatx16 acc0, acc1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-    MmB3::mma(xraw, wf, acc0, acc1, li, lg);
-    __syncthreads();         // all waves are done reading the images
-    acc_to_lds(xs, acc0, acc1, wave, li, lg);
-    __syncthreads();
-    const float4 b4 = ld4(bias + cgb * FH + lc4);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = lrow + 8 * it;
-      const int64_t grow = r0 + row;
-      const float4 v = ld4(xs + row * FP + lc4) + b4;
-      if (FULL || grow < M) st4(Y + grow * ldy + cgb * FH + lc4, v);
-    }
-  };
-  if (tb0 < tb1) prefetch(tb0);
-  if (tb0 < nfull) {
-    // throw-away stores behind the first prefetch: the loop-entry scoreboard equals the back edge's (see rowtile_nt_k)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) st4(Y + (tb0 * FTR + lrow + 8 * it) * ldy + cgb * FH + lc4, f4(0.f));
-    for (int64_t tile = tb0; tile < nfull; ++tile) body(full_t{}, tile);
-  }
-  if (nfull < tb1 && nfull >= tb0) body(ragged_t{}, nfull);
-}
-
-// ------------------------------------------------------------------------------------------
 // Split-mode edge t kernel with 32-row tiles: t = e W3^T + b3 + B1h[src] + B2h[dst] + BatchNorm sums.
 // 69 KB of LDS and <= 256 VGPRs -> two workgroups per CU (the 64-row version needs 330 registers, and
 // with one wave per SIMD its split staging and epilogue leave the matrix pipe 32 % busy).  The two
@@ -1853,7 +1777,7 @@ static inline int64_t cdiv_(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 namespace gnm {   // gnm_tr.hip: the split-mode TN kernel on swizzled row-major images + transpose reads
 int tn_tr_rows_per_tile();
-int tn_tr_occupancy(bool s3 = false, bool conv = false, bool h2 = false);
+int tn_tr_occupancy(bool conv = false, bool h2 = false);
 void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B, int64_t ldb, int ncgb, float* slab,
                   double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv = nullptr, bool h2 = false);
 size_t edge_bwd_tr_pack_bytes();
@@ -1867,12 +1791,9 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
 static int g_eb_variant = 1;     // edge_bwd_tr_k: 1 = LDS stash + pinned prefetch (default), 2 = registers, unpinned (within 1 %)
 namespace gnm {
 int eb_variant() { return g_eb_variant; }
-static int g_tn_s3_occ = 2;      // tn_tr_k with a pre-split B: built for 2 or 3 workgroups per CU
-int tn_s3_occ_variant() { return g_tn_s3_occ; }
 }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
-  if (what && !strcmp(what, "tn_s3_occ")) { g_tn_s3_occ = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }
@@ -1993,27 +1914,6 @@ extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, co
   return g_matmul_mode == 2 ? node_proj_fwd_impl<MmH2>(N, ncols, h, W, b, Pout, ws, stream)
          : g_matmul_mode  ? node_proj_fwd_impl<MmB3>(N, ncols, h, W, b, Pout, ws, stream)
                           : node_proj_fwd_impl<MmF32>(N, ncols, h, W, b, Pout, ws, stream);
-}
-
-// the same from the pre-split image of h (gnm_split_rows_s3 / gnm_node_update_fwd_s3): split matmul mode only
-extern "C" int gnm_node_proj_fwd_s3(int64_t N, int H, int ncols, const void* hs, const float* W, const float* b,
-                                    float* Pout, void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(H == FH, "node_proj_fwd_s3: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(g_matmul_mode == 1, "node_proj_fwd_s3: the pre-split image belongs to the bf16x3 matmul mode");
-  GNM_CHECK_ARG(N > 0 && ncols > 0 && ncols % FH == 0 && hs && W && b && Pout, "node_proj_fwd_s3: bad argument");
-  GNM_CHECK_ARG(ws && ws_bytes >= gnm_rowtile_workspace_bytes(ncols), "node_proj_fwd_s3: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  launch_pack<MmB3>(W, FH, ncols / 32, 0, ws, st);
-  GNM_LAUNCH_CHECK("pack_w (NT, node, s3)");
-  const int64_t ntiles = cdiv_(N, FTR);
-  const int ncg = ncols / FH;
-  int nslot = (num_cus() * occ_blocks<rowtile_nt_s3_k>()) / ncg / kXcds * kXcds;
-  if (nslot > (int)((ntiles + kXcds - 1) / kXcds * kXcds)) nslot = (int)((ntiles + kXcds - 1) / kXcds * kXcds);
-  if (nslot < kXcds) nslot = kXcds;
-  hipLaunchKernelGGL(rowtile_nt_s3_k, dim3(nslot * ncg), dim3(kBlock), 0, st, N, (const __bf16*)hs, (const void*)ws, b, Pout,
-                     (int64_t)ncols, cdiv_(ntiles, nslot), ncg);
-  GNM_LAUNCH_CHECK("node_proj_fwd_s3");
-  return 0;
 }
 
 namespace gnm {
@@ -2174,22 +2074,19 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
 }
 
 static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,
-                        double* partials, float* slab, void* stream, int max_blocks_per_cu = 0, const void* Bs3 = nullptr,
-                        const TnConv* cv = nullptr) {
+                        double* partials, float* slab, void* stream, int max_blocks_per_cu = 0, const TnConv* cv = nullptr) {
   hipStream_t st = (hipStream_t)stream;
-  const bool tr = g_matmul_mode || Bs3 || cv;            // split mode: tn_tr_k (transpose reads); fp32-MFMA mode: tn_colgroup_k
+  const bool tr = g_matmul_mode || cv;                   // split mode: tn_tr_k (transpose reads); fp32-MFMA mode: tn_colgroup_k
   const int64_t ntiles = cdiv_(N, tr ? tn_tr_rows_per_tile() : FTR);
-  const bool h2 = g_matmul_mode == 2 && !Bs3;            // f16x2 (tn_tr_k<., ., ., true>); the pre-split image holds bf16x3 terms
-  int occ = tr ? tn_tr_occupancy(Bs3 != nullptr, cv != nullptr, h2) : occ_blocks<tn_colgroup_k<MmF32>>();
+  const bool h2 = g_matmul_mode == 2;                    // f16x2 (tn_tr_k<., ., true>)
+  int occ = tr ? tn_tr_occupancy(cv != nullptr, h2) : occ_blocks<tn_colgroup_k<MmF32>>();
   if (max_blocks_per_cu > 0 && occ > max_blocks_per_cu) occ = max_blocks_per_cu;    // the caller shares the CUs with another stream
   int nslot = (num_cus() * occ) / ncg;
   if (nslot > kMaxPartialBlocks / ncg) nslot = kMaxPartialBlocks / ncg;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
   nslot = nslot / kXcds * kXcds;             // whole slots per XCD (see tn_colgroup_k)
   if (nslot < kXcds) nslot = kXcds;          // empty slots write zero slabs
-  if (Bs3)
-    tn_tr_launch(N, A, lda, ncg, Bs3, -1, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv);
-  else if (tr)
+  if (tr)
     tn_tr_launch(N, A, lda, ncg, B, FH, 1, slab, partials, nslot, cdiv_(ntiles, nslot), st, cv, h2);
   else
     hipLaunchKernelGGL(tn_colgroup_k<MmF32>, dim3(nslot * ncg), dim3(kBlock), 0, st, N, A, lda, ncg, B, slab, partials,
@@ -2215,7 +2112,7 @@ static bool gemm_b3_shape_ok(int mode, int64_t M, int64_t N, int64_t K) {
 }
 static int gemm_b3_tn_slots(int64_t rows, int ncls) {
   const int64_t ntiles = cdiv_(rows, tn_tr_rows_per_tile());
-  int nslot = (num_cus() * tn_tr_occupancy(false, false, g_matmul_mode == 2)) / ncls;
+  int nslot = (num_cus() * tn_tr_occupancy(false, g_matmul_mode == 2)) / ncls;
   if (nslot > kMaxPartialBlocks / ncls) nslot = kMaxPartialBlocks / ncls;
   if ((int64_t)nslot > ntiles) nslot = (int)ntiles;
   nslot = nslot / kXcds * kXcds;
@@ -2391,27 +2288,18 @@ extern "C" int gnm_tn128(int64_t M, const float* A, int64_t lda, int ncg, const 
 // gnm_tn128 over the column groups gB1h | gB2h of gP (ncg = 2: out = gW5[3H:5H], colsum = gb5[3H:5H]) with gnm_node_bgrad in
 // its operand load: the groups are formed from the raw sums UT = [Us | Ts] (pitch 2H), Ud, Td (pitch ud_pitch = H or 2H) and
 // the BatchNorm_e backward means, and WRITTEN to gP[:, 3H:5H] (row pitch 5H) for gnm_node_proj_bwd_nn*, which runs behind
-// this call.  B: the layer's h_in [M,128] (fp32), or Bs: its pre-split image (exactly one of the two).  bf16x3 mode, H = 128.
+// this call.  B: the layer's h_in [M,128].  Split matmul modes, H = 128.
 extern "C" int gnm_tn128_bgrad(int64_t M, int H, const float* UT, const float* Ud, const float* Td, int64_t ud_pitch,
                                const float* stat_e, const float* bstat_e, const float* gamma_e, const int32_t* in_ptr,
-                               const int32_t* out_ptr, float* gP, const float* B, const void* Bs, float* out, float* colsum,
+                               const int32_t* out_ptr, float* gP, const float* B, float* out, float* colsum,
                                double* partials, void* ws, size_t ws_bytes, void* stream) {
   GNM_CHECK_ARG(H == FH, "tn128_bgrad: H=%d (only 128 is built)", H);
   GNM_CHECK_ARG(g_matmul_mode >= 1, "tn128_bgrad: split matmul modes only");
   GNM_CHECK_ARG(M > 0 && UT && Ud && Td && (ud_pitch == H || ud_pitch == 2 * H) && stat_e && bstat_e && gamma_e && in_ptr &&
-                    out_ptr && gP && (!B != !Bs) && out && colsum && partials, "tn128_bgrad: bad argument");
+                    out_ptr && gP && B && out && colsum && partials, "tn128_bgrad: bad argument");
   GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128_bgrad: workspace too small");
   const TnConv cv{{UT, Ud}, {UT + H, Td}, {(int64_t)2 * H, ud_pitch}, {out_ptr, in_ptr}, stat_e, bstat_e, gamma_e,
                   gP + 3 * H, (int64_t)5 * H};
-  return tn_colgroups(M, nullptr, 0, 2, B, out, colsum, partials, (float*)ws, stream, 0, Bs, &cv);
+  return tn_colgroups(M, nullptr, 0, 2, B, out, colsum, partials, (float*)ws, stream, 0, &cv);
 }
 
-// the same with B as the pre-split image of the [M,128] tensor (gnm_split_rows_s3 / gnm_node_update_fwd_s3): bf16x3 mode only
-extern "C" int gnm_tn128_s3(int64_t M, const float* A, int64_t lda, int ncg, const void* Bs, float* out, float* colsum,
-                            double* partials, void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(g_matmul_mode == 1, "tn128_s3: the pre-split image belongs to the bf16x3 matmul mode");
-  GNM_CHECK_ARG(M > 0 && A && Bs && out && colsum && partials && ncg > 0 && lda >= (int64_t)ncg * FH && ncg <= 16,
-                "tn128_s3: bad argument");
-  GNM_CHECK_ARG(ws && ws_bytes >= gnm_tn128_workspace_bytes(), "tn128_s3: workspace too small");
-  return tn_colgroups(M, A, lda, ncg, nullptr, out, colsum, partials, (float*)ws, stream, 0, Bs);
-}

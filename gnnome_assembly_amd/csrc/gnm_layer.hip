@@ -167,63 +167,6 @@ __global__ __launch_bounds__(kBlock) void node_update_fwd_k(int64_t N, const flo
 }
 
 
-// ---- the pre-split image of a [N,128] node tensor (round 5) ---------------------------------------------------------
-// The bf16x3 matrix kernels split every fp32 operand into three bf16 parts on the way into LDS (~6 VALU instructions per
-// element), and the node features h of a layer are an operand FIVE times in the forward projections (one workgroup class
-// per 128-column group of W5) and five times again in their weight gradient gP^T h.  Those kernels issue VALU and MFMA work
-// from the same few waves -- their matrix pipe is ~60 % busy, the vector ALU the rest -- so the redundant splits cost time.
-// The elementwise kernel that PRODUCES h (HBM bound, vector ALU idle) therefore also writes h as the split image the
-// matrix kernels stage by plain 16-byte copies:
-//     S3[v] = [ hi(h[v][0..127]) | mid(..) | lo(..) ]   bf16, 768 bytes per row,   h = hi + mid + lo exactly
-// (the same three values split3 / split3f of gnm_fused.hip / gnm_tr.h compute in the kernels, so results are bit-identical).
-typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void s3_store(__bf16* __restrict__ row, int c4, const float4& v) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  bf16x4_l hi, mid, lo;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const __bf16 h = (__bf16)x[j];
-    const float r1 = x[j] - (float)h;      // exact
-    const __bf16 m = (__bf16)r1;
-    hi[j] = h;
-    mid[j] = m;
-    lo[j] = (__bf16)(r1 - (float)m);       // exact, fits 8 bits
-  }
-  *reinterpret_cast<bf16x4_l*>(row + c4) = hi;
-  *reinterpret_cast<bf16x4_l*>(row + 128 + c4) = mid;
-  *reinterpret_cast<bf16x4_l*>(row + 256 + c4) = lo;
-}
-
-// S3 image of x [N,128]
-__global__ __launch_bounds__(kBlock) void split_rows_s3_k(int64_t N, const float* __restrict__ x, __bf16* __restrict__ xs) {
-  const int64_t total = N * 32;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    const int c4 = (int)(i & 31) * 4;
-    const int64_t v = i >> 5;
-    s3_store(xs + v * 384, c4, ld4(x + v * 128 + c4));
-  }
-}
-
-// node_update_fwd_k<128> that also writes the S3 image of h_out
-template <bool RES>
-__global__ __launch_bounds__(kBlock) void node_update_fwd_s3_k(int64_t N, const float* __restrict__ z, const float* __restrict__ stat,
-                                                               const float* __restrict__ h_in, float* __restrict__ h_out,
-                                                               __bf16* __restrict__ hs) {
-  constexpr int H = 128;
-  const int64_t total = N * 32;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    const int c4 = (int)(i & 31) * 4;
-    const int64_t v = i >> 5;
-    const int64_t o = v * H + c4;
-    const float4 sc = ld4(stat + 2 * H + c4), sh = ld4(stat + 3 * H + c4);
-    float4 hr = f4(0.f);
-    if constexpr (RES) hr = ld4(h_in + o);
-    const float4 ho = relu4(fma4(ld4(z + o), sc, sh)) + hr;
-    st4(h_out + o, ho);
-    s3_store(hs + v * 384, c4, ho);
-  }
-}
-
 // -------------------------------------------------------------------------------------------
 // backward
 // -------------------------------------------------------------------------------------------
@@ -642,28 +585,6 @@ extern "C" int gnm_node_update_fwd(int64_t N, int H, const float* z, const float
       hipLaunchKernelGGL((node_update_fwd_k<HH, false>), dim3(ew_grid(N * (HH / 4))), dim3(kBlock), 0, (hipStream_t)stream, N, z, stat_h, h_in, h_out);
   });
   GNM_LAUNCH_CHECK("node_update_fwd");
-  return 0;
-}
-
-extern "C" size_t gnm_s3_bytes(int64_t N, int H) { return H == 128 && N >= 0 ? (size_t)N * 768 : 0; }
-
-extern "C" int gnm_split_rows_s3(int64_t N, int H, const float* x, void* xs, void* stream) {
-  GNM_CHECK_ARG(H == 128, "split_rows_s3: H=%d (the split image is built for the 128-wide matrix kernels)", H);
-  GNM_CHECK_ARG(N >= 0 && x && xs, "split_rows_s3: null/neg argument");
-  hipLaunchKernelGGL(split_rows_s3_k, dim3(ew_grid(N * 32)), dim3(kBlock), 0, (hipStream_t)stream, N, x, (__bf16*)xs);
-  GNM_LAUNCH_CHECK("split_rows_s3");
-  return 0;
-}
-
-extern "C" int gnm_node_update_fwd_s3(int64_t N, int H, const float* z, const float* stat_h, const float* h_in, float* h_out,
-                                      void* hs, void* stream) {
-  GNM_CHECK_ARG(H == 128, "node_update_fwd_s3: H=%d (only 128 is built)", H);
-  GNM_CHECK_ARG(N >= 0 && z && stat_h && h_out && hs, "node_update_fwd_s3: null/neg argument");   // h_in == NULL: no residual
-  if (h_in)
-    hipLaunchKernelGGL(node_update_fwd_s3_k<true>, dim3(ew_grid(N * 32)), dim3(kBlock), 0, (hipStream_t)stream, N, z, stat_h, h_in, h_out, (__bf16*)hs);
-  else
-    hipLaunchKernelGGL(node_update_fwd_s3_k<false>, dim3(ew_grid(N * 32)), dim3(kBlock), 0, (hipStream_t)stream, N, z, stat_h, h_in, h_out, (__bf16*)hs);
-  GNM_LAUNCH_CHECK("node_update_fwd_s3");
   return 0;
 }
 

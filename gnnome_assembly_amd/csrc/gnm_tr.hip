@@ -16,16 +16,14 @@ constexpr int TRIMG = TRR * SPITCH;         // bytes per image (8 KB)
 // 32-row tiles, 48 KB of LDS, coalesced float4 loads one tile ahead; each of the 4 waves owns a 64 x 64 block of
 // the 128 x 128 result (64 accumulator registers).  Two or three workgroups share a CU, so one's split / staging
 // VALU work and HBM waits run under the others' MFMAs.
-// BS3 (round 5): B is the pre-split image of a [M,128] tensor (768 bytes per row: gnm_split_rows_s3 / gnm_node_update_fwd_s3;
-// ncgb = 1) -- the ncg workgroup classes of a slot no longer split the same B tile ncg times, they copy it (six 16-byte
-// pieces per thread into the swizzled images); same parts, same MFMA order: bit-identical results.
+// (Round 5 also built a variant that copied a PRE-SPLIT image of B instead of splitting the tile in every workgroup class:
+//  -0.9 ms per step here, +1.7 in the kernel that wrote the image; removed)
 // CONV (round 5): the A operand does not exist yet -- the two column groups of this launch are gB1h, gB2h, which the chained
 // edge kernel left as RAW sums (Us | Ts by source, Ud | Td by destination); with the BatchNorm_e backward means m1, m2
 //     gB1h = c (Us - outdeg m1 - m2 Ts),   gB2h = c (Ud - indeg m1 - m2 Td),   c = gamma_e rstd_e      (node_bgrad_k)
 // A tile is FORMED from the sums on its way into the images (two rows of loads per operand row) and written once to
 // gP[:, 3H:5H] for the kernel that multiplies gP by W5 right behind this one: the elementwise launch in between (6 [N,H]
 // streams, 0.87 ms per layer) is gone.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // H2: the binades a row that lies d = R - P below the reference gives up on its A side (the B side gives up d - da)
 __device__ __forceinline__ int h2_tn_da(int R, int P) { const int d = R - P; return d > 0 ? (d > 200 ? 100 : d >> 1) : 0; }
 // H2 (round 5, gnm_set_matmul_mode(2)): the f16x2 form of gnm_tr.h -- three MFMAs per product, two images per operand.  A TN
@@ -40,13 +38,12 @@ __device__ __forceinline__ int h2_tn_da(int R, int P) { const int d = R - P; ret
 // staging barrier every wave takes the tile's maximum of them -- the same number in every wave -- and the accumulators
 // move to the new unit (one exact multiplication) after the tile's MFMAs.  Only a tile with a row more than 2^10 above R
 // (the first tile; a jump of three decades between neighbouring tiles) is staged again with its own maximum as R.
-template <bool BS3, bool CONV, int OCC, bool H2 = false>
+template <bool CONV, int OCC, bool H2 = false>
 __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* __restrict__ A, int64_t lda, int ncg,
                                                      const void* __restrict__ Bv, int64_t ldb, int ncgb,
                                                      float* __restrict__ slab, double* __restrict__ partials, int nslot,
                                                      int64_t tiles_per_slot, const TnConv cv) {
   const float* __restrict__ B = reinterpret_cast<const float*>(Bv);
-  const __bf16* __restrict__ Bs = reinterpret_cast<const __bf16*>(Bv);
   __shared__ __attribute__((aligned(16))) unsigned char lds[6 * TRIMG];
   unsigned char* ia = lds;
   unsigned char* ib = lds + 3 * TRIMG;
@@ -74,8 +71,7 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
 #pragma unroll
       for (int e = 0; e < 16; ++e) tn[a][b][e] = 0.f;
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;     // column sums of A for columns lc4 .. lc4+3
-  float4 pa[4], pb[BS3 ? 1 : 4];
-  u32x4_t ps[BS3 ? 6 : 1];
+  float4 pa[4], pb[4];
   float4 pt[CONV ? 4 : 1];                        // CONV: the T rows and the CSR pointers the degrees come from
   int dg[CONV ? 4 : 1][2];
   float4 cc = f4(0.f), m1 = f4(0.f), m2 = f4(0.f);
@@ -88,7 +84,6 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
   const float* const Tcg = CONV ? cv.T[cg] : nullptr;
   const int64_t pcg = CONV ? cv.pitch[cg] : 0;
   const int32_t* const dptr = CONV ? cv.ptr[cg] : nullptr;
-  const int r16 = tid >> 4, s16 = tid & 15;       // BS3: piece j = row 16 (j / 3) + r16, part j % 3, 16-byte slot s16
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * TRR;
 #pragma unroll
@@ -103,18 +98,9 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
       } else {
         pa[it] = ld4_nt(A + r * lda + cg * SW + lc4);
       }
-      if constexpr (!BS3) pb[it] = ld4(B + r * ldb + cgb * SW + lc4);        // shared by the workgroups of the slot through L2
-    }
-    if constexpr (BS3) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        int64_t r = r0 + 16 * (j / 3) + r16;
-        r = r < Mlast ? r : Mlast;
-        ps[j] = *reinterpret_cast<const u32x4_t*>(Bs + r * (3 * SW) + (j % 3) * SW + s16 * 8);
-      }
+      pb[it] = ld4(B + r * ldb + cgb * SW + lc4);        // shared by the workgroups of the slot through L2
     }
   };
-  static_assert(!(H2 && BS3), "the pre-split image holds bf16x3 terms");
   constexpr int kNoRef = -100000;            // H2: no row met yet (every row of the first tile lies above it)
   int Rref = kNoRef;                         // H2: reference exponent (unbiased EA + EB), the same in every thread
   int* const rexp = reinterpret_cast<int*>(lds + 2 * TRIMG);   // H2: [32] EA + EB of the tile's rows, [32] = "a row lies above R + 10"
@@ -148,14 +134,7 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
         simg_stage_h2(ib, TRIMG, lrow + 8 * it, lc4, pb[it], pow2_biased(127 + 4 - Rref + ea + da));
       } else {
         simg_stage(ia, TRIMG, lrow + 8 * it, lc4, pa[it]);
-        if constexpr (!BS3) simg_stage(ib, TRIMG, lrow + 8 * it, lc4, pb[it]);
-      }
-    }
-    if constexpr (BS3) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int r = 16 * (j / 3) + r16;
-        *reinterpret_cast<u32x4_t*>(ib + (j % 3) * TRIMG + r * SPITCH + ((s16 ^ swz(r)) << 4)) = ps[j];
+        simg_stage(ib, TRIMG, lrow + 8 * it, lc4, pb[it]);
       }
     }
     __syncthreads();
@@ -1080,40 +1059,23 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
 }
 
 int tn_tr_rows_per_tile() { return TRR; }
-// s3: the pre-split-B variant; built for two (208 registers) and for three (168, 14 spilled) workgroups per CU, A/B by GNM_VARIANTS
-int tn_s3_occ_variant();   // gnm_fused.hip
-int tn_tr_occupancy(bool s3, bool conv, bool h2) {
-  if (h2 && !s3) return conv ? occ_blocks<tn_tr_k<false, true, 2, true>>() : occ_blocks<tn_tr_k<false, false, 2, true>>();
-  if (conv) return s3 ? occ_blocks<tn_tr_k<true, true, 2>>() : occ_blocks<tn_tr_k<false, true, 2>>();
-  if (!s3) return occ_blocks<tn_tr_k<false, false, 2>>();
-  return tn_s3_occ_variant() == 3 ? occ_blocks<tn_tr_k<true, false, 3>>() : occ_blocks<tn_tr_k<true, false, 2>>();
+int tn_tr_occupancy(bool conv, bool h2) {
+  if (h2) return conv ? occ_blocks<tn_tr_k<true, 2, true>>() : occ_blocks<tn_tr_k<false, 2, true>>();
+  return conv ? occ_blocks<tn_tr_k<true, 2>>() : occ_blocks<tn_tr_k<false, 2>>();
 }
-// ldb < 0: B is the pre-split image (ncgb = 1);  cv: the A operand is formed from raw sums (ncg = 2, ncgb = 1);
-// h2: the f16x2 form (fp32 B operand only)
+// cv: the A operand is formed from raw sums (ncg = 2, ncgb = 1);  h2: the f16x2 form
 void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B, int64_t ldb, int ncgb, float* slab,
                   double* partials, int nslot, int64_t tiles_per_slot, hipStream_t st, const TnConv* cv, bool h2) {
   const TnConv none{};
-  if (h2 && ldb >= 0 && cv)
-    hipLaunchKernelGGL((tn_tr_k<false, true, 2, true>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, 1, slab,
-                       partials, nslot, tiles_per_slot, *cv);
-  else if (h2 && ldb >= 0)
-    hipLaunchKernelGGL((tn_tr_k<false, false, 2, true>), dim3(nslot * ncg * ncgb), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, ncgb,
-                       slab, partials, nslot, tiles_per_slot, none);
-  else if (cv && ldb < 0)
-    hipLaunchKernelGGL((tn_tr_k<true, true, 2>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, (int64_t)0, 1, slab,
-                       partials, nslot, tiles_per_slot, *cv);
-  else if (cv)
-    hipLaunchKernelGGL((tn_tr_k<false, true, 2>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, 1, slab,
-                       partials, nslot, tiles_per_slot, *cv);
-  else if (ldb < 0 && tn_s3_occ_variant() == 3)
-    hipLaunchKernelGGL((tn_tr_k<true, false, 3>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, (int64_t)0, 1, slab,
-                       partials, nslot, tiles_per_slot, none);
-  else if (ldb < 0)
-    hipLaunchKernelGGL((tn_tr_k<true, false, 2>), dim3(nslot * ncg), dim3(kBlock), 0, st, M, A, lda, ncg, B, (int64_t)0, 1, slab,
-                       partials, nslot, tiles_per_slot, none);
-  else
-    hipLaunchKernelGGL((tn_tr_k<false, false, 2>), dim3(nslot * ncg * ncgb), dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, ncgb,
-                       slab, partials, nslot, tiles_per_slot, none);
+  const dim3 grid(nslot * ncg * (cv ? 1 : ncgb));
+#define GNM_TN_LAUNCH(CONV, H2)                                                                                             \
+  hipLaunchKernelGGL((tn_tr_k<CONV, 2, H2>), grid, dim3(kBlock), 0, st, M, A, lda, ncg, B, ldb, cv ? 1 : ncgb, slab, partials, \
+                     nslot, tiles_per_slot, cv ? *cv : none)
+  if (cv && h2) GNM_TN_LAUNCH(true, true);
+  else if (cv) GNM_TN_LAUNCH(true, false);
+  else if (h2) GNM_TN_LAUNCH(false, true);
+  else GNM_TN_LAUNCH(false, false);
+#undef GNM_TN_LAUNCH
 }
 
 }  // namespace gnm

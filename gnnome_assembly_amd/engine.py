@@ -39,7 +39,7 @@ ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
 
 
 _OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TN_SPLIT", "TWO_SIDED", "TWO_SIDED_FWD", "WIDE_FUSED",
-                 "PRESPLIT", "PRESPLIT_L0", "NODE_FUSED")
+                 "NODE_FUSED")
 
 
 _options_lock = threading.RLock()
@@ -48,7 +48,7 @@ _options_lock = threading.RLock()
 @contextlib.contextmanager
 def options(**kw):
     """Temporarily change schedule switches of this module (FUSED, ACTIVATIONS, CHAIN, TN_SIDE, TN_SIDE_CAP, SRC_SIDE_CAP, TN_AT,
-    TN_SPLIT, TWO_SIDED, TWO_SIDED_FWD, WIDE_FUSED, PRESPLIT, PRESPLIT_L0, NODE_FUSED) and restore them on exit, whatever happens
+    TN_SPLIT, TWO_SIDED, TWO_SIDED_FWD, WIDE_FUSED, NODE_FUSED) and restore them on exit, whatever happens
     inside:
         with engine.options(TWO_SIDED=False, CHAIN=False): ...
     The switches select between schedules that compute the same thing (tests and bench.py A/B them).  They are process-wide and
@@ -315,7 +315,6 @@ class LayerParams:
 
 @dataclass
 class LayerSaved:
-    hs_in: torch.Tensor = None     # the pre-split image of h_in (PRESPLIT), for the projections' weight gradient
     h_in: torch.Tensor = None
     e_in: torch.Tensor = None
     P: torch.Tensor = None
@@ -330,7 +329,7 @@ class LayerSaved:
     stat_h: torch.Tensor = None
 
 
-def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk, hs_in=None):
+def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
     """P = h W5^T + b5 [N,5H] and t = e W3^T + b3 + B1h[src] + B2h[dst] [E,H] (gated_gcn_full.py:107-113,120-121);
     leaves the BatchNorm partial sums of t in the scratch buffer and their count in nblk.  H is the layer's OUTPUT
     width; h_in / e_in may be narrower or wider (in_channels != out_channels: the generic GEMM route)."""
@@ -344,11 +343,7 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk, hs_in=None):
         # W-stationary fused MFMA path: projections, then t + BatchNorm partials in one pass
         need = lib.gnm_rowtile_workspace_bytes(5 * H)
         ws = sc.ws(need)
-        if hs_in is not None:       # the projections copy the pre-split image of h_in instead of splitting it in 5 workgroup classes
-            _call("gnm_node_proj_fwd_s3", N, H, 5 * H, _ptr(hs_in), _ptr(prm.W5), _ptr(prm.b5), _ptr(P), _ptr(ws), need, st,
-                  tag="gnm_node_proj_fwd")
-        else:
-            _call("gnm_node_proj_fwd", N, H, 5 * H, _ptr(h_in), _ptr(prm.W5), _ptr(prm.b5), _ptr(P), _ptr(ws), need, st)
+        _call("gnm_node_proj_fwd", N, H, 5 * H, _ptr(h_in), _ptr(prm.W5), _ptr(prm.b5), _ptr(P), _ptr(ws), need, st)
         _call("gnm_edge_t_fused_fwd", E, H, _ptr(e_in), _ptr(prm.W3), _ptr(prm.b3), _ptr(P), _ptr(idx["isrc"]),
               _ptr(idx["idst"]), _ptr(t), _ptr(sc.partials), C.byref(nblk), _ptr(ws), need, st)
     elif H == 256 and FUSED and WIDE_FUSED and e_in.shape[1] == H and _lib.split_mode():
@@ -371,17 +366,14 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk, hs_in=None):
 
 @on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
 def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True,
-                  residual: bool = True, plan: Optional[dict] = None, ln_width: Optional[int] = None, aux: Optional[dict] = None):
+                  residual: bool = True, plan: Optional[dict] = None, ln_width: Optional[int] = None):
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
     Returns (h_out, e_out, LayerSaved or None).  H = out_channels; h_in [N,Hin], e_in [E,Hin] with Hin != H only
     when residual is False (the reference drops the residual then: gated_gcn_full.py:41-42).
     plan (graph.sweep_plan(device, 2), BatchNorm, H = 128 or 256): gate + by-source aggregation as ONE two-sided sweep.
     ln_width (LayerNorm mode, a layer zero-padded to the kernel width H): the layer's real out_channels -- nn.LayerNorm
-    normalises over those (gated_gcn_full.py:58-59), the dead channels are left out of the row statistics.
-    aux (PRESPLIT, model_forward): aux["hs_in"] = the pre-split image of h_in, or None; with aux["make_hs"] the node update also
-    writes the image of h_out and leaves it in aux["hs_out"] (for the next layer's projections)."""
+    normalises over those (gated_gcn_full.py:58-59), the dead channels are left out of the row statistics."""
     lnw = H if ln_width is None else int(ln_width)
-    hs_in = aux.get("hs_in") if aux else None
     if residual and h_in.shape[1] != H:
         raise _lib.GnmError("layer_forward: a residual layer needs in_channels == out_channels")
     res_e = _ptr(e_in) if residual else C.c_void_p(0)
@@ -392,7 +384,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     st = _stream()
     nblk = C.c_int(0)
     f32 = dict(dtype=torch.float32, device=dev)
-    P, t = _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk, hs_in)
+    P, t = _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk)
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
@@ -426,19 +418,14 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     h_out = torch.empty(N, H, **f32)
     if batch_norm:
         stat_h = bn_finalize(sc.partials, nblk.value, N, H, prm.gamma_h, prm.beta_h)
-        if aux and aux.get("make_hs"):
-            aux["hs_out"] = _s3_empty(N, dev)
-            _call("gnm_node_update_fwd_s3", N, H, _ptr(z), _ptr(stat_h), res_h, _ptr(h_out), _ptr(aux["hs_out"]), st,
-                  tag="gnm_node_update_fwd")
-        else:
-            _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), res_h, _ptr(h_out), st)
+        _call("gnm_node_update_fwd", N, H, _ptr(z), _ptr(stat_h), res_h, _ptr(h_out), st)
     else:
         stat_h = None
         _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), res_h, _ptr(h_out), lnw, st)
     saved = None
     if save:
         lean = ACTIVATIONS == "lean"
-        saved = LayerSaved(hs_in=hs_in, h_in=h_in, e_in=e_in, P=None if lean else P, t=None if lean else t, stat_e=stat_e, e_out=e_out,
+        saved = LayerSaved(h_in=h_in, e_in=e_in, P=None if lean else P, t=None if lean else t, stat_e=stat_e, e_out=e_out,
                            hf=hf, inv_f=inv_f, hb=hb, inv_b=inv_b, z=z, stat_h=stat_h)
     return h_out, e_out, saved
 
@@ -465,7 +452,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     f32 = dict(dtype=torch.float32, device=dev)
     g: Dict[str, torch.Tensor] = {}
     if s.P is None or s.t is None:      # "lean" activations: rebuild P and t with the kernels that made them
-        s.P, s.t = _proj_and_t(idx, N, E, H, prm, s.h_in, s.e_in, C.c_int(0), s.hs_in)
+        s.P, s.t = _proj_and_t(idx, N, E, H, prm, s.h_in, s.e_in, C.c_int(0))
     gP = torch.empty(N, 5 * H, **f32)
     Q = torch.empty(N, (2 if batch_norm else 4) * H, **f32)     # BatchNorm mode: Qf | Qb; LayerNorm mode keeps Rf, Rb too
     g["W3"] = new("W3", H, Hin)
@@ -608,16 +595,9 @@ TWO_SIDED_FWD = os.environ.get("GNM_TWO_SIDED_FWD", "1") != "0"
 WIDE_FUSED = os.environ.get("GNM_WIDE_FUSED", "1") != "0"
 
 
-# Round 5, the node side.  PRESPLIT (GNM_PRESPLIT=1; OFF by default): the kernel that produces a layer's node features h
-# (node_update_fwd) also writes them as the three-part bf16 image the split-mode matrix kernels stage (gnm.h "the pre-split
-# image"); the next layer's projections and their weight gradient copy it instead of splitting the same rows in five workgroup
-# classes each.  Bit-identical results either way.  MEASURED (profiles/r05_ab_node_side.txt, one box): the projections do not
-# get faster at all (11.66 vs 11.70 ms per step: their 60 %-busy matrix pipe waits on the stage -> barrier -> MFMA -> barrier ->
-# epilogue phase structure at two workgroups per CU, not on the ~320 split instructions of a tile), the weight gradient gains
-# 0.9 ms per step and the node update pays 1.7 ms for the extra 1.5 [N,H] of writes: +1.4 ms per step in all.  Kept as the
-# measurement VERDICT r4 (e) asked for; PRESPLIT_L0: also for layer 0, whose input comes from the positional-encoding GEMM.
-PRESPLIT = os.environ.get("GNM_PRESPLIT", "0") != "0"
-PRESPLIT_L0 = os.environ.get("GNM_PRESPLIT_L0", "1") != "0"
+# Round 5, the node side.  (A pre-split image of h -- the kernel that produces h also writes its three bf16 terms, the projections
+# and their weight gradient copy them instead of splitting the rows in every workgroup class -- was built, measured at +1.4 ms per
+# step, profiles/r05_ab_node_side.txt, and removed again when the f16x2 mode made its bf16x3 layout the wrong one: DESIGN.md 3g.)
 # NODE_FUSED (chained schedule with a sweep plan): no gnm_node_bgrad / gnm_node_bwd_stats launches -- the conversion of the raw
 # by-source / by-destination sums runs in the operand load of the weight-gradient kernel of those two column groups
 # (gnm_tn128_bgrad, which also writes them for the projection backward behind it), the BatchNorm_h backward sums of the layer
@@ -625,32 +605,14 @@ PRESPLIT_L0 = os.environ.get("GNM_PRESPLIT_L0", "1") != "0"
 NODE_FUSED = os.environ.get("GNM_NODE_FUSED", "1") != "0"
 
 
-def presplit_eligible(H: int, batch_norm: bool) -> bool:
-    return PRESPLIT and FUSED and H == 128 and batch_norm and _lib.get_matmul_mode() == "bf16x3"
-
-
-def _s3_empty(N: int, device) -> torch.Tensor:
-    return torch.empty(N * 768, dtype=torch.uint8, device=device)
-
-
-def split_rows_s3(x: torch.Tensor) -> torch.Tensor:
-    """The pre-split image of x [N,128] (gnm_split_rows_s3)."""
-    xs = _s3_empty(x.shape[0], x.device)
-    _call("gnm_split_rows_s3", x.shape[0], x.shape[1], _ptr(x), _ptr(xs), _stream())
-    return xs
-
-
-def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, hs: Optional[torch.Tensor], W, b, partials, ws, need,
-          stream=None, tag: str = None):
-    """gW[cg] = A[:, cg]^T h, gb[cg] = sum A[:, cg] (gnm_tn128), from the pre-split image of h when there is one.  `stream`:
-    a torch side stream (the call is then not profiled); None = the current stream."""
-    name = "gnm_tn128_s3" if hs is not None else "gnm_tn128"
-    B = hs if hs is not None else h
+def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, W, b, partials, ws, need, stream=None, tag: str = None):
+    """gW[cg] = A[:, cg]^T h, gb[cg] = sum A[:, cg] (gnm_tn128).  `stream`: a torch side stream (the call is then not profiled);
+    None = the current stream."""
     if stream is None:
-        _call(name, N, _ptr(A), lda, ncg, _ptr(B), _ptr(W), _ptr(b), _ptr(partials), _ptr(ws), need, _stream(), tag=tag)
+        _call("gnm_tn128", N, _ptr(A), lda, ncg, _ptr(h), _ptr(W), _ptr(b), _ptr(partials), _ptr(ws), need, _stream(), tag=tag)
     else:
-        _lib.check(getattr(_lib.load(), name)(N, _ptr(A), lda, ncg, _ptr(B), _ptr(W), _ptr(b), _ptr(partials), _ptr(ws), need,
-                                              C.c_void_p(stream.cuda_stream)), name)
+        _lib.check(_lib.load().gnm_tn128(N, _ptr(A), lda, ncg, _ptr(h), _ptr(W), _ptr(b), _ptr(partials), _ptr(ws), need,
+                                         C.c_void_p(stream.cuda_stream)), "gnm_tn128")
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
@@ -684,7 +646,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             prms[i] = layer_params(P, i)
         s = saved[i]
         if s.P is None or s.t is None:      # "lean" activations
-            s.P, s.t = _proj_and_t(idx, N, E, H, prms[i], s.h_in, s.e_in, C.c_int(0), s.hs_in)
+            s.P, s.t = _proj_and_t(idx, N, E, H, prms[i], s.h_in, s.e_in, C.c_int(0))
         return prms[i], s
 
     def node(i, gh_out, nblk_h=None):
@@ -733,7 +695,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     side = _side_stream(dev) if (TN_SIDE and _prof is None and ACTIVATIONS != "lean") else None
     main = torch.cuda.current_stream()
     fusedn = NODE_FUSED and plan is not None      # the node side without node_bgrad / node_bwd_stats launches (see NODE_FUSED)
-    pending = None              # (gP, h_in, hs_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
+    pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
     pending2 = None             # the same, when only its first launch (TN_SPLIT) has been issued
     held: List[torch.Tensor] = []   # what the side stream is reading; dropped only after the main stream has waited for it
 
@@ -757,14 +719,14 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             #      column groups on the side stream beside the HBM-bound BatchNorm_h backward of layer i-1
             sc3 = scratch(dev, "tn")
             if side is not None and pending is not None:        # tn012 of the layer above, deferred (TN_AT = "next")
-                pgP, ph, phs, pW, pb = pending
+                pgP, ph, pW, pb = pending
                 side_begin()
-                tn128(N, pgP, 5 * H, 3, ph, phs, pW, pb, sc3.partials, sc3.ws(need_t), need_t, stream=side)
-                held.extend((pgP, ph) if phs is None else (pgP, phs))
+                tn128(N, pgP, 5 * H, 3, ph, pW, pb, sc3.partials, sc3.ws(need_t), need_t, stream=side)
+                held.extend((pgP, ph))
                 pending = None
             _call("gnm_tn128_bgrad", N, H, _ptr(UT), _ptr(Ud), _ptr(Td), Ud.stride(0), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]), _ptr(gP),
-                  _ptr(s.h_in) if s.hs_in is None else C.c_void_p(0), _ptr(s.hs_in), _ptr(g["W5"][3 * H:]), _ptr(g["b5"][3 * H:]),
+                  _ptr(s.h_in), _ptr(g["W5"][3 * H:]), _ptr(g["b5"][3 * H:]),
                   _ptr(sc.partials), _ptr(ws), need_t, st)
             del Ud, Td, Q
             UT = None
@@ -777,32 +739,30 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
             if side is not None and TN_AT == "now":             # tn012(i) right away, beside node(i-1)'s [N,H] passes
                 side_begin()
-                tn128(N, gP, 5 * H, 3, s.h_in, s.hs_in, g["W5"], g["b5"], sc3.partials, sc3.ws(need_t), need_t, stream=side)
-                held.extend((gP, s.h_in) if s.hs_in is None else (gP, s.hs_in))
+                tn128(N, gP, 5 * H, 3, s.h_in, g["W5"], g["b5"], sc3.partials, sc3.ws(need_t), need_t, stream=side)
+                held.extend((gP, s.h_in))
             elif side is not None and i > 0:
-                pending = (gP, s.h_in, s.hs_in, g["W5"], g["b5"])
+                pending = (gP, s.h_in, g["W5"], g["b5"])
             else:       # no side stream (lean activations, per-op timing) or the last iteration: the same launch on this stream
-                tn128(N, gP, 5 * H, 3, s.h_in, s.hs_in, g["W5"], g["b5"], sc.partials if nblk_h is None else sc3.partials,
+                tn128(N, gP, 5 * H, 3, s.h_in, g["W5"], g["b5"], sc.partials if nblk_h is None else sc3.partials,
                       sc.ws(max(need_p, need_f, need_t)) if nblk_h is None else sc3.ws(need_t), need_t, tag="gnm_tn128[3]")
         else:
             src_cap = 0
             if pending is not None:
                 # the matrix-bound weight gradient of the layer above on the side stream, beside this layer's HBM-bound
                 # by-source pass (see TN_SIDE)
-                pgP, ph, phs, pW, pb = pending
+                pgP, ph, pW, pb = pending
                 side_begin()
                 sc3 = scratch(dev, "tn")
                 if TN_SPLIT and UT is not None:
-                    tn128(N, pgP[:, 3 * H:], 5 * H, 2, ph, phs, pW[3 * H:], pb[3 * H:], sc3.partials, sc3.ws(need_t), need_t, stream=side)
+                    tn128(N, pgP[:, 3 * H:], 5 * H, 2, ph, pW[3 * H:], pb[3 * H:], sc3.partials, sc3.ws(need_t), need_t, stream=side)
                     pending2 = pending
-                elif phs is not None:
-                    tn128(N, pgP, 5 * H, 5, ph, phs, pW, pb, sc3.partials, sc3.ws(need_t), need_t, stream=side)
                 else:
                     ws3 = sc3.ws(need_p)
                     _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(pgP), _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials),
                                                         _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
                                "gnm_node_proj_bwd_tn")
-                held.extend((pgP, ph) if phs is None else (pgP, phs))
+                held.extend((pgP, ph))
                 pending = None
                 src_cap = SRC_SIDE_CAP
             if UT is None:
@@ -818,35 +778,29 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             if not (side is not None and TN_AT == "now"):
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
             if pending2 is not None:        # the other three column groups of the layer above, behind this layer's nn
-                pgP, ph, phs, pW, pb = pending2
+                pgP, ph, pW, pb = pending2
                 side.wait_stream(main)
                 sc3 = scratch(dev, "tn")
-                tn128(N, pgP, 5 * H, 3, ph, phs, pW, pb, sc3.partials, sc3.ws(need_t), need_t, stream=side)
+                tn128(N, pgP, 5 * H, 3, ph, pW, pb, sc3.partials, sc3.ws(need_t), need_t, stream=side)
                 pending2 = None
             if side is not None and TN_AT == "now":
                 side_begin()
                 sc3 = scratch(dev, "tn")
-                if s.hs_in is not None:
-                    tn128(N, gP, 5 * H, 5, s.h_in, s.hs_in, g["W5"], g["b5"], sc3.partials, sc3.ws(need_t), need_t, stream=side)
-                else:
-                    ws3 = sc3.ws(need_p)
-                    _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc3.partials),
-                                                        _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
-                               "gnm_node_proj_bwd_tn")
-                held.extend((gP, s.h_in) if s.hs_in is None else (gP, s.hs_in))
+                ws3 = sc3.ws(need_p)
+                _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc3.partials),
+                                                    _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
+                           "gnm_node_proj_bwd_tn")
+                held.extend((gP, s.h_in))
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
             elif side is not None and i > 0:
-                pending = (gP, s.h_in, s.hs_in, g["W5"], g["b5"])
+                pending = (gP, s.h_in, g["W5"], g["b5"])
             elif side is None and i > 0 and TN_SPLIT and split2:
                 # no side stream (lean activations, per-op timing): the same two launches the deferred path issues, back to back --
                 # the row partition of a launch depends on its column-group count, and the two modes must stay bit-identical
                 ws_t = sc.ws(max(need_p, need_f, need_t))
-                tn128(N, gP[:, 3 * H:], 5 * H, 2, s.h_in, s.hs_in, g["W5"][3 * H:], g["b5"][3 * H:], sc.partials, ws_t, need_t,
+                tn128(N, gP[:, 3 * H:], 5 * H, 2, s.h_in, g["W5"][3 * H:], g["b5"][3 * H:], sc.partials, ws_t, need_t,
                       tag="gnm_node_proj_bwd_tn")
-                tn128(N, gP, 5 * H, 3, s.h_in, s.hs_in, g["W5"], g["b5"], sc.partials, ws_t, need_t, tag="gnm_node_proj_bwd_tn")
-            elif s.hs_in is not None:
-                tn128(N, gP, 5 * H, 5, s.h_in, s.hs_in, g["W5"], g["b5"], sc.partials, sc.ws(max(need_p, need_f, need_t)), need_t,
-                      tag="gnm_node_proj_bwd_tn")
+                tn128(N, gP, 5 * H, 3, s.h_in, g["W5"], g["b5"], sc.partials, ws_t, need_t, tag="gnm_node_proj_bwd_tn")
             else:
                 _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
                       _ptr(sc.partials), _ptr(ws), need_p, 0, st)
@@ -1073,12 +1027,8 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw) if save else None
     plan2 = graph.sweep_plan(dev, 2) if (TWO_SIDED_FWD and batch_norm and H in (128, 256) and hasattr(graph, "sweep_plan")) else None
-    presplit = presplit_eligible(H, batch_norm)
-    hs = split_rows_s3(h) if (presplit and PRESPLIT_L0) else None       # layer 0's input comes from the GEMM above
     for i in range(num_layers):
-        aux = {"hs_in": hs, "make_hs": presplit and i + 1 < num_layers}     # the predictor reads the last h as fp32
-        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width, aux=aux)
-        hs = aux.get("hs_out")
+        h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width)
         if save:
             ms.layers.append(ls)
     scores, ps = predictor_forward(idx, N, E, H, P["predictor.W1.weight"], P["predictor.W1.bias"],

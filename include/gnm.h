@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 5   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points */
+#define GNM_ABI_VERSION 6   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -206,18 +206,6 @@ int gnm_node_agg_src_fwd(int64_t N, int64_t E, int H, const float* e_out, const 
 /* node_update: h_out = relu(z*scale+shift) + h_in                             (:147-152) */
 int gnm_node_update_fwd(int64_t N, int H, const float* z, const float* stat_h, const float* h_in,
                         float* h_out, void* stream);
-/* ---- the pre-split image of a [N,128] node tensor (ABI 5; bf16x3 matmul mode, H = 128) ----
- * S3[v] = [ hi(x[v][0..127]) | mid | lo ] bf16, 768 bytes per row, x = hi + mid + lo exactly: the three parts the
- * split-mode matrix kernels otherwise compute while staging.  The node features h of a layer are a matrix operand in ten
- * workgroup classes (5 x nn.Linear(h) forward, gated_gcn_full.py:107-112, and their 5 weight gradients): the kernel that
- * PRODUCES h writes the image once (gnm_node_update_fwd_s3 = gnm_node_update_fwd + the image; gnm_split_rows_s3 for
- * a tensor that exists already), gnm_node_proj_fwd_s3 / gnm_tn128_s3 copy it into LDS.  Results are bit-identical to the
- * fp32-operand entry points.  gnm_s3_bytes(N, H): size of the image (0 if H != 128).                              */
-size_t gnm_s3_bytes(int64_t N, int H);
-int gnm_split_rows_s3(int64_t N, int H, const float* x, void* xs, void* stream);
-int gnm_node_update_fwd_s3(int64_t N, int H, const float* z, const float* stat_h, const float* h_in, float* h_out,
-                           void* hs, void* stream);
-
 /* ---- GatedGCN layer, backward (autograd of the above) -------
  * node_bwd_stats: gw = gh_out*[relu(bn(z))>0]; partials (sum gw, sum gw*zhat)            */
 int gnm_node_bwd_stats(int64_t N, int H, const float* z, const float* stat_h, const float* gh_out,
@@ -322,9 +310,6 @@ int gnm_edge_bwd_gt_nn(int64_t E, int H, const float* ge, const float* t, const 
                        void* stream);
 int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, const float* W, const float* b,
                       float* Pout, void* ws, size_t ws_bytes, void* stream);
-/* the same from the pre-split image hs of h (any ncols % 128 == 0; same workspace) */
-int gnm_node_proj_fwd_s3(int64_t N, int H, int ncols, const void* hs, const float* W, const float* b,
-                         float* Pout, void* ws, size_t ws_bytes, void* stream);
 /* edge_bwd_chain (bf16x3 mode, H = 128): gnm_edge_bwd_fused of layer i ("hi": ge, t_hi, e_mid = e_in(i) = e_out(i-1),
  * stat/bstat/gamma/W3 of layer i -> gW3_hi, gb3_hi) CHAINED with gnm_edge_bwd_dst of layer i-1 ("lo": t_lo, stat_lo,
  * P_lo, Q_lo, hf_lo, hb_lo -> gP_lo[:,2H:3H], Ud_lo, Td_lo, BatchNorm partials in partials_lo, *nblk_out rows) in
@@ -389,14 +374,14 @@ int gnm_node_proj_bwd_tn(int64_t N, int H, int ncols, const float* gP, const flo
  * tn128_bgrad = gnm_tn128 over the column groups gB1h | gB2h of gP (out = gW5[3H:5H], colsum = gb5[3H:5H]) with
  *   gnm_node_bgrad in its operand load: the groups are FORMED from the raw sums the two-sided sweep left (UT = [Us | Ts] with
  *   pitch 2H; Ud, Td with pitch ud_pitch = H or 2H) and the BatchNorm_e backward means, and WRITTEN to gP[:, 3H:5H] (row
- *   pitch 5H) for gnm_node_proj_bwd_nn*, which must run behind this call.  B = the layer's h_in [M,128], or Bs = its
- *   pre-split image: exactly one of the two is non-NULL.  ws >= gnm_tn128_workspace_bytes().   autograd of :107-112,120-122 */
+ *   pitch 5H) for gnm_node_proj_bwd_nn*, which must run behind this call.  B = the layer's h_in [M,128].
+ *   ws >= gnm_tn128_workspace_bytes().                                                  autograd of :107-112,120-122 */
 int gnm_node_proj_bwd_nn_stats(int64_t N, int H, int ncols, const float* gP, const float* W, const float* gh_out,
                                float* gh_in, const float* z_lo, const float* stat_h_lo, double* partials, int* nblk_out,
                                void* ws, size_t ws_bytes, void* stream);
 int gnm_tn128_bgrad(int64_t M, int H, const float* UT, const float* Ud, const float* Td, int64_t ud_pitch,
                     const float* stat_e, const float* bstat_e, const float* gamma_e, const int32_t* in_ptr,
-                    const int32_t* out_ptr, float* gP, const float* B, const void* Bs, float* out, float* colsum,
+                    const int32_t* out_ptr, float* gP, const float* B, float* out, float* colsum,
                     double* partials, void* ws, size_t ws_bytes, void* stream);
 size_t gnm_edge_bwd_fused_workspace_bytes(void);
 int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const float* t, const float* e_in,
@@ -448,9 +433,6 @@ int gnm_predictor_fused_bwd(int64_t E, int H, int HS, float* hid, const float* g
 size_t gnm_tn128_workspace_bytes(void);
 int gnm_tn128(int64_t M, const float* A, int64_t lda, int ncg, const float* B, float* out, float* colsum,
               double* partials, void* ws, size_t ws_bytes, void* stream);
-/* the same with B given as its pre-split image Bs [M][3][128] bf16 */
-int gnm_tn128_s3(int64_t M, const float* A, int64_t lda, int ncg, const void* Bs, float* out, float* colsum,
-                 double* partials, void* ws, size_t ws_bytes, void* stream);
 /* reduce double partials [nblk][rows][W] -> float out[rows][W] */
 int gnm_reduce_partials(const double* partials, int nblk, int rows, int W, float* out, void* stream);
 /* out[v*ldo + c] = sum_{m in [ptr[v],ptr[v+1])} X[(pos ? pos[m] : m)*W + c], c < W        */

@@ -349,7 +349,7 @@ int main() {
                             plan[1].d_s, plan[1].npb, d_UT, &nblk, d_ws, wsb, st));
     GNM_OK(gnm_edge_bwd_src_fix(plan[1].nfix, plan[1].d_fix, N, E, H, d.e_out, d.t, d.stat_e, d_ge, d_Q, d_outp, d_opos, d_odst, d_gP1, d_UT, st));
     GNM_OK(gnm_bn_bwd_finalize(d_part, nblk, E, H, d.bstat_e, d.g_gam_e, d.g_bet_e, st));
-    GNM_OK(gnm_tn128_bgrad(N, H, d_UT, d_Ud, d_Td, udp, d.stat_e, d.bstat_e, d.gam_e, d_inp, d_outp, d_gP1, d.h_in, nullptr,
+    GNM_OK(gnm_tn128_bgrad(N, H, d_UT, d_Ud, d_Td, udp, d.stat_e, d.bstat_e, d.gam_e, d_inp, d_outp, d_gP1, d.h_in,
                            d.gW5 + (size_t)3 * H * H, d.gb5 + 3 * H, d_part, d_ws, wsb, st));
     GNM_OK(gnm_node_proj_bwd_nn_stats(N, H, 5 * H, d_gP1, d.W5, d_gh, d_gh0, L[0].z, L[0].stat_h, d_part, &nblk_h, d_ws, wsb, st));
     GNM_OK(gnm_tn128(N, d_gP1, 5 * H, 3, d.h_in, d.gW5, d.gb5, d_part_tn, d_ws_tn, wsb, st));
@@ -363,7 +363,7 @@ int main() {
                                   plan[1].npb, d_UT, &nblk, d_ws, wsb, st));
     GNM_OK(gnm_edge_bwd_src_fix(plan[1].nfix, plan[1].d_fix, N, E, H, d.e_out, d.t, d.stat_e, d_ge, d_Q, d_outp, d_opos, d_odst, d_gP0, d_UT, st));
     GNM_OK(gnm_bn_bwd_finalize(d_part, nblk, E, H, d.bstat_e, d.g_gam_e, d.g_bet_e, st));
-    GNM_OK(gnm_tn128_bgrad(N, H, d_UT, d_Ud, d_Td, udp, d.stat_e, d.bstat_e, d.gam_e, d_inp, d_outp, d_gP0, d.h_in, nullptr,
+    GNM_OK(gnm_tn128_bgrad(N, H, d_UT, d_Ud, d_Td, udp, d.stat_e, d.bstat_e, d.gam_e, d_inp, d_outp, d_gP0, d.h_in,
                            d.gW5 + (size_t)3 * H * H, d.gb5 + 3 * H, d_part, d_ws, wsb, st));
     GNM_OK(gnm_node_proj_bwd_nn(N, H, 5 * H, d_gP0, d.W5, d_gh0, d_ghin, d_ws, wsb, st));
     GNM_OK(gnm_tn128(N, d_gP0, 5 * H, 3, d.h_in, d.gW5, d.gb5, d_part_tn, d_ws_tn, wsb, st));

@@ -193,7 +193,7 @@ def test_weight_gradient_kernel_keeps_one_unit_across_rows(case):
         sc = engine.scratch(dev)
         need = lib.gnm_tn128_workspace_bytes()
         gW, gb = torch.empty(3 * H, H, device=dev), torch.empty(3 * H, device=dev)
-        engine.tn128(N, A, 3 * H, 3, h, None, gW, gb, sc.partials, sc.ws(need), need)
+        engine.tn128(N, A, 3 * H, 3, h, gW, gb, sc.partials, sc.ws(need), need)
         torch.cuda.synchronize()
         return gW.cpu().numpy()
     _check(f"tn128 [{case}]", run, ref, scale, cw_bar=4e-6)

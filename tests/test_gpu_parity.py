@@ -116,7 +116,7 @@ def _cmp(name, got, want, rows):
 def test_library_loaded_and_device():
     from gnnome_assembly_amd import _lib
     lib = _lib.load()
-    assert lib.gnm_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.gnm_abi_version() == _lib.ABI_VERSION == 6
     assert lib.gnm_num_cus() >= 64
     print("CUs:", lib.gnm_num_cus(), torch.cuda.get_device_name(0))
 
@@ -1159,66 +1159,8 @@ def test_chained_backward_matches_the_layer_by_layer_backward():
 
 
 # -----------------------------------------------------------------------------------------
-# round 5: the node side (pre-split image of h, fused conversion / BatchNorm_h sums)
+# round 5: the node side (fused conversion / BatchNorm_h sums)
 # -----------------------------------------------------------------------------------------
-
-def test_presplit_image_kernels_are_bit_identical_to_the_fp32_operand_kernels(matmul_mode):
-    """include/gnm.h "the pre-split image": gnm_node_update_fwd_s3 = gnm_node_update_fwd + the three-part bf16 image of
-    h_out; gnm_node_proj_fwd_s3 / gnm_tn128_s3 copy that image where the fp32-operand kernels split the same rows in
-    every workgroup class.  Same parts, same MFMA order: P, gW5, gb5 bit for bit; the image reassembles h exactly."""
-    import ctypes as C
-    from gnnome_assembly_amd import engine, _lib
-    if matmul_mode != "bf16x3":
-        pytest.skip("the pre-split image holds the three bf16 terms of the bf16x3 mode")
-    dev = _dev()
-    lib = _lib.load()
-    H = 128
-    rng = np.random.default_rng(21)
-    for N in (70001, 4096, 37):          # ragged last tile, whole tiles, fewer rows than one tile
-        z = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dev)
-        h_prev = torch.from_numpy((rng.standard_normal((N, H)) * 3).astype(np.float32)).to(dev)
-        stat = torch.from_numpy(rng.standard_normal((4, H)).astype(np.float32)).to(dev)
-        W5 = torch.from_numpy((rng.standard_normal((5 * H, H)) / 11).astype(np.float32)).to(dev)
-        b5 = torch.from_numpy(rng.standard_normal(5 * H).astype(np.float32)).to(dev)
-        gP = torch.from_numpy((rng.standard_normal((N, 5 * H)) * 1e-3).astype(np.float32)).to(dev)
-        st = engine._stream()
-        h0 = torch.empty(N, H, device=dev)
-        h1 = torch.empty(N, H, device=dev)
-        hs = torch.empty(N * 768, dtype=torch.uint8, device=dev)
-        engine._call("gnm_node_update_fwd", N, H, engine._ptr(z), engine._ptr(stat), engine._ptr(h_prev), engine._ptr(h0), st)
-        engine._call("gnm_node_update_fwd_s3", N, H, engine._ptr(z), engine._ptr(stat), engine._ptr(h_prev), engine._ptr(h1),
-                     engine._ptr(hs), st)
-        assert torch.equal(h0, h1)
-        assert torch.equal(engine.split_rows_s3(h0), hs)
-        parts = hs.view(torch.bfloat16).reshape(N, 3, H).float()
-        assert torch.equal((parts[:, 0] + parts[:, 1]) + parts[:, 2], h0), "hi + mid + lo must give h back exactly"
-        need = lib.gnm_rowtile_workspace_bytes(5 * H)
-        ws = engine.scratch(dev).ws(max(need, lib.gnm_tn128_workspace_bytes()))
-        P0 = torch.empty(N, 5 * H, device=dev)
-        P1 = torch.empty(N, 5 * H, device=dev)
-        engine._call("gnm_node_proj_fwd", N, H, 5 * H, engine._ptr(h0), engine._ptr(W5), engine._ptr(b5), engine._ptr(P0),
-                     engine._ptr(ws), need, st)
-        engine._call("gnm_node_proj_fwd_s3", N, H, 5 * H, engine._ptr(hs), engine._ptr(W5), engine._ptr(b5), engine._ptr(P1),
-                     engine._ptr(ws), need, st)
-        assert torch.equal(P0, P1), f"N={N}: projections from the image differ"
-        ref = h0.double() @ W5.double().t() + b5.double()
-        assert float((P1.double() - ref).norm() / ref.norm()) < 2e-6
-        sc = engine.scratch(dev)
-        needt = lib.gnm_tn128_workspace_bytes()
-        for ncg in (5, 3, 2):
-            g0, c0 = torch.empty(ncg * H, H, device=dev), torch.empty(ncg * H, device=dev)
-            g1, c1 = torch.empty(ncg * H, H, device=dev), torch.empty(ncg * H, device=dev)
-            engine.tn128(N, gP, 5 * H, ncg, h0, None, g0, c0, sc.partials, ws, needt)
-            engine.tn128(N, gP, 5 * H, ncg, h0, hs, g1, c1, sc.partials, ws, needt)
-            assert torch.equal(g0, g1) and torch.equal(c0, c1), f"N={N} ncg={ncg}: weight gradient from the image differs"
-        for occ in (3, 2):          # the two builds of the pre-split weight-gradient kernel
-            assert lib.gnm_debug_set_variant(b"tn_s3_occ", occ) == 0
-            g2, c2 = torch.empty(5 * H, H, device=dev), torch.empty(5 * H, device=dev)
-            engine.tn128(N, gP, 5 * H, 5, h0, hs, g2, c2, sc.partials, ws, needt)
-            ref = gP.double().t() @ h0.double()
-            assert float((g2.double() - ref).norm() / ref.norm()) < 2e-6
-        torch.cuda.synchronize()
-
 
 @pytest.mark.default_mode_only
 def test_fused_node_backward_kernels_match_the_separate_launches():
@@ -1241,7 +1183,6 @@ def test_fused_node_backward_kernels_match_the_separate_launches():
         out_ptr = torch.from_numpy(np.concatenate(([0], np.cumsum(deg[1]))).astype(np.int32)).to(dev)
         h, W5, gh_out, z = f(N, H), f(5 * H, H, s=0.09), f(N, H, s=1e-3), f(N, H)
         stat_h = f(4, H)
-        hs = engine.split_rows_s3(h)
         gP0 = f(N, 5 * H, s=1e-3)
         gP1 = gP0.clone()
         gP1[:, 3 * H:] = float("nan")          # the fused kernel must write every element of the two groups
@@ -1253,13 +1194,13 @@ def test_fused_node_backward_kernels_match_the_separate_launches():
         engine._call("gnm_node_bgrad", N, H, engine._ptr(stat_e), engine._ptr(bstat_e), engine._ptr(gamma_e), engine._ptr(in_ptr),
                      engine._ptr(out_ptr), engine._ptr(UT), engine._ptr(Ud), engine._ptr(Td), Ud.stride(0), engine._ptr(gP0), st)
         gW0, gb0 = torch.empty(2 * H, H, device=dev), torch.empty(2 * H, device=dev)
-        engine.tn128(N, gP0[:, 3 * H:], 5 * H, 2, h, None, gW0, gb0, sc.partials, ws, needt)
-        for use_hs in (False, True):
+        engine.tn128(N, gP0[:, 3 * H:], 5 * H, 2, h, gW0, gb0, sc.partials, ws, needt)
+        for _rep in range(2):
             gW1, gb1 = torch.empty(2 * H, H, device=dev), torch.empty(2 * H, device=dev)
             gP1[:, 3 * H:] = float("nan")
             engine._call("gnm_tn128_bgrad", N, H, engine._ptr(UT), engine._ptr(Ud), engine._ptr(Td), Ud.stride(0),
                          engine._ptr(stat_e), engine._ptr(bstat_e), engine._ptr(gamma_e), engine._ptr(in_ptr), engine._ptr(out_ptr),
-                         engine._ptr(gP1), C.c_void_p(0) if use_hs else engine._ptr(h), engine._ptr(hs) if use_hs else C.c_void_p(0),
+                         engine._ptr(gP1), engine._ptr(h),
                          engine._ptr(gW1), engine._ptr(gb1), engine._ptr(sc.partials), engine._ptr(ws), needt, st)
             assert bool(torch.isfinite(gP1).all())
             d = (gP1[:, 3 * H:] - gP0[:, 3 * H:]).abs().max().item()
@@ -1288,10 +1229,9 @@ def test_fused_node_backward_kernels_match_the_separate_launches():
 @pytest.mark.default_mode_only
 @pytest.mark.parametrize("ids", ["sorted", "shuffled"])
 def test_round5_node_side_schedule_matches_the_round4_schedule(ids):
-    """engine.PRESPLIT (opt-in) + engine.NODE_FUSED (default) against the round-4 schedule (fp32 operands everywhere, gnm_node_bgrad and
-    gnm_node_bwd_stats as launches of their own): the forward is bit-identical (the image holds the same three parts the
-    kernels compute), every gradient agrees to summation order, two runs are bit-identical, and each switch alone as well.
-    Also under lean activations (no side stream: the same launches back to back) bit for bit."""
+    """engine.NODE_FUSED (default) against the round-4 schedule (gnm_node_bgrad and gnm_node_bwd_stats as launches of their own): the
+    forward is the same code, every gradient agrees to summation order, two runs are bit-identical; under lean activations (no side
+    stream: the same launches back to back) and with the deferred weight-gradient kernel issued at the other point, bit for bit."""
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import engine
     dev = _dev()
@@ -1315,36 +1255,23 @@ def test_round5_node_side_schedule_matches_the_round4_schedule(ids):
             loss.backward()
             torch.cuda.synchronize()
             return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
-    s0, l0, g0 = run(PRESPLIT=False, NODE_FUSED=False)
-    s1, l1, g1 = run(PRESPLIT=True)
-    s2, l2, g2 = run(PRESPLIT=True)
-    assert torch.equal(s0, s1) and l0 == l1, "the pre-split image must not change the forward"
+    s0, l0, g0 = run(NODE_FUSED=False)
+    s1, l1, g1 = run()
+    s2, l2, g2 = run()
+    assert torch.equal(s0, s1) and l0 == l1, "the backward schedule must not change the forward"
     assert all(torch.equal(g1[k], g2[k]) for k in g1), "not run-to-run deterministic"
     gmax = max(float(v.abs().max()) for v in g0.values())
-
-    def close(ga, gb, what):
-        bad = []
-        for k in ga:
-            a, b = ga[k].double(), gb[k].double()
-            r = float((a - b).norm() / b.norm().clamp_min(1e-30))
-            if r > 2e-6 and float((a - b).abs().max()) > 1e-7 * gmax:
-                bad.append((k, r))
-        assert not bad, (what, bad)
-    close(g1, g0, "round 5 vs round 4")
-    _, _, g3 = run(PRESPLIT=True, NODE_FUSED=False)
-    assert all(torch.equal(g3[k], g0[k]) for k in g0), "the pre-split image alone must be bit-identical"
-    _, _, g4 = run(PRESPLIT=False, NODE_FUSED=True)
-    close(g4, g0, "NODE_FUSED alone")
-    _, _, g5 = run(PRESPLIT=True, PRESPLIT_L0=False)
-    assert all(torch.equal(g5[k], g1[k]) for k in g1), "layer 0 on fp32 operands must be bit-identical"
-    s6, _, g6 = run(PRESPLIT=True, ACTIVATIONS="lean")
+    bad = []
+    for k in g1:
+        a, b = g1[k].double(), g0[k].double()
+        r = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        if r > 2e-6 and float((a - b).abs().max()) > 1e-7 * gmax:
+            bad.append((k, r))
+    assert not bad, ("round 5 vs round 4", bad)
+    s6, _, g6 = run(ACTIVATIONS="lean")
     assert torch.equal(s6, s1) and all(torch.equal(g6[k], g1[k]) for k in g1), "lean activations must be bit-identical"
-    _, _, g7 = run(PRESPLIT=True, TN_AT="now")
+    _, _, g7 = run(TN_AT="next")
     assert all(torch.equal(g7[k], g1[k]) for k in g1), "where the deferred weight-gradient kernel runs must not matter"
-    _, _, g8 = run()                                # the default: NODE_FUSED on fp32 operands
-    assert all(torch.equal(g8[k], g4[k]) for k in g4)
-    _, _, g9 = run(ACTIVATIONS="lean")
-    assert all(torch.equal(g9[k], g8[k]) for k in g8), "lean activations must be bit-identical (default schedule)"
 
 
 @pytest.mark.default_mode_only

@@ -31,9 +31,15 @@ if [ -z "$FAST" ]; then
   ab() { name=$1; shift; env "$@" $B 2>/dev/null | python -c "
 import json,sys;b=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$name', round(b['ms_per_step'],2), 'ms/step;', {k:round(v,2) for k,v in b['op_ms'].items() if v>3.0})" >> $O/ab_node_side_final.txt; }
   for i in 1 2 3; do
-    ab "round 5 (NODE_FUSED, TN_AT=now)" GNM_X=1
-    ab "round-4 schedule (NODE_FUSED=0, TN_AT=next)" GNM_NODE_FUSED=0 GNM_TN_AT=next
+    ab "round 5 (f16x2, NODE_FUSED, TN_AT=now)" GNM_X=1
+    ab "bf16x3 matmul mode" GNM_MATMUL=bf16x3
+    ab "round-4 schedule and matmul mode (bf16x3, NODE_FUSED=0, TN_AT=next)" GNM_MATMUL=bf16x3 GNM_NODE_FUSED=0 GNM_TN_AT=next
   done
-  ab "round 5 + PRESPLIT" GNM_PRESPLIT=1
+  python tools/matmul_accuracy.py > $O/f16x2_accuracy.log 2>&1; cp gpurun_out/f16x2_accuracy.txt $O/ 2>/dev/null
+  python tools/power_per_op.py > $O/power_per_op.log 2>&1; cp gpurun_out/power_per_op.txt $O/ 2>/dev/null
+  rm -f gpurun_out/power_probe.txt
+  python tools/power_probe.py train 10 > /dev/null 2>&1; python tools/power_probe.py forward 6 > /dev/null 2>&1
+  GNM_MATMUL=bf16x3 python tools/power_probe.py train 8 > /dev/null 2>&1; GNM_MATMUL=f32 python tools/power_probe.py train 8 > /dev/null 2>&1
+  cp gpurun_out/power_probe.txt $O/ 2>/dev/null
 fi
 ls -la $O
