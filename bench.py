@@ -132,12 +132,13 @@ OP_KERNELS = {
     "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true, true, 128>"], "gnm_node_bgrad": ["node_bgrad_k<128>"], "gnm_edge_bwd_top": ["edge_bwd_chain_k"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
     "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128, true>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
-    "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3p_k"]},
-    "gnm_node_proj_fwd": {"f32": ["rowtile_nt_k<MmF32, false, 5>"], "bf16x3": ["rowtile_nt_k<MmB3, false, 1>"]},
-    "gnm_node_proj_bwd_nn": {"f32": ["rowtile_nn_acc_k<MmF32>"], "bf16x3": ["rowtile_nn_group32_b3_k<4>"]},
-    "gnm_node_proj_bwd_tn": {"f32": ["tn_colgroup_k<MmF32>"], "bf16x3": ["tn_tr_k<false, false, 2>"]},
-    "gnm_tn128_bgrad": ["tn_tr_k<false, true, 2>"], "gnm_tn128[3]": ["tn_tr_k<false, false, 2>"],
-    "gnm_node_proj_bwd_nn_stats": ["rowtile_nn2_k<4>"],
+    "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3p_k<MmB3>"], "f16x2": ["edge_t32_b3p_k<MmH2>"]},
+    "gnm_node_proj_fwd": {"f32": ["rowtile_nt_k<MmF32, false, 5>"], "bf16x3": ["rowtile_nt_k<MmB3, false, 1>"], "f16x2": ["rowtile_nt_k<MmH2, false, 1>"]},
+    "gnm_node_proj_bwd_nn": {"f32": ["rowtile_nn_acc_k<MmF32>"], "bf16x3": ["rowtile_nn_group32_b3_k<MmB3, 4>"], "f16x2": ["rowtile_nn_group32_b3_k<MmH2, 4>"]},
+    "gnm_node_proj_bwd_tn": {"f32": ["tn_colgroup_k<MmF32>"], "bf16x3": ["tn_tr_k<false, 2, false>"], "f16x2": ["tn_tr_k<false, 2, true>"]},
+    "gnm_tn128_bgrad": {"bf16x3": ["tn_tr_k<true, 2, false>"], "f16x2": ["tn_tr_k<true, 2, true>"]},
+    "gnm_tn128[3]": {"bf16x3": ["tn_tr_k<false, 2, false>"], "f16x2": ["tn_tr_k<false, 2, true>"]},
+    "gnm_node_proj_bwd_nn_stats": {"bf16x3": ["rowtile_nn2_k<MmB3, 4>"], "f16x2": ["rowtile_nn2_k<MmH2, 4>"]},
     "gnm_node_bwd_apply": ["node_bwd_apply_k<128>"], "gnm_node_bwd_stats": ["node_bwd_stats_k<128>"],
     "gnm_node_update_fwd": ["node_update_fwd_k<128, true>"],
 }
@@ -470,7 +471,15 @@ def main():
     if rank == 0:
         tot = sum(t for _, t in ops.values())
         ranked = sorted(ops.items(), key=lambda kv: -kv[1][1])
-        mm_peak = BF16_MFMA_PEAK / 6 if mode == "bf16x3" else BF16_MFMA_PEAK / 3 if mode == "f16x2" else F32_MFMA_PEAK   # fp32-equivalent FLOP/s of the mode
+        # fp32-equivalent FLOP/s of an op's matrix arithmetic: six bf16 MFMAs per product (bf16x3), three fp16 (f16x2, in the ops that
+        # have it: include/gnm.h), or the fp32 MFMA rate
+        H2_OPS = ("gnm_node_proj_fwd", "gnm_edge_t_fused_fwd", "gnm_node_proj_bwd_nn", "gnm_tn128", "gnm_node_proj_bwd_tn", "gemm_")
+
+        def mm_peak_of(op):
+            if mode == "f32":
+                return F32_MFMA_PEAK
+            h2 = mode == "f16x2" and op.startswith(H2_OPS) and not op.startswith("gnm_edge_t_fused_fwd[256]")
+            return BF16_MFMA_PEAK / (3 if h2 else 6)
         traffic, step_traffic, traffic_src = load_traffic(n, E, H, mode)
         if args.inference:
             step_traffic = None
@@ -479,6 +488,7 @@ def main():
             if tms < 0.02 * tot:
                 continue
             ab, fl = op_model(k, n, E, H)
+            mm_peak = mm_peak_of(k)
             avg_s = tms / c / 1e3
             row = {"op": k, "launches_per_step": c, "avg_launch_ms": round(avg_s * 1e3, 4), "share_of_step": round(tms / tot, 4)}
             if ab:

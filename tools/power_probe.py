@@ -127,7 +127,7 @@ def main():
     smp.on = False
     smp.done = True
     src_ = "hwmon " + smp.pw if smp.pw else "rocm-smi"
-    out = [f"# {what} pass, R={R} H={H} L={L}, {secs:.0f} s loop, samples from {src_}; idle before: {idle[0]:.0f} W, {idle[1]:.0f} MHz",
+    out = [f"# {what} pass, R={R} H={H} L={L} matmul={G._lib.get_matmul_mode()}, {secs:.0f} s loop, samples from {src_}; idle before: {idle[0]:.0f} W, {idle[1]:.0f} MHz",
            summary(what, smp.samples, ms)]
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "power_probe.txt"), "a") as fh:
