@@ -1917,7 +1917,7 @@ extern "C" int gnm_node_proj_fwd(int64_t N, int H, int ncols, const float* h, co
 }
 
 namespace gnm {
-int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st);   // gnm_tr.hip
+int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st, bool h2 = false);   // gnm_tr.hip
 }
 extern "C" size_t gnm_edge_bwd_fused_workspace_bytes(void);
 
@@ -1960,7 +1960,7 @@ static int edge_bwd_chain_impl(int64_t N, int64_t E, int H, const float* ge, flo
     GNM_CHECK_ARG(plan_nodes_per_block == npb, "edge_bwd_chain_src: the sweep plan was built for %lld nodes per workgroup, the kernel uses %lld "
                   "(gnm_sweep_partition(N, 1))", (long long)plan_nodes_per_block, (long long)npb);
   }
-  const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st);
+  const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st, g_matmul_mode == 2);
   GNM_LAUNCH_CHECK("edge_bwd_chain");
   hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3_hi);
   GNM_LAUNCH_CHECK("edge_bwd_chain slab reduce");

@@ -201,6 +201,9 @@ typedef float floatx4_acc __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mfb16s(floatx4_acc& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
+__device__ __forceinline__ void mfh16s(floatx4_acc& acc, const h16x8& a, const h16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mfb16(floatx16& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }

@@ -298,6 +298,33 @@ __global__ void pack_w3_nn16_k(const float* __restrict__ W, int64_t ld, bf16x8* 
   }
 }
 
+// f16x2 form (edge_bwd_chain_k<..., H2>): Wp2[cb][kc][s = hi/lo][lane] (h16x8) of W s_n, s_n = the power of two that puts the largest
+// magnitude of output column n at 2^14 (h2_scale); 1 / s_n of the 128 columns as floats behind the 64 KB of fragments
+constexpr size_t kW2Nn16FragBytes = (size_t)(SW / 16) * (SW / 32) * 2 * 64 * 16;
+__global__ void pack_w2_nn16_k(const float* __restrict__ W, int64_t ld, unsigned char* __restrict__ Wp) {
+  const int total = (SW / 16) * (SW / 32) * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, kc = (idx >> 6) % (SW / 32), cb = idx / (64 * (SW / 32));
+    const int n = lane & 15, g = lane >> 4;
+    float m = 0.f;
+    for (int k = 0; k < SW; ++k) m = fmaxf(m, fabsf(W[(int64_t)k * ld + 16 * cb + n]));
+    float sc, inv;
+    h2_scale(__float_as_uint(m), sc, inv);
+    h16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = W[(int64_t)(32 * kc + 8 * g + j) * ld + 16 * cb + n] * sc;
+      const _Float16 h = (_Float16)x;
+      hi[j] = h;
+      lo[j] = (_Float16)(x - (float)h);
+    }
+    h16x8* o = reinterpret_cast<h16x8*>(Wp) + ((int64_t)(cb * (SW / 32) + kc) * 2) * 64 + lane;
+    o[0] = hi;
+    o[64] = lo;
+    if (kc == 0 && g == 0) reinterpret_cast<float*>(Wp + kW2Nn16FragBytes)[16 * cb + n] = inv;
+  }
+}
+
 template <bool FULL>
 struct tile_tag { static constexpr bool full = FULL; };
 
@@ -581,9 +608,14 @@ struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][
 // left it): phase 0 only parks the rows, no gt, no MFMAs, no gW3 -- the sweep is edge_bwd_dst_k (+ the by-source sums).
 // HF = the row pitch (floats) of every layer-(i-1) tensor = that layer's full width: 128, or 256 with the HI = false sweep run
 // once per 128-column half (column-separable; the caller offsets every pointer by the half's first column)
-template <int ABL, bool SRC, bool WSKIP = true, bool HI = true, int HF = SW>
+// H2 (round 5): the matrix half in the f16x2 form -- the NN product scales gt per row and W3 per output column, the TN product
+// keeps one unit across rows through this workgroup's reference exponent, exactly as tn_tr_k<., ., true> (see there): rows staged
+// with the reference of the tiles before, the tile's own maximum taken by every wave after the staging barrier, a tile with a row
+// 2^10 above the reference staged again (gt stays in registers until then, the e row is still in its prefetch registers).
+template <int ABL, bool SRC, bool WSKIP = true, bool HI = true, int HF = SW, bool H2 = false>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   static_assert(HF == SW || !HI, "the chained (matrix) half of the kernel is built for 128-wide layers only");
+  static_assert(HI || !H2, "f16x2 belongs to the matrix half");
   __shared__ __attribute__((aligned(16))) unsigned char lds[SRC ? CH_LDS_SRC : CH_LDS];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
@@ -625,13 +657,31 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     cl[3 * SW + c] = a.stat_lo[3 * HF + c];
   }
   W3Frag16 wf;
-  if constexpr (HI) {
+  h16x8 wfh[H2 ? SW / 32 : 1][2];           // H2: 16 output columns of W3 s_n: [kc][hi/lo] = 32 VGPRs
+  float cinv = 1.f;                          //     1 / s_n of this lane's output column (wave * 16 + (lane & 15))
+  if constexpr (HI && !H2) {
     const bf16x8* p = a.Wp + ((int64_t)wave * (SW / 32) * 3) * 64 + lane;
 #pragma unroll
     for (int kc = 0; kc < SW / 32; ++kc)
 #pragma unroll
       for (int s_ = 0; s_ < 3; ++s_) wf.w[kc][s_] = p[(kc * 3 + s_) * 64];
   }
+  if constexpr (H2) {
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.Wp);
+    const h16x8* p = reinterpret_cast<const h16x8*>(wp) + ((int64_t)wave * (SW / 32) * 2) * 64 + lane;
+#pragma unroll
+    for (int kc = 0; kc < SW / 32; ++kc)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) wfh[kc][s_] = p[(kc * 2 + s_) * 64];
+    cinv = reinterpret_cast<const float*>(wp + kW2Nn16FragBytes)[wave * 16 + (lane & 15)];
+  }
+  // H2: per-tile scratch in the third gt image of the bf16x3 layout (unused here): [16] EA + EB of the rows, [16] 1 / (gt row factor),
+  //     [32] = "a row lies more than 2^10 above the reference"
+  int* const rexp = reinterpret_cast<int*>(lds + 2 * EIMG);
+  float* const rinv = reinterpret_cast<float*>(lds + 2 * EIMG) + ER;
+  constexpr int kNoRef = -100000;
+  int Rref = kNoRef;
+  if constexpr (H2) { if (tid == 0) rexp[2 * ER] = 0; }
   floatx16 tn[2];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -675,6 +725,8 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
+  float4 gt_keep = f4(0.f);                  // H2: this thread's gt row piece and its exponent, until the tile is known not to be staged again
+  int row_ea = 0;
   float4 ga2, gqb, ghb, gqf, ghf, ga3;       // the node rows of this thread's edge: A2h[s] Qb[s] hb[s] | Qf[d] hf[d] A3h[d]
   int fs = 0, fd = 0;                        // source / destination node of this thread's row TWO tiles ahead (in flight)
   unsigned fi = 0;                           // SRC: its plan word (0 for the clamped rows past the chunk)
@@ -754,8 +806,22 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
         float4 gt = cc * (gu - m1 - ((pt - mu) * rs) * m2);
         if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
         cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
-        simg_stage(ig, EIMG, row, lc4, gt);
-        simg_stage(ie, EIMG, row, lc4, pe_);
+        if constexpr (H2) {
+          gt_keep = gt;
+          const int ea = h2_row_exp(gt) - 127, eb = h2_row_exp(pe_) - 127;
+          const int da = h2_tn_da(Rref, ea + eb);
+          row_ea = ea;
+          if ((tid & 31) == 0) {
+            rexp[row] = ea + eb;
+            rinv[row] = pow2_biased(127 + ea + da - 4);
+            if (ea + eb > Rref + 10) rexp[2 * ER] = 1;
+          }
+          simg_stage_h2(ig, EIMG, row, lc4, gt, pow2_biased(127 + 4 - ea - da));
+          simg_stage_h2(ie, EIMG, row, lc4, pe_, pow2_biased(127 + 4 - Rref + ea + da));
+        } else {
+          simg_stage(ig, EIMG, row, lc4, gt);
+          simg_stage(ie, EIMG, row, lc4, pe_);
+        }
       }
       if ((tid & 31) == 0) {                        // indices of tile k+1 (requested a tile ago) -> ring
         int* sdn = sd + (int)((k + 1) % 3) * 2 * ER;
@@ -765,13 +831,79 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       }
     }
     __syncthreads();   // images, residual rows, the next tile's indices ready
+    int Rnext = Rref;
+    if constexpr (H2) {
+      int m = rexp[lane & (ER - 1)];              // the tile's largest EA + EB: the same number in every wave
+#pragma unroll
+      for (int o = 1; o < ER; o <<= 1) { const int x = __shfl_xor(m, o); m = x > m ? x : m; }
+      if (rexp[2 * ER] != 0) {                    // rare (the first tile; a three-decade jump): staged again in the unit of its own maximum
+        const float f = pow2_biased(127 + (Rref == kNoRef ? -127 : Rref - m));
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) tn[x][e] *= f;
+        Rref = m;
+        __syncthreads();                          // every wave has read the flag and the exponents
+        if (tid == 0) rexp[2 * ER] = 0;
+        const int da = h2_tn_da(Rref, rexp[row]);
+        if ((tid & 31) == 0) rinv[row] = pow2_biased(127 + row_ea + da - 4);
+        simg_stage_h2(ig, EIMG, row, lc4, gt_keep, pow2_biased(127 + 4 - row_ea - da));
+        simg_stage_h2(ie, EIMG, row, lc4, pe_, pow2_biased(127 + 4 - Rref + row_ea + da));
+        __syncthreads();
+      }
+      Rnext = m > Rref ? m : Rref;
+    }
     // a tile (two for the indices) ahead, in flight under the MFMAs and the gather arithmetic; past the end the
     // last tile is requested again instead of branching around the loads
     prefetch_idx(k + 2 < klast ? k + 2 : klast);
     prefetch_rows(k + 1 < klast ? k + 1 : klast);
     __builtin_amdgcn_sched_barrier(0);
     // ---- TN: gW3[n][c] += sum_rows gt[row][n] e[row][c], this wave's 64 x 32 block (transpose reads) ----
-    if (HI && !(ABL & 4)) {
+    if constexpr (HI && H2 && !(ABL & 4)) {
+      int tr0 = trq0, tr1 = trq1;
+      asm volatile("" : "+v"(tr0), "+v"(tr1));
+      h16x8 fa[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+          fa[x][s_] = __builtin_bit_cast(h16x8, simg_col_frag2(ig + s_ * EIMG, tr0 ^ ((2 * wn + x) << 6), tr1 ^ ((2 * wn + x) << 6)));
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        const h16x8 fb = __builtin_bit_cast(h16x8, simg_col_frag2(ie + sb * EIMG, tr0 ^ (wc << 6), tr1 ^ (wc << 6)));
+#pragma unroll
+        for (int sa = 0; sa < 2; ++sa) {
+          if (sa + sb > 1) continue;               // lo*lo is dropped
+          mfh(tn[0], fa[0][sa], fb);
+          mfh(tn[1], fa[1][sa], fb);
+        }
+      }
+      floatx4_acc acc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < SW / 32; ++kc) {
+        h16x8 fn[2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) fn[s_] = *reinterpret_cast<const h16x8*>(ig + s_ * EIMG + (nnb ^ (kc << 6)));
+        mfh16s(acc, fn[1], wfh[kc][0]);
+        mfh16s(acc, fn[0], wfh[kc][1]);
+        mfh16s(acc, fn[0], wfh[kc][0]);
+      }
+      const float4 ri = ld4(rinv + 4 * ng);        // 1 / (row factor) of rows 4 ng .. 4 ng + 3
+      const float rf[4] = {ri.x, ri.y, ri.z, ri.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) og[(4 * ng + e) * EOP + wave * 16 + ni] += acc[e] * (rf[e] * cinv);     // exact factors
+      if (Rnext != Rref) {                         // the next tile is staged in the unit of the new reference
+        const float f = pow2_biased(127 + Rref - Rnext);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) tn[x][e] *= f;
+        Rref = Rnext;
+      }
+    }
+    if (HI && !H2 && !(ABL & 4)) {
       int tr0 = trq0, tr1 = trq1;
       asm volatile("" : "+v"(tr0), "+v"(tr1));
       bf16x8 fa[2][3];
@@ -792,7 +924,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       }
     }
     // ---- NN: acc = gt W3 (16 rows x this wave's 16 columns), joined with the residual rows in og ----
-    if (HI && !(ABL & 4)) {
+    if (HI && !H2 && !(ABL & 4)) {
       floatx4_acc acc;
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] = 0.f;
@@ -950,12 +1082,13 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
 
   if constexpr (HI) {
     float* sl = a.slab + (size_t)chunk * SW * SW;
+    const float unit = !H2 ? 1.f : Rref == kNoRef ? 0.f : pow2_biased(127 + Rref - 8);       // H2: out of the products' unit 2^(8 - R)
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = (2 * wn + x) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-        sl[m * SW + wc * 32 + li] = tn[x][e];
+        sl[m * SW + wc * 32 + li] = H2 ? tn[x][e] * unit : tn[x][e];
       }
   }
   __syncthreads();
@@ -1022,8 +1155,9 @@ __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const in
 }
 
 // returns the grid size (= number of gW3 slabs / partial rows of both kinds)
-int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st) {
-  if (W3) hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
+int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st, bool h2) {
+  if (W3 && h2) hipLaunchKernelGGL(pack_w2_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
+  else if (W3) hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   ChainArgs a = in;
   a.Wp = (const bf16x8*)wpack;
   int grid = 0;
@@ -1051,6 +1185,11 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   if (!a.t_hi) {                                     // top of the stack: the sweep without a layer above
     if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, false>), dim3(grid), dim3(CT), 0, st, a);
     else hipLaunchKernelGGL((edge_bwd_chain_k<0, false, true, false>), dim3(grid), dim3(CT), 0, st, a);
+    return grid;
+  }
+  if (h2) {
+    if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, true, SW, true>), dim3(grid), dim3(CT), 0, st, a);
+    else hipLaunchKernelGGL((edge_bwd_chain_k<0, false, true, true, SW, true>), dim3(grid), dim3(CT), 0, st, a);
     return grid;
   }
   if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, true>), dim3(grid), dim3(CT), 0, st, a);     // column walk + by-source run sums
