@@ -23,7 +23,7 @@ import torch
 from . import _lib
 
 NT, NN, TN = 0, 1, 2
-FUSED = True    # use the W-stationary fused MFMA kernels where they exist (H = 128); tests flip it
+_D_FUSED = True    # Options.FUSED: use the W-stationary fused MFMA kernels where they exist (H = 128); tests flip it
 EPS_BN = 1e-5   # nn.BatchNorm1d default (gated_gcn_full.py:55-56)
 
 LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
@@ -35,45 +35,107 @@ LIN5 = ("A_1", "A_2", "A_3", "B_1", "B_2")
 #            (node projections, then the fused edge-t kernel) from h_in / e_in, which ARE kept (e_in is the previous
 #            layer's e_out).  Bit-identical results (same kernels, same inputs), about 7 GiB less per layer at the
 #            size above, for two extra kernels per layer (+3.3 ms of 25).
-ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
+_D_ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
 
 
 _OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TN_SPLIT", "TWO_SIDED", "TWO_SIDED_FWD", "WIDE_FUSED",
                  "NODE_FUSED")
 
 
-_options_lock = threading.RLock()
+class Options:
+    """The schedule switches of a pass (FUSED, ACTIVATIONS, CHAIN, TN_SIDE, TN_SIDE_CAP, SRC_SIDE_CAP, TN_AT, TN_SPLIT, TWO_SIDED,
+    TWO_SIDED_FWD, WIDE_FUSED, NODE_FUSED; what each selects is described where its default is defined below) as ONE immutable
+    object.  They choose between schedules that compute the same thing (tests and bench.py A/B them).  model_forward /
+    layer_forward read the object that is current in the calling thread -- `current()`: the innermost `with options(...)` /
+    `with use(opts)` of THIS thread, else the process defaults (environment, `set_default`) -- and the autograd functions of
+    models.py / layers.py keep it with the saved activations, so that the backward of a forward runs under the SAME switches
+    whatever thread autograd runs it on and whatever the caller has changed since."""
+    __slots__ = _OPTION_NAMES
+
+    def __init__(self, **kw):
+        for k in _OPTION_NAMES:
+            object.__setattr__(self, k, kw[k])
+
+    def __setattr__(self, k, v):
+        raise AttributeError("engine.Options is immutable: use replace(), options(...) or set_default(...)")
+
+    def replace(self, **kw) -> "Options":
+        bad = [k for k in kw if k not in _OPTION_NAMES]
+        if bad:
+            raise _lib.GnmError(f"engine.options: unknown switch {bad}; known: {_OPTION_NAMES}")
+        if "ACTIVATIONS" in kw and kw["ACTIVATIONS"] not in ("saved", "lean"):
+            raise _lib.GnmError(f"activation mode {kw['ACTIVATIONS']!r}: expected 'saved' or 'lean'")
+        d = {k: getattr(self, k) for k in _OPTION_NAMES}
+        d.update(kw)
+        return Options(**d)
+
+    def __repr__(self):
+        return "Options(" + ", ".join(f"{k}={getattr(self, k)!r}" for k in _OPTION_NAMES) + ")"
+
+
+_tls = threading.local()
+_default: Optional[Options] = None          # built from the _D_* definitions at the end of this module
+
+
+def current() -> Options:
+    """The options of the calling thread (see Options)."""
+    o = getattr(_tls, "opts", None)
+    return o if o is not None else _default
+
+
+@contextlib.contextmanager
+def use(opts: Optional[Options]):
+    """Run the body under `opts` in this thread (None: leave things as they are)."""
+    if opts is None:
+        yield current()
+        return
+    prev = getattr(_tls, "opts", None)
+    _tls.opts = opts
+    try:
+        yield opts
+    finally:
+        _tls.opts = prev
 
 
 @contextlib.contextmanager
 def options(**kw):
-    """Temporarily change schedule switches of this module (FUSED, ACTIVATIONS, CHAIN, TN_SIDE, TN_SIDE_CAP, SRC_SIDE_CAP, TN_AT,
-    TN_SPLIT, TWO_SIDED, TWO_SIDED_FWD, WIDE_FUSED, NODE_FUSED) and restore them on exit, whatever happens
-    inside:
-        with engine.options(TWO_SIDED=False, CHAIN=False): ...
-    The switches select between schedules that compute the same thing (tests and bench.py A/B them).  They are process-wide and
-    read at call time by the thread that runs the pass; the context holds a re-entrant lock for its whole body, so a second
-    thread that enters options() waits until the first has restored its values -- two threads can never see a mixture of each
-    other's settings (nested use by one thread is fine).  A pass that runs OUTSIDE any options() block sees whatever is current:
-    the supported pattern is one training loop per process (as everywhere on this path), switches set once at start-up."""
-    bad = [k for k in kw if k not in _OPTION_NAMES]
-    if bad:
-        raise _lib.GnmError(f"engine.options: unknown switch {bad}; known: {_OPTION_NAMES}")
-    g = globals()
-    with _options_lock:
-        old = {k: g[k] for k in kw}
-        try:
-            g.update(kw)
-            yield
-        finally:
-            g.update(old)
+    """`with engine.options(TWO_SIDED=False, CHAIN=False): ...` -- the current options of this thread with some switches
+    changed, for the body; restored on exit whatever happens inside.  Thread-local: another thread never sees them."""
+    with use(current().replace(**kw)) as o:
+        yield o
+
+
+def set_default(**kw) -> None:
+    """Change the process-wide defaults (what a thread outside any options() / use() block runs under): start-up configuration."""
+    global _default
+    _default = _default.replace(**kw)
+
+
+def _scoped(saved_arg: Optional[int] = None):
+    """Give a pass an `opts=` keyword: the Options it runs under.  A backward pass without one runs under the options its
+    forward left in the saved state (positional argument `saved_arg`)."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def w(*a, opts: Optional[Options] = None, **k):
+            if opts is None and saved_arg is not None and len(a) > saved_arg:
+                opts = getattr(a[saved_arg], "opts", None)
+            if opts is None:
+                return fn(*a, **k)
+            with use(opts):
+                return fn(*a, **k)
+        return w
+    return deco
+
+
+def __getattr__(name):          # engine.CHAIN, engine.ACTIVATIONS, ...: the current value (read-only; PEP 562)
+    if name in _OPTION_NAMES:
+        return getattr(current(), name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def set_activation_mode(mode: str) -> None:
-    global ACTIVATIONS
-    if mode not in ("saved", "lean"):
-        raise _lib.GnmError(f"activation mode {mode!r}: expected 'saved' or 'lean'")
-    ACTIVATIONS = mode
+    """Process-wide default of Options.ACTIVATIONS ('saved' / 'lean')."""
+    set_default(ACTIVATIONS=mode)
 
 
 
@@ -327,6 +389,7 @@ class LayerSaved:
     inv_b: torch.Tensor = None
     z: torch.Tensor = None
     stat_h: torch.Tensor = None
+    opts: "Options" = None       # the switches the forward ran under: its backward runs under the same (see Options)
 
 
 def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
@@ -339,14 +402,14 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
     st = _stream()
     P = torch.empty(N, 5 * H, dtype=torch.float32, device=dev)
     t = torch.empty(E, H, dtype=torch.float32, device=dev)
-    if H == 128 and FUSED and h_in.shape[1] == H:
+    if H == 128 and current().FUSED and h_in.shape[1] == H:
         # W-stationary fused MFMA path: projections, then t + BatchNorm partials in one pass
         need = lib.gnm_rowtile_workspace_bytes(5 * H)
         ws = sc.ws(need)
         _call("gnm_node_proj_fwd", N, H, 5 * H, _ptr(h_in), _ptr(prm.W5), _ptr(prm.b5), _ptr(P), _ptr(ws), need, st)
         _call("gnm_edge_t_fused_fwd", E, H, _ptr(e_in), _ptr(prm.W3), _ptr(prm.b3), _ptr(P), _ptr(idx["isrc"]),
               _ptr(idx["idst"]), _ptr(t), _ptr(sc.partials), C.byref(nblk), _ptr(ws), need, st)
-    elif H == 256 and FUSED and WIDE_FUSED and e_in.shape[1] == H and _lib.split_mode():
+    elif H == 256 and current().FUSED and current().WIDE_FUSED and e_in.shape[1] == H and _lib.split_mode():
         # the reference's default width: projections through the split-mode GEMM, t + BatchNorm partials in one pass
         # (a workgroup keeps one 128-column half of W3 stationary in eight waves)
         gemm(NT, h_in, prm.W5, P, bias=prm.b5)
@@ -365,6 +428,7 @@ def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
 
 
 @on_device_of(lambda idx, N, E, H, prm, h_in, *a, **k: h_in)
+@_scoped()
 def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, save: bool, batch_norm: bool = True,
                   residual: bool = True, plan: Optional[dict] = None, ln_width: Optional[int] = None):
     """GatedGCN_1d.forward (gated_gcn_full.py:99-157) on internal-order tensors.
@@ -388,7 +452,7 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
-    two_sided = plan is not None and batch_norm and H in (128, 256) and TWO_SIDED_FWD      # 256: one sweep per 128-column half
+    two_sided = plan is not None and batch_norm and H in (128, 256) and current().TWO_SIDED_FWD      # 256: one sweep per 128-column half
     inv_f = torch.empty(N, H, **f32) if (save or not two_sided) else None      # inv_f / inv_b: only the backward reads them
     if two_sided:
         hb = torch.empty(N, H, **f32)
@@ -424,13 +488,14 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
         _call("gnm_ln_node_update_fwd", N, H, _ptr(z), _ptr(prm.gamma_h), _ptr(prm.beta_h), res_h, _ptr(h_out), lnw, st)
     saved = None
     if save:
-        lean = ACTIVATIONS == "lean"
-        saved = LayerSaved(h_in=h_in, e_in=e_in, P=None if lean else P, t=None if lean else t, stat_e=stat_e, e_out=e_out,
+        lean = current().ACTIVATIONS == "lean"
+        saved = LayerSaved(opts=current(), h_in=h_in, e_in=e_in, P=None if lean else P, t=None if lean else t, stat_e=stat_e, e_out=e_out,
                            hf=hf, inv_f=inv_f, hb=hb, inv_b=inv_b, z=z, stat_h=stat_h)
     return h_out, e_out, saved
 
 
 @on_device_of(lambda idx, N, E, H, prm, s, gh_out, *a, **k: gh_out)
+@_scoped(5)
 def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True,
                    out: Optional[Dict[str, torch.Tensor]] = None, residual: bool = True, plan: Optional[dict] = None,
                    ln_width: Optional[int] = None):
@@ -442,7 +507,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     out = out or {}
     Hin = s.h_in.shape[1]
     lnw = H if ln_width is None else int(ln_width)
-    fused = H == 128 and FUSED and residual          # the fused backward kernels have the residual adds built in
+    fused = H == 128 and current().FUSED and residual          # the fused backward kernels have the residual adds built in
     new = lambda key, *shape: out[key] if key in out else torch.empty(*shape, dtype=torch.float32, device=gh_out.device)  # noqa: E731
     lib = _lib.load()
     dev = gh_out.device
@@ -482,7 +547,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
         _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
               _ptr(gh_out), _ptr(s.inv_f), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
-        if plan is not None and H in (128, 256) and TWO_SIDED:
+        if plan is not None and H in (128, 256) and current().TWO_SIDED:
             # the two-sided sweep of the chained schedule's top layer (H = 256: once per 128-column half, row pitch 256; H = 128:
             # the fp32-MFMA matmul mode, whose edge backward is not chained): by-destination AND by-source sums from one pass over
             # ge, e_out, t; then the unserved sources and the conversion through m1, m2
@@ -521,7 +586,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             ws = sc.ws(need)
             _call("gnm_edge_bwd_fused", E, H, _ptr(ge), _ptr(ge), _ptr(s.t), _ptr(s.e_in), _ptr(s.stat_e), _ptr(bstat_e),
                   _ptr(prm.gamma_e), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]), _ptr(sc.partials), _ptr(ws), need, st)
-        elif H == 256 and FUSED and WIDE_FUSED and residual and Hin == H and _lib.split_mode():
+        elif H == 256 and current().FUSED and current().WIDE_FUSED and residual and Hin == H and _lib.split_mode():
             # the reference's default width: gt and ge_in = ge_tot + gt W3 from one pass, gt kept for the weight-gradient GEMM
             gt = torch.empty(E, H, **f32)
             ge_in = torch.empty(E, H, **f32)
@@ -560,8 +625,8 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
 
 # The chained backward schedule (H = 128, BatchNorm, bf16x3 matmul mode): the fused edge backward of layer i runs in
 # ONE kernel with the by-destination pass of layer i-1 (gnm_edge_bwd_chain: 5 [E,H] streams instead of 4 + 4, the
-# matrix-core work under the gather arithmetic).  GNM_CHAIN=0 / engine.CHAIN = False goes back to layer_backward.
-CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
+# matrix-core work under the gather arithmetic).  GNM_CHAIN=0 / engine.options(CHAIN=False) goes back to layer_backward.
+_D_CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
 # Inside the chained schedule: layer i's node-projection weight gradient (gW5 = gP^T h_in, matrix-core bound, no consumer
 # before the optimizer step) is launched on a side stream BESIDE layer i-1's by-source pass (HBM bound), which is capped
 # at four workgroups per CU (4 x 80 registers per SIMD lane) so that the weight-gradient workgroups (168 registers) find
@@ -570,29 +635,29 @@ CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"
 # no process-wide state is touched (round 2 flipped gnm_set_occupancy_cap between the launches, and the weight-gradient
 # kernel never honoured it: TN_SIDE_CAP = 0 is what was measured).  GNM_TN_SIDE=0 keeps everything on one stream (the
 # per-op timing mode always does).
-TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
-TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
+_D_TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
+_D_TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
 # when the deferred weight-gradient kernel of layer i is launched: "next" = at the head of layer i-1's iteration (beside its
 # by-source pass / conversion), "now" = right after layer i's own by-source pass or conversion (beside nn(i), node(i-1))
-TN_AT = os.environ.get("GNM_TN_AT", "now")       # round 5 (NODE_FUSED): "now" 161.4 vs "next" 163.2 ms/step, profiles/r05_ab_tn_at.txt
+_D_TN_AT = os.environ.get("GNM_TN_AT", "now")       # round 5 (NODE_FUSED): "now" 161.4 vs "next" 163.2 ms/step, profiles/r05_ab_tn_at.txt
 # "next" only: the deferred kernel in TWO launches sized to the two HBM-bound windows of an iteration -- the gB1h | gB2h column groups
 # beside this layer's conversion (node_bgrad), the gA1h | gA2h | gA3h groups AFTER this layer's nn (both matrix bound: side by side
 # they only take turns) beside the next layer's BatchNorm_h backward.  GNM_TN_SPLIT=0: one launch at the head of the iteration.
-TN_SPLIT = os.environ.get("GNM_TN_SPLIT", "1") != "0"
-SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
+_D_TN_SPLIT = os.environ.get("GNM_TN_SPLIT", "1") != "0"
+_D_SRC_SIDE_CAP = int(os.environ.get("GNM_SRC_CAP", "4"))
 
 
 # The chained kernel as a TWO-SIDED sweep (gnm_edge_bwd_chain_src): layer i-1's by-source sums (gA2h, Us, Ts) come out of the
 # same pass through the graph's sweep plan (graph.sweep_plan), the separate by-source pass -- three [E,H] streams re-read per
 # layer -- shrinks to a gather over the few per cent of the nodes the plan does not serve plus an [N,H]-sized conversion
-# once the BatchNorm-backward means are known.  GNM_TWO_SIDED=0 / engine.TWO_SIDED = False keeps the separate pass.
-TWO_SIDED = os.environ.get("GNM_TWO_SIDED", "1") != "0"
+# once the BatchNorm-backward means are known.  GNM_TWO_SIDED=0 / engine.options(TWO_SIDED=False) keeps the separate pass.
+_D_TWO_SIDED = os.environ.get("GNM_TWO_SIDED", "1") != "0"
 # the forward twin (gnm_edge_gate2_fwd): gate + by-destination AND by-source aggregation in one sweep; GNM_TWO_SIDED_FWD=0
 # keeps edge_gate_fwd + node_agg_src_fwd
-TWO_SIDED_FWD = os.environ.get("GNM_TWO_SIDED_FWD", "1") != "0"
+_D_TWO_SIDED_FWD = os.environ.get("GNM_TWO_SIDED_FWD", "1") != "0"
 # H = 256 (the reference's default width): the fused forward kernel for t (gnm_edge_t_fused_fwd at H = 256);
 # GNM_WIDE_FUSED=0 keeps gemm NT + edge_t_stats_fwd
-WIDE_FUSED = os.environ.get("GNM_WIDE_FUSED", "1") != "0"
+_D_WIDE_FUSED = os.environ.get("GNM_WIDE_FUSED", "1") != "0"
 
 
 # Round 5, the node side.  (A pre-split image of h -- the kernel that produces h also writes its three bf16 terms, the projections
@@ -602,7 +667,7 @@ WIDE_FUSED = os.environ.get("GNM_WIDE_FUSED", "1") != "0"
 # by-source / by-destination sums runs in the operand load of the weight-gradient kernel of those two column groups
 # (gnm_tn128_bgrad, which also writes them for the projection backward behind it), the BatchNorm_h backward sums of the layer
 # below in the epilogue of the projection backward (gnm_node_proj_bwd_nn_stats).  GNM_NODE_FUSED=0: the round-4 schedule.
-NODE_FUSED = os.environ.get("GNM_NODE_FUSED", "1") != "0"
+_D_NODE_FUSED = os.environ.get("GNM_NODE_FUSED", "1") != "0"
 
 
 def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, W, b, partials, ws, need, stream=None, tag: str = None):
@@ -616,7 +681,7 @@ def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, W, b, pa
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
-    return CHAIN and FUSED and H == 128 and batch_norm and _lib.split_mode()
+    return current().CHAIN and current().FUSED and H == 128 and batch_norm and _lib.split_mode()
 
 
 def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tensor], L: int, saved: List[LayerSaved],
@@ -689,12 +754,12 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
         _call("gnm_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s.e_out), _ptr(s.t),
               _ptr(s.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
               _ptr(gP), _ptr(UT), st)
-    if ACTIVATIONS == "lean":
+    if current().ACTIVATIONS == "lean":
         s.P = None              # as below: only the by-destination pass reads the rebuilt P
     # not in the lean mode: the deferred kernel keeps its gP (one [E,H]-sized tensor) alive one layer longer
-    side = _side_stream(dev) if (TN_SIDE and _prof is None and ACTIVATIONS != "lean") else None
+    side = _side_stream(dev) if (current().TN_SIDE and _prof is None and current().ACTIVATIONS != "lean") else None
     main = torch.cuda.current_stream()
-    fusedn = NODE_FUSED and plan is not None      # the node side without node_bgrad / node_bwd_stats launches (see NODE_FUSED)
+    fusedn = current().NODE_FUSED and plan is not None      # the node side without node_bgrad / node_bwd_stats launches (see NODE_FUSED)
     pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
     pending2 = None             # the same, when only its first launch (TN_SPLIT) has been issued
     held: List[torch.Tensor] = []   # what the side stream is reading; dropped only after the main stream has waited for it
@@ -737,7 +802,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                       _ptr(s_j.stat_h), _ptr(sc.partials), C.byref(nblk_h), _ptr(ws), need_p, st)
             else:
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
-            if side is not None and TN_AT == "now":             # tn012(i) right away, beside node(i-1)'s [N,H] passes
+            if side is not None and current().TN_AT == "now":             # tn012(i) right away, beside node(i-1)'s [N,H] passes
                 side_begin()
                 tn128(N, gP, 5 * H, 3, s.h_in, g["W5"], g["b5"], sc3.partials, sc3.ws(need_t), need_t, stream=side)
                 held.extend((gP, s.h_in))
@@ -754,17 +819,17 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                 pgP, ph, pW, pb = pending
                 side_begin()
                 sc3 = scratch(dev, "tn")
-                if TN_SPLIT and UT is not None:
+                if current().TN_SPLIT and UT is not None:
                     tn128(N, pgP[:, 3 * H:], 5 * H, 2, ph, pW[3 * H:], pb[3 * H:], sc3.partials, sc3.ws(need_t), need_t, stream=side)
                     pending2 = pending
                 else:
                     ws3 = sc3.ws(need_p)
                     _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(pgP), _ptr(ph), _ptr(pW), _ptr(pb), _ptr(sc3.partials),
-                                                        _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
+                                                        _ptr(ws3), need_p, current().TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
                                "gnm_node_proj_bwd_tn")
                 held.extend((pgP, ph))
                 pending = None
-                src_cap = SRC_SIDE_CAP
+                src_cap = current().SRC_SIDE_CAP
             if UT is None:
                 _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
                       _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
@@ -775,7 +840,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             split2 = UT is not None
             del Ud, Td, Q
             UT = None
-            if not (side is not None and TN_AT == "now"):
+            if not (side is not None and current().TN_AT == "now"):
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
             if pending2 is not None:        # the other three column groups of the layer above, behind this layer's nn
                 pgP, ph, pW, pb = pending2
@@ -783,18 +848,18 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                 sc3 = scratch(dev, "tn")
                 tn128(N, pgP, 5 * H, 3, ph, pW, pb, sc3.partials, sc3.ws(need_t), need_t, stream=side)
                 pending2 = None
-            if side is not None and TN_AT == "now":
+            if side is not None and current().TN_AT == "now":
                 side_begin()
                 sc3 = scratch(dev, "tn")
                 ws3 = sc3.ws(need_p)
                 _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc3.partials),
-                                                    _ptr(ws3), need_p, TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
+                                                    _ptr(ws3), need_p, current().TN_SIDE_CAP, C.c_void_p(side.cuda_stream)),
                            "gnm_node_proj_bwd_tn")
                 held.extend((gP, s.h_in))
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
             elif side is not None and i > 0:
                 pending = (gP, s.h_in, g["W5"], g["b5"])
-            elif side is None and i > 0 and TN_SPLIT and split2:
+            elif side is None and i > 0 and current().TN_SPLIT and split2:
                 # no side stream (lean activations, per-op timing): the same two launches the deferred path issues, back to back --
                 # the row partition of a launch depends on its column-group count, and the two modes must stay bit-identical
                 ws_t = sc.ws(max(need_p, need_f, need_t))
@@ -839,7 +904,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                   _ptr(s_j.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
                   _ptr(gP), _ptr(UT), st)
         saved[i] = None         # release layer i's activations
-        if ACTIVATIONS == "lean":
+        if current().ACTIVATIONS == "lean":
             s_j.P = None        # rebuilt for the by-destination pass only; nothing after it reads P
         i = j
     return gh, ge, grads
@@ -855,9 +920,11 @@ class PredSaved:
     e: torch.Tensor = None
     hid: torch.Tensor = None     # pre-activation [E,HS]; overwritten by its gradient in backward
     W1sd: torch.Tensor = None
+    opts: "Options" = None
 
 
 @on_device_of(lambda idx, N, E, H, W1, b1, W2, b2, x, *a, **k: x)
+@_scoped()
 def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     """scores (caller edge-id order, [E,1]) from internal-order x [N,H], e [E,H]."""
     lib = _lib.load()
@@ -868,7 +935,7 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
     Pn = torch.empty(N, 2 * HS, **f32)
     gemm(NT, x, W1sd, Pn)
     scores = torch.empty(E, 1, **f32)
-    if (H == 128 or (H == 256 and WIDE_FUSED)) and HS == 64 and FUSED:
+    if (H == 128 or (H == 256 and current().WIDE_FUSED)) and HS == 64 and current().FUSED:
         # one pass over e: hid GEMM + gathers + relu + W2 dot; hid is only written when backward needs it
         hid = torch.empty(E, HS, **f32) if save else None
         need = lib.gnm_predictor_fused_workspace_bytes()
@@ -882,11 +949,12 @@ def predictor_forward(idx, N, E, H, W1, b1, W2, b2, x, e, save: bool):
         gemm(NT, e, W1[:, 2 * H:], hid, bias=b1)
         _call("gnm_predictor_score_fwd", E, HS, _ptr(hid), _ptr(Pn), _ptr(idx["isrc"]), _ptr(idx["idst"]),
                                                _ptr(W2), _ptr(b2), _ptr(idx["perm"]), _ptr(scores), _stream())
-    saved = PredSaved(x=x, e=e, hid=hid, W1sd=W1sd) if save else None
+    saved = PredSaved(x=x, e=e, hid=hid, W1sd=W1sd, opts=current()) if save else None
     return scores, saved
 
 
 @on_device_of(lambda idx, N, E, H, W1, W2, s, gscores, *a, **k: gscores)
+@_scoped(6)
 def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores, out: Optional[Dict[str, torch.Tensor]] = None):
     """Returns (gx [N,H], ge [E,H] fresh buffer, grads dict W1,b1,W2,b2); `out` as in layer_backward."""
     out = out or {}
@@ -900,7 +968,7 @@ def predictor_backward(idx, N, E, H, W1, W2, s: PredSaved, gscores, out: Optiona
     g = {}
     gscores = _f32c(gscores.reshape(-1))
     ghid = s.hid   # in place
-    fused = (H == 128 or (H == 256 and WIDE_FUSED)) and HS == 64 and FUSED
+    fused = (H == 128 or (H == 256 and current().WIDE_FUSED)) and HS == 64 and current().FUSED
     gW1 = out["W1"] if "W1" in out else torch.empty(HS, 3 * H, **f32)
     if fused:
         # one pass: ghid (in place), ge = ghid W1e, gW1e, and the gW2 / gb1 / gb2 column sums
@@ -967,6 +1035,7 @@ class ModelSaved:
     e_raw: torch.Tensor = None
     layers: List[LayerSaved] = field(default_factory=list)
     pred: PredSaved = None
+    opts: "Options" = None
 
 
 def stacked(ts):
@@ -995,6 +1064,7 @@ def layer_params(P: Dict[str, torch.Tensor], i: int) -> LayerParams:
 
 
 @on_device_of(lambda graph, e_raw, pe, *a, **k: pe)
+@_scoped()
 def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int, save: bool, batch_norm: bool = True,
                   ln_width: Optional[int] = None):
     """GraphGatedGCNModel.forward.  e_raw [E,edge_features] in edge-id order, pe [N,nb_pos_enc+2].
@@ -1012,7 +1082,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
     h = torch.empty(N, H, **f32)
     gemm(NT, pe, P["linear_pe.weight"], h, bias=P["linear_pe.bias"])
     Fe, Q = e_raw.shape[1], P["linear1_edge.weight"].shape[0]
-    fused_enc = FUSED and (H == 128 or (H == 256 and WIDE_FUSED)) and Fe == 2 and Q == 16
+    fused_enc = current().FUSED and (H == 128 or (H == 256 and current().WIDE_FUSED)) and Fe == 2 and Q == 16
     e = torch.empty(E, H, **f32)
     e_int = a1 = None
     if fused_enc:
@@ -1025,8 +1095,8 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         a1 = torch.empty(E, Q, **f32)
         gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
-    ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw) if save else None
-    plan2 = graph.sweep_plan(dev, 2) if (TWO_SIDED_FWD and batch_norm and H in (128, 256) and hasattr(graph, "sweep_plan")) else None
+    ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw, opts=current()) if save else None
+    plan2 = graph.sweep_plan(dev, 2) if (current().TWO_SIDED_FWD and batch_norm and H in (128, 256) and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
         h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width)
         if save:
@@ -1053,6 +1123,7 @@ def grad_targets(out: Dict[str, torch.Tensor], i: int) -> Optional[Dict[str, tor
 
 
 @on_device_of(lambda graph, P, num_layers, ms, gscores, *a, **k: gscores)
+@_scoped(3)
 def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: ModelSaved, gscores, batch_norm: bool = True,
                    out: Optional[Dict[str, torch.Tensor]] = None, ln_width: Optional[int] = None):
     """Gradients of every parameter (keys = state_dict keys) from d loss / d scores.  With `out` (state_dict key ->
@@ -1076,10 +1147,10 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     chained = None
     # layer-by-layer backward on the two-sided sweep (the chained schedule's top-layer kernel for every layer): H = 256, and H = 128
     # where the chained schedule does not apply (fp32-MFMA matmul mode, GNM_CHAIN=0)
-    plan_w = graph.sweep_plan(dev) if (H in (128, 256) and batch_norm and TWO_SIDED and not chain_eligible(H, batch_norm)
+    plan_w = graph.sweep_plan(dev) if (H in (128, 256) and batch_norm and current().TWO_SIDED and not chain_eligible(H, batch_norm)
                                        and hasattr(graph, "sweep_plan")) else None
     if chain_eligible(H, batch_norm):
-        plan = graph.sweep_plan(dev) if TWO_SIDED and hasattr(graph, "sweep_plan") else None
+        plan = graph.sweep_plan(dev) if current().TWO_SIDED and hasattr(graph, "sweep_plan") else None
         gh, ge, chained = layers_backward_chained(idx, N, E, H, P, num_layers, ms.layers, gh, ge, louts, plan)
     for i in reversed(range(num_layers)):
         p = f"gnn.convs.{i}."
@@ -1143,3 +1214,6 @@ def bce_with_logits(scores, y, pos_weight: float):
     _call("gnm_bce_fwd_bwd", E, _ptr(x), _ptr(y), float(pos_weight), _ptr(loss), _ptr(gs),
                                    _ptr(sc.partials), sc.partials.numel() * 8, _stream())
     return loss, gs
+
+
+_default = Options(**{k: globals()["_D_" + k] for k in _OPTION_NAMES})

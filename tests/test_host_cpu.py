@@ -261,3 +261,46 @@ def test_no_undefined_names_in_the_package():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "lint_names.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_schedule_switches_are_an_options_object_scoped_to_the_thread_and_kept_with_the_saved_state():
+    """engine.Options ("a small options object ... instead of module globals"): immutable, `options(...)` / `use(opts)`
+    change what is current for the CALLING thread only, a pass takes `opts=`, and a backward pass without one runs under the options
+    its forward left in the saved state -- autograd runs backward on another thread, where a `with options(...)` of the caller
+    would not be seen."""
+    import threading
+    from gnnome_assembly_amd import _lib, engine
+    base = engine.current()
+    assert isinstance(base, engine.Options) and engine.CHAIN == base.CHAIN and engine.ACTIVATIONS == base.ACTIVATIONS
+    with pytest.raises(AttributeError):
+        base.CHAIN = False
+    with pytest.raises(_lib.GnmError):
+        base.replace(NO_SUCH_SWITCH=1)
+    with pytest.raises(_lib.GnmError):
+        base.replace(ACTIVATIONS="half")
+    seen = []
+    with engine.options(CHAIN=not base.CHAIN, TN_AT="next") as o:
+        assert engine.current() is o and engine.CHAIN == (not base.CHAIN) and o.TN_AT == "next"
+        t = threading.Thread(target=lambda: seen.append(engine.current()))
+        t.start()
+        t.join()
+        with engine.options(TWO_SIDED=False) as o2:                       # nested: on top of the enclosing block
+            assert o2.CHAIN == (not base.CHAIN) and o2.TWO_SIDED is False
+        assert engine.current() is o
+    assert seen == [base] and engine.current() is base                    # the other thread never saw the block; restored on exit
+
+    class Saved:
+        opts = base.replace(NODE_FUSED=not base.NODE_FUSED)
+
+    @engine._scoped(1)
+    def fake_backward(x, saved):
+        return engine.current()
+    assert fake_backward(0, Saved()) is Saved.opts                        # the forward's options, from the saved state
+    assert fake_backward(0, Saved(), opts=base) is base                   # an explicit opts= wins
+    assert fake_backward(0, object()) is base
+    try:
+        engine.set_activation_mode("lean")
+        assert engine.ACTIVATIONS == "lean" and engine.current().ACTIVATIONS == "lean"
+    finally:
+        engine.set_activation_mode(base.ACTIVATIONS)
+    assert engine.current().ACTIVATIONS == base.ACTIVATIONS

@@ -17,11 +17,11 @@ def main():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--unfused", action="store_true")
-    ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3", "f16x2"])
     a = ap.parse_args()
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import synth, engine
-    engine.FUSED = not a.unfused
+    engine.set_default(FUSED=not a.unfused)
     G._lib.set_matmul_mode(a.matmul)
     dev = torch.device("cuda:0")
     H = a.hidden

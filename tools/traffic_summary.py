@@ -27,15 +27,18 @@ for k, v in res.items():
     w = v["write_kib"] * 1024 / v["n_w"]
     table[k] = {"fetch_gb": f / 1e9, "write_gb": w / 1e9, "total_gb": (f + w) / 1e9, "launches": v["n_f"]}
 commit = sys.argv[3] if len(sys.argv) > 3 else "unknown"
+from gnnome_assembly_amd._lib import DEFAULT_MATMUL_MODE, MATMUL_MODES      # the passes run bench.py as it is: GNM_MATMUL or the library default
+mode = os.environ.get("GNM_MATMUL", "").strip().lower() or DEFAULT_MATMUL_MODE
+assert mode in MATMUL_MODES, mode
 # the whole step: every kernel of the profiled run (bench.py --steps 1 --warmup 1 = warm-up + timed + per-op step), divided by
 # the number of steps in it (the loss kernel runs once per step)
 steps = max(1, res.get("bce_fwd_bwd_k", {}).get("n_f", 0))
 step_total_gb = sum((2.0 * v["fetch_kib"] + v["write_kib"]) * 1024 for v in res.values() if v["n_f"] and v["n_w"]) / steps / 1e9
 json.dump({"csrc_sha": csrc_sha(), "steps_profiled": steps, "per_step_total_gb": step_total_gb,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/collect_traffic.sh) on one bench.py "
-                     "step (E=7540278, N=1500000, H=128, L=8, bf16x3 matmul mode); FETCH_SIZE doubled (gfx950)",
+                     f"step (E=7540278, N=1500000, H=128, L=8, {mode} matmul mode); FETCH_SIZE doubled (gfx950)",
            "commit": commit,
-           "workload": {"edges": 7540278, "nodes": 1500000, "hidden": 128, "matmul": "bf16x3"},   # bench.py defaults (R=750k, seed 0)
+           "workload": {"edges": 7540278, "nodes": 1500000, "hidden": 128, "matmul": mode},   # bench.py defaults (R=750k, seed 0)
            "per_launch": table}, open(out, "w"), indent=1, sort_keys=True)
 print(f"whole step: {step_total_gb:.1f} GB ({steps} steps profiled); per layer (1/8 of the kernels that run once per layer) see the table")
 for k, v in sorted(table.items(), key=lambda kv: -kv[1]["total_gb"])[:24]:
