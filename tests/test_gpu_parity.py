@@ -1400,7 +1400,7 @@ def test_two_sided_forward_sweep_matches_the_separate_passes(ids):
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import engine
     dev = _dev()
-    model, src, dst, n, inp = _model_and_inputs(40000, 128, 4, 11, dev)
+    model, src, dst, n, inp = _model_and_inputs(16000, 128, 4, 11, dev)
     pe_np, e_np = inp["pe"], inp["e"]
     if ids == "shuffled":
         p = np.random.default_rng(5).permutation(n).astype(np.int32)
