@@ -432,35 +432,10 @@ __global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int 
   }
 }
 
-// f16x2 fragment pack: block cb = { h16x8 frag[c][s][lane] (s = hi/lo of W s_n), float inv[32] = 1 / s_n of its 32 output
-// columns }, s_n from the largest magnitude of the column's 128 weights (every thread of a column recomputes it: the weight
-// is 64 KB and sits in L2); element order as pack_w3_k
-__global__ void pack_w2_k(const float* __restrict__ W, int64_t ld, int ncb, int nn, unsigned char* __restrict__ Wp) {
-  const int total = ncb * BKC * 64;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int lane = idx & 63, c = (idx >> 6) % BKC, cb = idx / (64 * BKC);
-    const int i = lane & 31, g = lane >> 5;
-    const int n = cb * 32 + i;
-    float m = 0.f;
-    for (int k = 0; k < FH; ++k) m = fmaxf(m, fabsf(nn ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k]));
-    float sc, inv;
-    h2_scale(__float_as_uint(m), sc, inv);
-    h16x8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 16 * c + 8 * g + j;
-      const float x = (nn ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k]) * sc;
-      const _Float16 h = (_Float16)x;
-      hi[j] = h;
-      lo[j] = (_Float16)(x - (float)h);
-    }
-    unsigned char* blk = Wp + (size_t)cb * MmH2::kPackBytes;
-    h16x8* o = reinterpret_cast<h16x8*>(blk) + (c * 2) * 64 + lane;
-    o[0] = hi;
-    o[64] = lo;
-    if (c == 0 && g == 0) reinterpret_cast<float*>(blk + MmH2::kFragBytes)[i] = inv;
-  }
-}
+// f16x2 fragment pack: block = { h16x8 frag[c][s][lane] (s = hi/lo of W s_n), float inv[32] = 1 / s_n of its 32 output columns }, s_n from
+// the largest magnitude of column n over its whole contraction (launch_col_amax, gnm_tr.hip); element order as pack_w3_k.  Defined with the
+// general row GEMM below (pack_w2_gen_k): a single 128-deep weight is its ncg = 1 case.
+static void launch_pack_w2_gen(const float* W, int64_t ld, int ncls, int ncg, int nn, void* ws, hipStream_t st);
 
 // 0: fp32 MFMA; 1: bf16x3 split (the default of rounds 2-4: same parity bars, 2.7x the matrix rate);
 // 2: f16x2 in the kernels that have it (MmH2: node projections, edge t, projection backward), bf16x3 in the rest -- the default
@@ -471,7 +446,7 @@ constexpr size_t kPackBytesPerBlk = MmB3::kPackBytes;   // workspace sizing: the
 
 template <class MM>
 static void launch_pack(const float* W, int64_t ld, int ncb, int nn, void* wp, hipStream_t st) {
-  if (MM::kScaled) hipLaunchKernelGGL(pack_w2_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (unsigned char*)wp);
+  if (MM::kScaled) launch_pack_w2_gen(W, ld, ncb / 4, 1, nn, wp, st);      // ncb % 4 == 0: whole 128-column groups
   else if (MM::kSplit) hipLaunchKernelGGL(pack_w3_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (bf16x8*)wp);
   else hipLaunchKernelGGL(pack_w_k, dim3(4 * ncb), dim3(256), 0, st, W, ld, ncb, nn, (float*)wp);
 }
@@ -1620,15 +1595,8 @@ __global__ void pack_w3_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
 }
 
 // the same for MmH2 (block layout of pack_w2_k); a column's factor is taken over its WHOLE contraction (all ncg groups), so that
-// an accumulator that runs over the groups keeps one unit per column: col_amax_k leaves the columns' largest magnitudes behind
-// the fragment blocks (the workspace is sized for the larger bf16x3 blocks), pack_w2_gen_k reads them
-__global__ void col_amax_k(const float* __restrict__ W, int64_t ld, int ncols, int64_t K, int nn, float* __restrict__ amax) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= ncols) return;
-  float m = 0.f;
-  for (int64_t k = 0; k < K; ++k) m = fmaxf(m, fabsf(nn ? W[k * ld + n] : W[(int64_t)n * ld + k]));
-  amax[n] = m;
-}
+// an accumulator that runs over the groups keeps one unit per column: launch_col_amax (gnm_tr.hip) leaves the columns' largest magnitudes
+// behind the fragment blocks (the workspace is sized for the larger bf16x3 blocks), pack_w2_gen_k reads them
 __global__ void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncls, int ncg, int nn, unsigned char* __restrict__ Wp) {
   const int total = ncls * ncg * 4 * BKC * 64;
   const float* amax = reinterpret_cast<const float*>(Wp + (size_t)ncls * ncg * 4 * MmH2::kPackBytes);
@@ -1660,7 +1628,7 @@ __global__ void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
 static void launch_pack_w2_gen(const float* W, int64_t ld, int ncls, int ncg, int nn, void* ws, hipStream_t st) {
   static_assert(MmB3::kPackBytes - MmH2::kPackBytes >= FH * sizeof(float), "the column maxima fit behind the f16x2 blocks");
   float* amax = reinterpret_cast<float*>((unsigned char*)ws + (size_t)ncls * ncg * 4 * MmH2::kPackBytes);
-  hipLaunchKernelGGL(col_amax_k, dim3((ncls * FH + 255) / 256), dim3(256), 0, st, W, ld, ncls * FH, (int64_t)ncg * FH, nn, amax);
+  launch_col_amax(W, ld, ncls * FH, (int64_t)ncg * FH, nn, amax, st);
   hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, W, ld, ncls, ncg, nn, (unsigned char*)ws);
 }
 

@@ -298,16 +298,44 @@ __global__ void pack_w3_nn16_k(const float* __restrict__ W, int64_t ld, bf16x8* 
   }
 }
 
+// Largest magnitude per output column of a weight, for the f16x2 packs (a column's factor spans its whole contraction).  The weight is
+// small (<= 1.3 MB, L2-resident) and the launch sits on the critical path of the kernel behind it: 32 columns x 8 contraction slices per
+// workgroup, joined through LDS -- one thread per column (the first version) was a 640-deep serial loop, 0.1 ms per call.
+__global__ __launch_bounds__(256) void col_amax_k(const float* __restrict__ W, int64_t ld, int ncols, int64_t K, int nn, float* __restrict__ amax) {
+  __shared__ float part[8][32];
+  const int c = threadIdx.x & 31, ks = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  float m = 0.f;
+  if (n < ncols) {
+    if (nn) {
+      for (int64_t k = ks; k < K; k += 8) m = fmaxf(m, fabsf(W[k * ld + n]));
+    } else {
+      const float* row = W + (int64_t)n * ld;
+      for (int64_t k = ks; k < K; k += 8) m = fmaxf(m, fabsf(row[k]));
+    }
+  }
+  part[ks][c] = m;
+  __syncthreads();
+  if (ks == 0 && n < ncols) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) m = fmaxf(m, part[q][c]);
+    amax[n] = m;
+  }
+}
+void launch_col_amax(const float* W, int64_t ld, int ncols, int64_t K, int nn, float* amax, hipStream_t st) {
+  hipLaunchKernelGGL(col_amax_k, dim3((ncols + 31) / 32), dim3(256), 0, st, W, ld, ncols, K, nn, amax);
+}
+
 // f16x2 form (edge_bwd_chain_k<..., H2>): Wp2[cb][kc][s = hi/lo][lane] (h16x8) of W s_n, s_n = the power of two that puts the largest
 // magnitude of output column n at 2^14 (h2_scale); 1 / s_n of the 128 columns as floats behind the 64 KB of fragments
 constexpr size_t kW2Nn16FragBytes = (size_t)(SW / 16) * (SW / 32) * 2 * 64 * 16;
 __global__ void pack_w2_nn16_k(const float* __restrict__ W, int64_t ld, unsigned char* __restrict__ Wp) {
   const int total = (SW / 16) * (SW / 32) * 64;
+  const float* amax = reinterpret_cast<const float*>(Wp + kW2Nn16FragBytes) + SW;      // launch_col_amax left them behind the 128 factors
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63, kc = (idx >> 6) % (SW / 32), cb = idx / (64 * (SW / 32));
     const int n = lane & 15, g = lane >> 4;
-    float m = 0.f;
-    for (int k = 0; k < SW; ++k) m = fmaxf(m, fabsf(W[(int64_t)k * ld + 16 * cb + n]));
+    const float m = amax[16 * cb + n];
     float sc, inv;
     h2_scale(__float_as_uint(m), sc, inv);
     h16x8 hi, lo;
@@ -1156,7 +1184,10 @@ __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const in
 
 // returns the grid size (= number of gW3 slabs / partial rows of both kinds)
 int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st, bool h2) {
-  if (W3 && h2) hipLaunchKernelGGL(pack_w2_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
+  if (W3 && h2) {
+    launch_col_amax(W3, (int64_t)SW, SW, SW, 1, reinterpret_cast<float*>((unsigned char*)wpack + kW2Nn16FragBytes) + SW, st);
+    hipLaunchKernelGGL(pack_w2_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
+  }
   else if (W3) hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   ChainArgs a = in;
   a.Wp = (const bf16x8*)wpack;
