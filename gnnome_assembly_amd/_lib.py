@@ -74,6 +74,7 @@ SIGNATURES = {
     "gnm_graph_build_sweep_plan_device": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_sweep_partition": (_i32, [_i64, _i32, C.POINTER(C.c_int64), _pi]),
     "gnm_edge_gate2_fwd": (_i32, [_i64, _i64, _i32] + [_p] * 9 + [_i64, _i64] + [_p] * 11 + [_pi, _p]),
+    "gnm_ln_edge_gate2_fwd": (_i32, [_i64, _i64, _i32] + [_p] * 4 + [_i32] + [_p] * 6 + [_i64, _i64] + [_p] * 11 + [_pi, _p]),
     "gnm_edge_bwd_fused_workspace_bytes": (_sz, []),
     "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_encoder_fwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),

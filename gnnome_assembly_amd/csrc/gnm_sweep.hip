@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "gnm_tr.h"
+#include "gnm_ln.h"
 
 namespace gnm {
 
@@ -31,6 +32,7 @@ struct Gate2Args {
   const uint32_t* sinfo; const uint32_t* dinfo;
   float* e_out; float* hf; float* inv_f; float* hb; float* inv_b;
   int64_t nodes_per_block, margin;
+  const float* gamma; const float* beta; int width;      // LN: the edge LayerNorm's affine pair and the layer's real width (stat unused)
 };
 
 constexpr int G2_LDS = 3 * GR * SW * 4 + 2 * kSweepSlots * SW * 4 + 2 * 2 * SW * 4 + 2 * SW * 4 + 3 * 4 * GR * 4;
@@ -44,8 +46,12 @@ __device__ __forceinline__ u32x4g_ bits4g(const float4& v) {
 // INV = false (a forward under no_grad): inv_f / inv_b -- which only the backward reads -- are not stored
 // HF = the row pitch of every tensor (floats) = the layer's full width: 128, or 256 with the kernel run once per 128-column
 // half (the sweep is column-separable; the caller offsets every pointer by the half's first column)
-template <bool RES, bool INV, int HF>
+// LN (round 5, batch_norm = False, HF = 128): e_out = relu(LayerNorm(t)) + e_in with the row statistics taken by the 32 lanes that hold the
+// row (row_normalize of gnm_ln.h: the expressions of ln_edge_gate_fwd_k, bit-identical e_out) -- LayerNorm has no global barrier, so the
+// sweep needs nothing else changed.
+template <bool RES, bool INV, int HF, bool LN = false>
 __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
+  static_assert(!LN || HF == SW, "the LayerNorm sweep is built for 128-wide layers");
   __shared__ __attribute__((aligned(16))) unsigned char lds[G2_LDS];
   float* i1 = reinterpret_cast<float*>(lds);          // sigma * A2h[src]
   float* i2 = i1 + GR * SW;                            // sigma
@@ -62,8 +68,8 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   const int64_t rb = a.in_ptr[v0], re = a.in_ptr[v1];
   const int64_t ntile = (re - rb + GR - 1) / GR;
   for (int c = tid; c < SW; c += GT) {
-    cs[c] = a.stat[2 * HF + c];
-    cs[SW + c] = a.stat[3 * HF + c];
+    cs[c] = LN ? a.gamma[c] : a.stat[2 * HF + c];
+    cs[SW + c] = LN ? a.beta[c] : a.stat[3 * HF + c];
   }
   // outputs as buffers: rows outside the range (a lane that has nothing to store carries offset 0x80000000) are dropped
   const int64_t vbase = v0 - a.margin;
@@ -122,6 +128,8 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
   prefetch_rows(klast < 2 ? klast : 2, ptC, peC);
   gather(s0, d0);
   const float4 sc = ld4(cs + c4), sh = ld4(cs + SW + c4);
+  const float4 ln_live = LN ? live_mask(c4, a.width) : f4(1.f);
+  const float ln_inv_w = LN ? 1.0f / (float)a.width : 0.f;
   // one tile; its rows are in (pt, pe_), which are refilled with the rows of tile k + 3 behind the first barrier: the row
   // streams are requested THREE tiles ahead (one tile's run sums + barriers are shorter than the HBM latency under load)
   auto tile = [&](int64_t k, float4& pt, float4& pe_) __attribute__((always_inline)) {
@@ -131,7 +139,12 @@ __global__ __launch_bounds__(GT, 4) void edge_gate2_fwd_k(const Gate2Args a) {
     // ---- per-edge arithmetic of this thread's row: e_out, sigma, the three images ----
     {
       const bool live = row < nvalid;
-      const float4 eo = relu4(fma4(pt, sc, sh)) + pe_;
+      float4 x = pt;
+      if constexpr (LN) {
+        float rstd;
+        x = row_normalize<SW>(pt, ln_live, ln_inv_w, rstd);
+      }
+      const float4 eo = relu4(fma4(x, sc, sh)) + pe_;
       __builtin_amdgcn_raw_buffer_store_b128(bits4g(eo), rs_e, live ? (int)(((k * GR + row) * HF + c4) * 4) : (int)0x80000000, 0, 2);
       const float4 sg = live ? sigmoid4(eo) : f4(0.f);
       st4(i1 + row * SW + c4, sg * ga2);
@@ -306,14 +319,16 @@ extern "C" int gnm_sweep_partition(int64_t N, int wg_per_cu, int64_t* nodes_per_
   return 0;
 }
 
-extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* stat_e,
-                                  const float* P, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr,
-                                  const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
-                                  int64_t nfix, const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos,
-                                  const int32_t* out_dst, float* e_out, float* hf, float* inv_f, float* hb, float* inv_b,
-                                  float* z, double* partials, int* nblk_out, void* stream) {
-  GNM_CHECK_ARG(H == SW || H == 2 * SW, "edge_gate2_fwd: H=%d (128 and 256 are built)", H);
-  GNM_CHECK_ARG(N > 0 && E > 0 && t && stat_e && P && isrc && idst && in_ptr && sinfo && dinfo && (nfix == 0 || fix_nodes) &&
+// ln_gamma != NULL: the LayerNorm form (stat_e unused; H = 128)
+static int edge_gate2_fwd_impl(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* stat_e,
+                               const float* ln_gamma, const float* ln_beta, int ln_width,
+                               const float* P, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr,
+                               const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
+                               int64_t nfix, const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos,
+                               const int32_t* out_dst, float* e_out, float* hf, float* inv_f, float* hb, float* inv_b,
+                               float* z, double* partials, int* nblk_out, void* stream) {
+  GNM_CHECK_ARG(H == SW || (H == 2 * SW && !ln_gamma), "edge_gate2_fwd: H=%d (128 and 256 are built; LayerNorm: 128)", H);
+  GNM_CHECK_ARG(N > 0 && E > 0 && t && (stat_e || ln_gamma) && P && isrc && idst && in_ptr && sinfo && dinfo && (nfix == 0 || fix_nodes) &&
                     nfix >= 0 && out_ptr && out_pos && out_dst && e_out && hf && hb && z && partials && nblk_out &&
                     (inv_f != nullptr) == (inv_b != nullptr),
                 "edge_gate2_fwd: null/neg argument");      // e_in == NULL: no residual; inv_f == inv_b == NULL: not wanted (no backward)
@@ -322,6 +337,7 @@ extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, c
   a.N = N; a.E = E; a.t = t; a.e_in = e_in; a.stat = stat_e; a.P = P; a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
   a.sinfo = sinfo; a.dinfo = dinfo; a.e_out = e_out; a.hf = hf; a.inv_f = inv_f; a.hb = hb; a.inv_b = inv_b;
   a.margin = kSweepMargin;
+  a.gamma = ln_gamma; a.beta = ln_beta; a.width = ln_width;
   int grid = 0;
   gnm_sweep_partition(N, 2, &a.nodes_per_block, &grid);
   GNM_CHECK_ARG(plan_nodes_per_block == a.nodes_per_block, "edge_gate2_fwd: the sweep plan was built for %lld nodes per workgroup, the "
@@ -333,10 +349,19 @@ extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, c
   auto run = [&](auto hf_tag, int c0) -> int {
     constexpr int HF = decltype(hf_tag)::value;
     Gate2Args b = a;              // this 128-column problem: every pointer starts at the half's first column
-    b.t = t + c0; b.e_in = e_in ? e_in + c0 : nullptr; b.stat = stat_e + c0; b.P = P + c0; b.e_out = e_out + c0; b.hf = hf + c0;
+    b.t = t + c0; b.e_in = e_in ? e_in + c0 : nullptr; b.stat = stat_e ? stat_e + c0 : nullptr; b.P = P + c0; b.e_out = e_out + c0; b.hf = hf + c0;
     b.inv_f = inv_f ? inv_f + c0 : nullptr; b.hb = hb + c0; b.inv_b = inv_b ? inv_b + c0 : nullptr;
     hipLaunchKernelGGL(gate2_empty_segments_k<HF>, dim3(num_cus() * 2), dim3(256), 0, st, N, in_ptr, b.hf, b.inv_f);
-    if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true, HF>), dim3(grid), dim3(GT), 0, st, b);
+    if constexpr (HF == SW) {
+      if (ln_gamma) {
+        if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true, SW, true>), dim3(grid), dim3(GT), 0, st, b);
+        else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false, SW, true>), dim3(grid), dim3(GT), 0, st, b);
+        else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true, SW, true>), dim3(grid), dim3(GT), 0, st, b);
+        else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false, SW, true>), dim3(grid), dim3(GT), 0, st, b);
+      }
+    }
+    if (ln_gamma) { /* launched above */ }
+    else if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true, HF>), dim3(grid), dim3(GT), 0, st, b);
     else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false, HF>), dim3(grid), dim3(GT), 0, st, b);
     else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true, HF>), dim3(grid), dim3(GT), 0, st, b);
     else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false, HF>), dim3(grid), dim3(GT), 0, st, b);
@@ -361,4 +386,28 @@ extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, c
   }
   *nblk_out = gz;
   return 0;
+}
+
+extern "C" int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* stat_e,
+                                  const float* P, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr,
+                                  const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
+                                  int64_t nfix, const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos,
+                                  const int32_t* out_dst, float* e_out, float* hf, float* inv_f, float* hb, float* inv_b,
+                                  float* z, double* partials, int* nblk_out, void* stream) {
+  GNM_CHECK_ARG(stat_e, "edge_gate2_fwd: stat_e is null");
+  return edge_gate2_fwd_impl(N, E, H, t, e_in, stat_e, nullptr, nullptr, 0, P, isrc, idst, in_ptr, sinfo, dinfo, plan_nodes_per_block, nfix,
+                             fix_nodes, out_ptr, out_pos, out_dst, e_out, hf, inv_f, hb, inv_b, z, partials, nblk_out, stream);
+}
+
+// The LayerNorm form (batch_norm = False, H = 128; width = the layer's real out_channels <= H): gnm_ln_edge_gate_fwd + gnm_node_agg_src_fwd
+// in one sweep.  z = A1h + hf + hb as in the BatchNorm form (the column sums in `partials` are computed and not needed).
+extern "C" int gnm_ln_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* gamma_e,
+                                     const float* beta_e, int width, const float* P, const int32_t* isrc, const int32_t* idst,
+                                     const int32_t* in_ptr, const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
+                                     int64_t nfix, const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos,
+                                     const int32_t* out_dst, float* e_out, float* hf, float* inv_f, float* hb, float* inv_b,
+                                     float* z, double* partials, int* nblk_out, void* stream) {
+  GNM_CHECK_ARG(gamma_e && beta_e && width >= 1 && width <= H, "ln_edge_gate2_fwd: null argument or width outside [1, H]");
+  return edge_gate2_fwd_impl(N, E, H, t, e_in, nullptr, gamma_e, beta_e, width, P, isrc, idst, in_ptr, sinfo, dinfo, plan_nodes_per_block, nfix,
+                             fix_nodes, out_ptr, out_pos, out_dst, e_out, hf, inv_f, hb, inv_b, z, partials, nblk_out, stream);
 }

@@ -452,9 +452,19 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
-    two_sided = plan is not None and batch_norm and H in (128, 256) and current().TWO_SIDED_FWD      # 256: one sweep per 128-column half
+    # 256: one sweep per 128-column half (BatchNorm); LayerNorm: H = 128 (row statistics inside the sweep, no barrier)
+    two_sided = plan is not None and (H in (128, 256) if batch_norm else H == 128) and current().TWO_SIDED_FWD
     inv_f = torch.empty(N, H, **f32) if (save or not two_sided) else None      # inv_f / inv_b: only the backward reads them
-    if two_sided:
+    if two_sided and not batch_norm:
+        hb = torch.empty(N, H, **f32)
+        inv_b = torch.empty(N, H, **f32) if save else None
+        z = torch.empty(N, H, **f32)
+        stat_e = None
+        _call("gnm_ln_edge_gate2_fwd", N, E, H, _ptr(t), res_e, _ptr(prm.gamma_e), _ptr(prm.beta_e), lnw, _ptr(P), _ptr(idx["isrc"]),
+              _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(plan["sinfo"]), _ptr(plan["dinfo"]), plan["nodes_per_block"], plan["nfix"],
+              _ptr(plan["fix_nodes"]), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(e_out),
+              _ptr(hf), _ptr(inv_f), _ptr(hb), _ptr(inv_b), _ptr(z), _ptr(sc.partials), C.byref(nblk), st)
+    elif two_sided:
         hb = torch.empty(N, H, **f32)
         inv_b = torch.empty(N, H, **f32) if save else None
         z = torch.empty(N, H, **f32)
@@ -1096,7 +1106,8 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw, opts=current()) if save else None
-    plan2 = graph.sweep_plan(dev, 2) if (current().TWO_SIDED_FWD and batch_norm and H in (128, 256) and hasattr(graph, "sweep_plan")) else None
+    plan2 = graph.sweep_plan(dev, 2) if (current().TWO_SIDED_FWD and (H in (128, 256) if batch_norm else H == 128)
+                                         and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
         h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width)
         if save:

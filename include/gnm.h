@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 6   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed */
+#define GNM_ABI_VERSION 6   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed, gnm_ln_edge_gate2_fwd */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -197,6 +197,15 @@ int gnm_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float*
                        const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
                        float* e_out, float* hf, float* inv_f, float* hb, float* inv_b, float* z, double* partials,
                        int* nblk_out, void* stream);
+/* the same sweep for a LayerNorm layer (batch_norm = False; H = 128; width = the layer's real out_channels, see the gnm_ln_*
+ * entry points): gnm_ln_edge_gate_fwd AND gnm_node_agg_src_fwd in one pass, e_out bit-identical to gnm_ln_edge_gate_fwd's.
+ * `partials` receives column sums nobody needs (z is formed by the same kernel as in the BatchNorm form).          (:122-147) */
+int gnm_ln_edge_gate2_fwd(int64_t N, int64_t E, int H, const float* t, const float* e_in, const float* gamma_e,
+                          const float* beta_e, int width, const float* P, const int32_t* isrc, const int32_t* idst,
+                          const int32_t* in_ptr, const uint32_t* sinfo, const uint32_t* dinfo, int64_t plan_nodes_per_block,
+                          int64_t nfix, const int32_t* fix_nodes, const int32_t* out_ptr, const int32_t* out_pos,
+                          const int32_t* out_dst, float* e_out, float* hf, float* inv_f, float* hb, float* inv_b, float* z,
+                          double* partials, int* nblk_out, void* stream);
 /* node_agg_src: hb[v] = sum_{out(v)} sigma*A3h[dst] / (sum sigma + 1e-6), inv_b likewise;
  *               z = A1h + hf + hb; per-block (sum z, sum z^2) -> partials   (:133-145) */
 int gnm_node_agg_src_fwd(int64_t N, int64_t E, int H, const float* e_out, const float* P,

@@ -1453,6 +1453,64 @@ def test_two_sided_forward_sweep_matches_the_separate_passes(ids):
 
 
 @pytest.mark.default_mode_only
+@pytest.mark.parametrize("H", [128, 96])
+def test_layernorm_two_sided_forward_sweep_matches_the_separate_passes(H):
+    """batch_norm = False (nn.LayerNorm, gated_gcn_full.py:57-59) at H = 128 -- and at 96, which runs zero-padded to 128 with the row
+    statistics over the 96 real channels: gnm_ln_edge_gate2_fwd forms e_out, the by-destination AND the by-source gated means in one
+    sweep (LayerNorm has no global barrier: the row statistics are taken inside the sweep) instead of gnm_ln_edge_gate_fwd +
+    gnm_node_agg_src_fwd.  Same per-edge expressions (e_out bit-identical), another fixed order inside a node's sums: logits within
+    2e-6 (rel-L2) of the separate-pass forward and of the fp64 oracle's bar, gradients at the bar they have against the oracle, two
+    runs bit-identical."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import engine, synth
+    from oracle import gatedgcn_oracle as orc
+    dev = _dev()
+    L = 3
+    src, dst, n = synth.make_graph(12000, 13)
+    inp = synth.make_inputs(src, dst, n, 13)
+    sd = synth.synth_state_dict(H, L, 13)
+    model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, False, 16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.to(dev)
+    g = G.AssemblyGraph(src, dst, n).to(dev)
+    e, pe, y = (torch.from_numpy(inp[k]).to(dev) for k in ("e", "pe", "y"))
+    crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+    plan = g.sweep_plan(dev, 2)
+    assert plan is not None and 0 < plan["nfix"] < 0.3 * n
+
+    def run(two_sided):
+        with engine.options(TWO_SIDED_FWD=two_sided):
+            model.zero_grad(set_to_none=True)
+            s = model(g, None, e, pe)
+            loss = crit(s.squeeze(-1), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            return s.detach().clone(), loss.item(), {k: v.grad.clone() for k, v in model.named_parameters()}
+    engine.profile_ops(True)
+    s1, l1, g1 = run(True)
+    ops = engine.profile_ops(False)
+    assert "gnm_ln_edge_gate2_fwd" in ops and "gnm_node_agg_src_fwd" not in ops        # the sweep really is what ran
+    s0, l0, g0 = run(False)
+    s2, l2, g2 = run(True)
+    assert torch.equal(s1, s2) and l1 == l2 and all(torch.equal(g1[k], g2[k]) for k in g1), "not run-to-run deterministic"
+    r = rel_l2(s1.cpu().numpy(), s0.cpu().numpy())
+    print(f"LayerNorm two-sided forward vs separate passes [H={H}]: logits rel_l2 = {r:.2e}")
+    assert r <= 2e-6 and abs(l1 - l0) <= 1e-6 * abs(l0)
+    p64 = sd_to_torch(sd, torch.float64)
+    s64 = orc.model_forward(p64, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(inp["e"]).double(),
+                            torch.from_numpy(inp["pe"]).double(), False)
+    assert_parity(s1.cpu().numpy(), s64.numpy(), f"LayerNorm two-sided forward H={H} vs the fp64 oracle")
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    bad = []
+    for k in g0:
+        a, b = g1[k].double(), g0[k].double()
+        rr = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        if rr > GRAD_L2 and float((a - b).abs().max()) > 1e-6 * gmax:
+            bad.append((k, rr))
+    assert not bad, bad
+
+
+@pytest.mark.default_mode_only
 def test_wide_layers_fused_kernels_and_sweeps_match_the_generic_route():
     """H = 256 (the reference's default dim_latent, hyperparameters.py:8).  Default: t + BatchNorm sums from the fused forward
     kernel (edge_t32_h256_k), gt and ge_in from one pass (edge_gt_nn_h256_k), the fused edge-encoder kernels, and the two-sided
