@@ -352,19 +352,19 @@ static int edge_gate2_fwd_impl(int64_t N, int64_t E, int H, const float* t, cons
     b.t = t + c0; b.e_in = e_in ? e_in + c0 : nullptr; b.stat = stat_e ? stat_e + c0 : nullptr; b.P = P + c0; b.e_out = e_out + c0; b.hf = hf + c0;
     b.inv_f = inv_f ? inv_f + c0 : nullptr; b.hb = hb + c0; b.inv_b = inv_b ? inv_b + c0 : nullptr;
     hipLaunchKernelGGL(gate2_empty_segments_k<HF>, dim3(num_cus() * 2), dim3(256), 0, st, N, in_ptr, b.hf, b.inv_f);
+    auto launch = [&](auto ln_tag) {
+      constexpr bool LN_ = decltype(ln_tag)::value;
+      if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true, HF, LN_>), dim3(grid), dim3(GT), 0, st, b);
+      else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false, HF, LN_>), dim3(grid), dim3(GT), 0, st, b);
+      else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true, HF, LN_>), dim3(grid), dim3(GT), 0, st, b);
+      else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false, HF, LN_>), dim3(grid), dim3(GT), 0, st, b);
+    };
     if constexpr (HF == SW) {
-      if (ln_gamma) {
-        if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true, SW, true>), dim3(grid), dim3(GT), 0, st, b);
-        else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false, SW, true>), dim3(grid), dim3(GT), 0, st, b);
-        else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true, SW, true>), dim3(grid), dim3(GT), 0, st, b);
-        else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false, SW, true>), dim3(grid), dim3(GT), 0, st, b);
-      }
+      if (ln_gamma) launch(std::true_type{});
+      else launch(std::false_type{});
+    } else {
+      launch(std::false_type{});
     }
-    if (ln_gamma) { /* launched above */ }
-    else if (e_in && inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<true, true, HF>), dim3(grid), dim3(GT), 0, st, b);
-    else if (e_in) hipLaunchKernelGGL((edge_gate2_fwd_k<true, false, HF>), dim3(grid), dim3(GT), 0, st, b);
-    else if (inv_f) hipLaunchKernelGGL((edge_gate2_fwd_k<false, true, HF>), dim3(grid), dim3(GT), 0, st, b);
-    else hipLaunchKernelGGL((edge_gate2_fwd_k<false, false, HF>), dim3(grid), dim3(GT), 0, st, b);
     GNM_LAUNCH_CHECK("edge_gate2_fwd");
     if (nfix > 0) {
       int64_t g2 = (nfix + kWavesPerBlock - 1) / kWavesPerBlock;
