@@ -1751,7 +1751,7 @@ void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B
 size_t edge_bwd_tr_pack_bytes();
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
-                       double* partials, hipStream_t st);
+                       double* partials, hipStream_t st, bool h2 = false);
 }
 // kernel-generation switches for same-process A/B runs (gnm_debug_set_variant, GNM_VARIANTS).  Round 5 removed the generations
 // that had lost their A/B (the round-1 split-mode edge backward / weight gradient / VALU encoders, the unpipelined t kernels,
@@ -2010,7 +2010,7 @@ static int edge_bwd_fused_impl(int64_t E, const float* ge, float* ge_out, const 
   float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
   int grid;
   if constexpr (MM::kSplit) {
-    grid = edge_bwd_tr_launch(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, ws, slab, partials, st);
+    grid = edge_bwd_tr_launch(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, ws, slab, partials, st, g_matmul_mode == 2);
     GNM_LAUNCH_CHECK("edge_bwd_fused (tr)");
     hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
     GNM_LAUNCH_CHECK("edge_bwd_fused slab reduce");

@@ -358,7 +358,9 @@ struct tile_tag { static constexpr bool full = FULL; };
 
 // VAR bit 0: residual ge rows and the fp64 column sums wait in LDS (1) or in registers (0);
 //     bit 1: the prefetch is pinned right behind the first barrier (1) or left to hipcc's scheduler (0)
-template <int VAR>
+// H2 (round 5): the f16x2 form, as in edge_bwd_chain_k<..., H2> (the NN product per row of gt and column of W3, the TN product through the
+// workgroup's reference exponent; a thread owns two rows of a tile here)
+template <int VAR, bool H2 = false>
 __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     int64_t E, const float* ge, float* ge_out, const float* __restrict__ t, const float* __restrict__ e_in,
     const float* __restrict__ stat, const float* __restrict__ bstat, const float* __restrict__ gamma,
@@ -395,14 +397,34 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     cs[6 * SW + c] = gamma[c] * stat[SW + c];
   }
   W3Frag wf;
+  h16x8 wfh[H2 ? 2 : 1][H2 ? SW / 32 : 1][2];       // H2: [nb][kc][hi/lo] = 64 VGPRs
+  float cinv[2] = {1.f, 1.f};                       //     1 / s_n of this lane's two output columns
+  if constexpr (!H2) {
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const bf16x8* p = Wp + ((int64_t)(2 * wave + nb) * (SW / 32) * 3) * 64 + lane;
+    for (int nb = 0; nb < 2; ++nb) {
+      const bf16x8* p = Wp + ((int64_t)(2 * wave + nb) * (SW / 32) * 3) * 64 + lane;
 #pragma unroll
-    for (int kc = 0; kc < SW / 32; ++kc)
+      for (int kc = 0; kc < SW / 32; ++kc)
 #pragma unroll
-      for (int s_ = 0; s_ < 3; ++s_) wf.w[nb][kc][s_] = p[(kc * 3 + s_) * 64];
+        for (int s_ = 0; s_ < 3; ++s_) wf.w[nb][kc][s_] = p[(kc * 3 + s_) * 64];
+    }
+  } else {
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(Wp);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const h16x8* p = reinterpret_cast<const h16x8*>(wp) + ((int64_t)(2 * wave + nb) * (SW / 32) * 2) * 64 + lane;
+#pragma unroll
+      for (int kc = 0; kc < SW / 32; ++kc)
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) wfh[nb][kc][s_] = p[(kc * 2 + s_) * 64];
+      cinv[nb] = reinterpret_cast<const float*>(wp + kW2Nn16FragBytes)[(2 * wave + nb) * 16 + (lane & 15)];
+    }
   }
+  int* const rexp = reinterpret_cast<int*>(lds + 2 * EIMG);          // H2: as in edge_bwd_chain_k (the unused third gt image)
+  float* const rinv = reinterpret_cast<float*>(lds + 2 * EIMG) + ER;
+  constexpr int kNoRef = -100000;
+  int Rref = kNoRef;
+  if constexpr (H2) { if (threadIdx.x == 0) rexp[2 * ER] = 0; }
   floatx16 tn[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -444,6 +466,8 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     const int64_t r0 = tile * ER;
     // ---- phase 0: gt tile and e_in tile -> split images; residual ge rows -> og ----
     float4 gk[2];
+    float4 gt_keep[H2 ? 2 : 1], ev_keep[H2 ? 2 : 1];      // H2: this thread's rows until the tile is known not to be staged again
+    int row_ea[H2 ? 2 : 1];
     {
       double c0 = cg0, c1 = cg1, c2 = cg2, c3 = cg3;
       if (STASH) { c0 = cgs[0]; c1 = cgs[1]; c2 = cgs[2]; c3 = cgs[3]; }
@@ -461,17 +485,82 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
         float4 ev = pe_[it];
         if (!ok) { gt = f4(0.f); ev = f4(0.f); }
         c0 += (double)gt.x; c1 += (double)gt.y; c2 += (double)gt.z; c3 += (double)gt.w;
-        simg_stage(ig, EIMG, row, lc4, gt);
-        simg_stage(ie, EIMG, row, lc4, ev);
+        if constexpr (H2) {
+          gt_keep[it] = gt;
+          ev_keep[it] = ev;
+          const int ea = h2_row_exp(gt) - 127, eb = h2_row_exp(ev) - 127;
+          const int da = h2_tn_da(Rref, ea + eb);
+          row_ea[it] = ea;
+          if ((tid & 31) == 0) {
+            rexp[row] = ea + eb;
+            rinv[row] = pow2_biased(127 + ea + da - 4);
+            if (ea + eb > Rref + 10) rexp[2 * ER] = 1;
+          }
+          simg_stage_h2(ig, EIMG, row, lc4, gt, pow2_biased(127 + 4 - ea - da));
+          simg_stage_h2(ie, EIMG, row, lc4, ev, pow2_biased(127 + 4 - Rref + ea + da));
+        } else {
+          simg_stage(ig, EIMG, row, lc4, gt);
+          simg_stage(ie, EIMG, row, lc4, ev);
+        }
       }
       if (STASH) { cgs[0] = c0; cgs[1] = c1; cgs[2] = c2; cgs[3] = c3; }
       else { cg0 = c0; cg1 = c1; cg2 = c2; cg3 = c3; }
     }
     __syncthreads();   // images and residual rows ready
+    int Rnext = Rref;
+    if constexpr (H2) {
+      int m = rexp[lane & (ER - 1)];
+#pragma unroll
+      for (int o = 1; o < ER; o <<= 1) { const int x = __shfl_xor(m, o); m = x > m ? x : m; }
+      if (rexp[2 * ER] != 0) {                    // rare: the tile is staged again in the unit of its own maximum
+        const float f = pow2_biased(127 + (Rref == kNoRef ? -127 : Rref - m));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tn[a][b][e] *= f;
+        Rref = m;
+        __syncthreads();
+        if (tid == 0) rexp[2 * ER] = 0;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = lrow + 8 * it;
+          const int da = h2_tn_da(Rref, rexp[row]);
+          if ((tid & 31) == 0) rinv[row] = pow2_biased(127 + row_ea[it] + da - 4);
+          simg_stage_h2(ig, EIMG, row, lc4, gt_keep[it], pow2_biased(127 + 4 - row_ea[it] - da));
+          simg_stage_h2(ie, EIMG, row, lc4, ev_keep[it], pow2_biased(127 + 4 - Rref + row_ea[it] + da));
+        }
+        __syncthreads();
+      }
+      Rnext = m > Rref ? m : Rref;
+    }
     prefetch(tile + 1 < tb1 ? tile + 1 : tile);   // in flight under the MFMAs, the epilogue and the partner workgroup
     if (PIN) __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (hipcc otherwise sinks them behind the MFMAs)
     // ---- TN: gW3[n][c] += sum_rows gt[row][n] e_in[row][c], this wave's 64 x 64 block (transpose reads) ----
-    {
+    if constexpr (H2) {
+      int tr0 = trq0, tr1 = trq1;
+      asm volatile("" : "+v"(tr0), "+v"(tr1));
+      h16x8 a[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+          a[x][s_] = __builtin_bit_cast(h16x8, simg_col_frag2(ig + s_ * EIMG, tr0 ^ ((2 * wn + x) << 6), tr1 ^ ((2 * wn + x) << 6)));
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        const h16x8 b0 = __builtin_bit_cast(h16x8, simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc) << 6), tr1 ^ ((2 * wc) << 6)));
+        const h16x8 b1 = __builtin_bit_cast(h16x8, simg_col_frag2(ie + sb * EIMG, tr0 ^ ((2 * wc + 1) << 6), tr1 ^ ((2 * wc + 1) << 6)));
+#pragma unroll
+        for (int sa = 0; sa < 2; ++sa) {
+          if (sa + sb > 1) continue;               // lo*lo is dropped
+          mfh(tn[0][0], a[0][sa], b0);
+          mfh(tn[0][1], a[0][sa], b1);
+          mfh(tn[1][0], a[1][sa], b0);
+          mfh(tn[1][1], a[1][sa], b1);
+        }
+      }
+    } else {
       // two lane-constant bases; the column-block term is a wave-uniform XOR applied at the read.  The empty asm
       // keeps hipcc from hoisting the eight XORed addresses into registers that live across the whole loop.
       int tr0 = trq0, tr1 = trq1;
@@ -502,6 +591,36 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[nb][e] = 0.f;
+    if constexpr (H2) {
+#pragma unroll
+      for (int kc = 0; kc < SW / 32; ++kc) {
+        h16x8 a[2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) a[s_] = *reinterpret_cast<const h16x8*>(ig + s_ * EIMG + (nnb ^ (kc << 6)));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          mfh16s(acc[nb], a[1], wfh[nb][kc][0]);
+          mfh16s(acc[nb], a[0], wfh[nb][kc][1]);
+          mfh16s(acc[nb], a[0], wfh[nb][kc][0]);
+        }
+      }
+      const float4 ri = ld4(rinv + 4 * ng);
+      const float rf[4] = {ri.x, ri.y, ri.z, ri.w};
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nb][e] *= rf[e] * cinv[nb];          // exact factors
+      if (Rnext != Rref) {
+        const float f = pow2_biased(127 + Rref - Rnext);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tn[a][b][e] *= f;
+        Rref = Rnext;
+      }
+    } else {
 #pragma unroll
     for (int kc = 0; kc < SW / 32; ++kc) {
       bf16x8 a[3];
@@ -516,6 +635,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
         mfb16s(acc[nb], a[0], wf.w[nb][kc][1]);
         mfb16s(acc[nb], a[0], wf.w[nb][kc][0]);
       }
+    }
     }
     // C / D of the 16 x 16 MFMA: column = lane & 15, row = 4 (lane >> 4) + e; every og element is touched by
     // exactly one lane: ge_in = ge + gt W3 is formed in place
@@ -545,6 +665,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
   if (nfull < tb1 && nfull >= tb0) body(tile_tag<false>{}, nfull);
 
   float* sl = slab + (size_t)chunk * SW * SW;
+  const float unit = !H2 ? 1.f : Rref == kNoRef ? 0.f : pow2_biased(127 + Rref - 8);       // H2: out of the products' unit 2^(8 - R)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -552,7 +673,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = (2 * wn + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-        sl[m * SW + (2 * wc + b) * 32 + li] = tn[a][b][e];
+        sl[m * SW + (2 * wc + b) * 32 + li] = H2 ? tn[a][b][e] * unit : tn[a][b][e];
       }
   __syncthreads();
   if (!STASH) { cgs[0] = cg0; cgs[1] = cg1; cgs[2] = cg2; cgs[3] = cg3; }
@@ -571,7 +692,16 @@ size_t edge_bwd_tr_pack_bytes() { return (size_t)(SW / 16) * (SW / 32) * 3 * 64 
 // returns the grid size (= number of slabs / partial rows written)
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
-                       double* partials, hipStream_t st) {
+                       double* partials, hipStream_t st, bool h2) {
+  if (h2) {
+    launch_col_amax(W3, (int64_t)SW, SW, SW, 1, reinterpret_cast<float*>((unsigned char*)wpack + kW2Nn16FragBytes) + SW, st);
+    hipLaunchKernelGGL(pack_w2_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
+    const int64_t ntiles = (E + ER - 1) / ER;
+    const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_bwd_tr_k<3, true>>());
+    hipLaunchKernelGGL((edge_bwd_tr_k<3, true>), dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e,
+                       (const bf16x8*)wpack, slab, partials, (ntiles + grid - 1) / grid);
+    return grid;
+  }
   hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   const int64_t ntiles = (E + ER - 1) / ER;
   const int var = eb_variant();      // 1: LDS stash + pinned prefetch (default); 2: registers, unpinned (A/B: within 1 % of each other)
