@@ -371,6 +371,23 @@ __device__ __forceinline__ void mma32_h2(const void* img, int row0, const MmH2::
   }
 }
 
+// MmH2 in the 256-wide fused edge kernels: a row is 256 columns = the 64 lanes of ONE wave (thread = 4 columns; the row's two 128-column
+// halves go to the images of the two contraction halves, which meet by addition: ONE factor per row).  The row's 1 / s goes to LDS: the
+// epilogue of these kernels runs in another thread layout.
+__device__ __forceinline__ void h2_stage_row64(void* img, int row, int c4, const float4& v, float* rinv_slot, bool writer) {
+  unsigned m = row32_max_bits(max_abs4_bits(v));
+  const unsigned o = (unsigned)__shfl_xor((int)m, 32);
+  m = o > m ? o : m;
+  float sc, inv;
+  h2_scale(m, sc, inv);
+  if (writer) *rinv_slot = inv;
+  h16x4 hi, lo;
+  split2(v, sc, hi, lo);
+  _Float16* b = reinterpret_cast<_Float16*>(img) + row * BP + c4;
+  *reinterpret_cast<h16x4*>(b) = hi;
+  *reinterpret_cast<h16x4*>(b + BIMG) = lo;
+}
+
 // this wave's 64 x 64 block of the TN result -> sl[n][c] (128 x 128, row-major)
 template <class MM>
 __device__ __forceinline__ void tn_store_slab(float* __restrict__ sl, const floatx16 (&tn)[2][2], int wn, int wc,
@@ -741,13 +758,15 @@ constexpr int kBlockW = 512;
 // apiece on its own), which leaves the vector ALU idle -- the next tile's 4 rows per thread are split and written to the OTHER half
 // of the image set between the chunks of the chain, so that per tile only the epilogue stays outside the matrix phase (27.1 -> 24.5
 // ms per step against the kernel that ran the phases one after the other, bit-identical; that kernel was removed in round 5).
+template <class MM>
 __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
     int64_t M, const float* __restrict__ X, const void* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ Y, const float* __restrict__ P, const int32_t* __restrict__ isrc,
     const int32_t* __restrict__ idst, double* __restrict__ partials, int nchunk, int64_t tiles_per_chunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MmB3::kImgBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MM::kImgBytes];
   __shared__ float os[2 * ER3 * FP];
   __shared__ int sd[2][2 * ER3];
+  __shared__ float rinv[2][ER3];       // MmH2: 1 / s of the rows of tile buffer 0 / 1 (h2_stage_row64)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -759,15 +778,21 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
   const int64_t tb1 = min(ntiles, tb0 + tiles_per_chunk);
   const int64_t nfull = min(tb1, M / ER3);
   const int srow = tid >> 6, sc = (tid & 63) * 4;
-  unsigned char* const simg = xraw + (sc >> 7) * MmB3::kImgBytes;
+  unsigned char* const simg = xraw + (sc >> 7) * MM::kImgBytes;
   const int slc4 = sc & (FH - 1);
   const int erow = tid >> 5, ec4 = (tid & 31) * 4;
   const int64_t Mlast = M - 1;
   const int32_t* const ibase = (lane & 32) ? idst : isrc;
 
-  MmB3::Frag wf;
-  MmB3::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
+  typename MM::Frag wf;
+  MM::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
   const float4 b4 = ld4(bias + J * FH + ec4);
+  float4 ci4 = f4(1.f);
+  if constexpr (MM::kScaled) ci4 = MM::col_inv4(Wp, J * 2 * 4, ec4);      // the column factors span both contraction halves
+  auto stage = [&](int buf, int r, const float4& v) __attribute__((always_inline)) {
+    if constexpr (MM::kScaled) h2_stage_row64(simg, 32 * buf + r, slc4, v, &rinv[buf][r], (tid & 63) == 0);
+    else MM::stage(simg, 32 * buf + r, slc4, v);
+  };
   float4 pre[2][4];
   int pidx[2] = {0, 0};
   auto prefetch = [&](float4 (&buf)[4], int& idx, int64_t tile) __attribute__((always_inline)) {
@@ -785,8 +810,30 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
     floatx16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    {
-      const __bf16* p0 = reinterpret_cast<const __bf16*>(xraw + kh * MmB3::kImgBytes) + (32 * hb + li) * BP + 8 * lg;
+    // the factors of THIS tile's rows (staged during the previous body, two barriers ago) before anybody stages into this buffer again
+    float ri[2] = {1.f, 1.f};
+    if constexpr (MM::kScaled) { ri[0] = rinv[hb][erow]; ri[1] = rinv[hb][erow + 16]; }
+    if constexpr (MM::kScaled) {
+      const _Float16* p0 = reinterpret_cast<const _Float16*>(xraw + kh * MM::kImgBytes) + (32 * hb + li) * BP + 8 * lg;
+      h16x8 a0[2];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) a0[s_] = *reinterpret_cast<const h16x8*>(p0 + s_ * BIMG);
+#pragma unroll
+      for (int c = 0; c < BKC; ++c) {
+        h16x8 n0[2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) n0[s_] = c + 1 < BKC ? *reinterpret_cast<const h16x8*>(p0 + s_ * BIMG + 16 * (c + 1)) : a0[s_];
+        __builtin_amdgcn_sched_barrier(0);
+        mfh(acc, a0[1], wf.w[c][0]);
+        if (c < 4) stage(hb ^ 1, srow + 8 * c, nbuf[c]);     // the next tile, one row per chunk
+        mfh(acc, a0[0], wf.w[c][1]);
+        mfh(acc, a0[0], wf.w[c][0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) a0[s_] = n0[s_];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const __bf16* p0 = reinterpret_cast<const __bf16*>(xraw + kh * MM::kImgBytes) + (32 * hb + li) * BP + 8 * lg;
       bf16x8 a0[3];
 #pragma unroll
       for (int s_ = 0; s_ < 3; ++s_) a0[s_] = *reinterpret_cast<const bf16x8*>(p0 + s_ * BIMG);
@@ -799,7 +846,7 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
         mfb(acc, a0[2], wf.w[c][0]);
         mfb(acc, a0[0], wf.w[c][2]);
         mfb(acc, a0[1], wf.w[c][1]);
-        if (c < 4) MmB3::stage(simg, 32 * (hb ^ 1) + srow + 8 * c, slc4, nbuf[c]);     // the next tile, one row per chunk
+        if (c < 4) stage(hb ^ 1, srow + 8 * c, nbuf[c]);     // the next tile, one row per chunk
         mfb(acc, a0[1], wf.w[c][0]);
         mfb(acc, a0[0], wf.w[c][1]);
         mfb(acc, a0[0], wf.w[c][0]);
@@ -827,7 +874,9 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
     for (int it = 0; it < 2; ++it) {
       const int row = erow + 16 * it;
       const int64_t grow = r0 + row;
-      const float4 v = (ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4)) + b4 + g1[it] + g2[it];
+      float4 v = ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4);
+      if constexpr (MM::kScaled) v = v * (ci4 * ri[it]);      // exact: powers of two
+      v = v + b4 + g1[it] + g2[it];
       if (FULL || grow < M) {
         st4_nt(Y + grow * WH + J * FH + ec4, v);
         st.add_prod(v, v);
@@ -838,7 +887,7 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
     prefetch(pre[0], pidx[0], tb0);
     prefetch(pre[1], pidx[1], tb0 + 1);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) MmB3::stage(simg, srow + 8 * it, slc4, pre[0][it]);
+    for (int it = 0; it < 4; ++it) stage(0, srow + 8 * it, pre[0][it]);
     if (wave == 0) sd[0][lane] = pidx[0];
     prefetch(pre[0], pidx[0], tb0 + 2);
     __syncthreads();
@@ -885,12 +934,14 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_t32_h256p_k(
 // Replaces edge_bwd_gt + gemm NN [E,256,256] (gt re-read, ge read twice).  (Staging the next tile inside the matrix phase as
 // edge_t32_h256p_k does was measured here too: 31.2 vs 30.8 ms per step -- this kernel moves twice the bytes and waits on HBM.)
 // ------------------------------------------------------------------------------------------
+template <class MM>
 __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
     int64_t M, const float* __restrict__ ge, const float* __restrict__ t, const float* __restrict__ stat,
     const float* __restrict__ bstat, const float* __restrict__ gamma, const void* __restrict__ Wp,
     float* __restrict__ gt, float* __restrict__ ge_out, int nchunk, int64_t tiles_per_chunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MmB3::kImgBytes];   // [contraction half][hi|mid|lo] (rows 0-31 used)
+  __shared__ __attribute__((aligned(16))) unsigned char xraw[2 * MM::kImgBytes];   // [contraction half][split images] (rows 0-31 used)
   __shared__ float os[2 * ER3 * FP];
+  __shared__ float rinv[ER3];          // MmH2: 1 / s of the tile's rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -902,7 +953,7 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
   const int64_t tb1 = min(ntiles, tb0 + tiles_per_chunk);
   const int64_t nfull = min(tb1, M / ER3);
   const int srow = tid >> 6, sc = (tid & 63) * 4;
-  unsigned char* const simg = xraw + (sc >> 7) * MmB3::kImgBytes;
+  unsigned char* const simg = xraw + (sc >> 7) * MM::kImgBytes;
   const int slc4 = sc & (FH - 1);
   const bool mine = (sc >> 7) == J;                          // this thread's gt columns belong to this class's half
   const int erow = tid >> 5, ec4 = (tid & 31) * 4;
@@ -910,8 +961,10 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
 
   const float4 mu = ld4(stat + sc), rs = ld4(stat + WH + sc), scl = ld4(stat + 2 * WH + sc), sh = ld4(stat + 3 * WH + sc);
   const float4 m1 = ld4(bstat + sc), m2 = ld4(bstat + WH + sc), cc = ld4(gamma + sc) * rs;
-  MmB3::Frag wf;
-  MmB3::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
+  typename MM::Frag wf;
+  MM::load_w(wf, Wp, (J * 2 + kh) * 4 + cb, lane);
+  float4 ci4 = f4(1.f);
+  if constexpr (MM::kScaled) ci4 = MM::col_inv4(Wp, J * 2 * 4, ec4);
   float4 pg[4], pt[4];
   auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = (tile < tb1 ? tile : tb1 - 1) * ER3;
@@ -932,9 +985,12 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
       float4 g = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
       if (!FULL && grow >= M) g = f4(0.f);
       if (mine && (FULL || grow < M)) st4_nt(gt + grow * WH + sc, g);
-      MmB3::stage(simg, srow + 8 * it, slc4, g);
+      if constexpr (MM::kScaled) h2_stage_row64(simg, srow + 8 * it, slc4, g, &rinv[srow + 8 * it], (tid & 63) == 0);
+      else MM::stage(simg, srow + 8 * it, slc4, g);
     }
     __syncthreads();
+    float ri[2] = {1.f, 1.f};        // before the next tile's staging (no barrier at the top of a tile) can rewrite them
+    if constexpr (MM::kScaled) { ri[0] = rinv[erow]; ri[1] = rinv[erow + 16]; }
     float4 rr[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) rr[it] = ld4(ge + clampi(r0 + erow + 16 * it, Mlast) * WH + J * FH + ec4);   // L2: staged a moment ago
@@ -942,7 +998,8 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
     floatx16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    mma32_b3(xraw + kh * MmB3::kImgBytes, 0, wf, acc, li, lg);
+    if constexpr (MM::kScaled) mma32_h2(xraw + kh * MM::kImgBytes, 0, wf, acc, li, lg);
+    else mma32_b3(xraw + kh * MM::kImgBytes, 0, wf, acc, li, lg);
     float* const oh = os + kh * (ER3 * FP);
 #pragma unroll
     for (int e = 0; e < 16; ++e) oh[((e & 3) + 8 * (e >> 2) + 4 * lg) * FP + cb * 32 + li] = acc[e];
@@ -951,7 +1008,9 @@ __global__ __launch_bounds__(kBlockW, 1) void edge_gt_nn_h256_k(
     for (int it = 0; it < 2; ++it) {
       const int row = erow + 16 * it;
       const int64_t grow = r0 + row;
-      const float4 v = (ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4)) + rr[it];
+      float4 v = ld4(os + row * FP + ec4) + ld4(os + ER3 * FP + row * FP + ec4);
+      if constexpr (MM::kScaled) v = v * (ci4 * ri[it]);
+      v = v + rr[it];
       if (FULL || grow < M) st4_nt(ge_out + grow * WH + J * FH + ec4, v);
     }
   };
@@ -1810,14 +1869,18 @@ extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const f
   if (H == WH) {
     GNM_CHECK_ARG(ws && ws_bytes >= (size_t)16 * MmB3::kPackBytes, "edge_t_fused_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pack_w3_gen_k, dim3(64), dim3(256), 0, st, W3, (int64_t)WH, 2, 2, 0, (bf16x8*)ws);
+    const bool h2 = g_matmul_mode == 2;
+    if (h2) launch_pack_w2_gen(W3, (int64_t)WH, 2, 2, 0, ws, st);
+    else hipLaunchKernelGGL(pack_w3_gen_k, dim3(64), dim3(256), 0, st, W3, (int64_t)WH, 2, 2, 0, (bf16x8*)ws);
     GNM_LAUNCH_CHECK("pack_w3_gen (NT 256)");
     const int64_t ntiles = cdiv_(E, ER3);
     int nchunk = num_cus() / 2 / kXcds * kXcds;            // one 8-wave workgroup per CU, two classes per chunk
     if (nchunk < kXcds) nchunk = kXcds;
     if (nchunk > kMaxPartialBlocks) nchunk = kMaxPartialBlocks / kXcds * kXcds;
-    hipLaunchKernelGGL(edge_t32_h256p_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
-                       partials, nchunk, cdiv_(ntiles, nchunk));
+    if (h2) hipLaunchKernelGGL(edge_t32_h256p_k<MmH2>, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                               partials, nchunk, cdiv_(ntiles, nchunk));
+    else hipLaunchKernelGGL(edge_t32_h256p_k<MmB3>, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, e_in, (const void*)ws, b3, t, P, isrc, idst,
+                            partials, nchunk, cdiv_(ntiles, nchunk));
     GNM_LAUNCH_CHECK("edge_t_fused_fwd (256)");
     *nblk_out = nchunk;
     return 0;
@@ -1837,13 +1900,17 @@ extern "C" int gnm_edge_bwd_gt_nn(int64_t E, int H, const float* ge, const float
                 "edge_bwd_gt_nn: null / aliased argument (ge_out and gt must not be ge)");
   GNM_CHECK_ARG(ws && ws_bytes >= (size_t)16 * MmB3::kPackBytes, "edge_bwd_gt_nn: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pack_w3_gen_k, dim3(64), dim3(256), 0, st, W3, (int64_t)WH, 2, 2, 1, (bf16x8*)ws);
+  const bool h2 = g_matmul_mode == 2;
+  if (h2) launch_pack_w2_gen(W3, (int64_t)WH, 2, 2, 1, ws, st);
+  else hipLaunchKernelGGL(pack_w3_gen_k, dim3(64), dim3(256), 0, st, W3, (int64_t)WH, 2, 2, 1, (bf16x8*)ws);
   GNM_LAUNCH_CHECK("pack_w3_gen (NN 256)");
   const int64_t ntiles = cdiv_(E, ER3);
   int nchunk = num_cus() / 2 / kXcds * kXcds;
   if (nchunk < kXcds) nchunk = kXcds;
-  hipLaunchKernelGGL(edge_gt_nn_h256_k, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, ge, t, stat_e, bstat_e, gamma_e, (const void*)ws,
-                     gt, ge_out, nchunk, cdiv_(ntiles, nchunk));
+  if (h2) hipLaunchKernelGGL(edge_gt_nn_h256_k<MmH2>, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, ge, t, stat_e, bstat_e, gamma_e, (const void*)ws,
+                             gt, ge_out, nchunk, cdiv_(ntiles, nchunk));
+  else hipLaunchKernelGGL(edge_gt_nn_h256_k<MmB3>, dim3(nchunk * 2), dim3(kBlockW), 0, st, E, ge, t, stat_e, bstat_e, gamma_e, (const void*)ws,
+                          gt, ge_out, nchunk, cdiv_(ntiles, nchunk));
   GNM_LAUNCH_CHECK("edge_bwd_gt_nn");
   return 0;
 }

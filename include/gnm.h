@@ -299,8 +299,8 @@ size_t gnm_rowtile_workspace_bytes(int ncols);
  *      accumulator is multiplied by the exact 1 / s afterwards -- and THREE v_mfma_f32_32x32x16_f16
  *      per product (h1 w1, h1 w2, h2 w1), accumulated in fp32.  In every matrix kernel of a 128-wide
  *      layer (node_proj_fwd, edge_t_fused_fwd, node_proj_bwd_nn(_stats), tn128*, edge_bwd_chain*,
- *      edge_bwd_fused) and in the general rows / weight-gradient GEMMs of the wide models; the two
- *      fused H = 256 edge kernels run as in mode 1.
+ *      edge_bwd_fused), in the fused H = 256 edge kernels and in the general rows / weight-gradient
+ *      GEMMs of the wide models.
  *      The step runs at the package power cap: half the matrix instructions come back as time;
  *      distance to fp64 per mode: profiles/r05_f16x2_accuracy.txt (mode 2 <= mode 1 <= mode 0).
  * Applies to the NT / NN contractions of edge_t_fused_fwd, node_proj_fwd/bwd, edge_bwd_fused.   */

@@ -39,16 +39,17 @@ def _weights(rng, rows, cols, axis):
     return W
 
 
-def _check(name, run, ref, scale, cw_bar=4e-6):
+def _check(name, run, ref, scale, cw_bar=4e-6, base="f32"):
+    """base: the mode f16x2 is held against -- fp32 MFMA where the kernel has that form, else bf16x3 (the exact split)."""
     from gnnome_assembly_amd import _lib
     res = {}
-    for mode in ("f32", "f16x2"):
+    for mode in (base, "f16x2"):
         _lib.set_matmul_mode(mode)
         o = run().astype(np.float64)
         assert np.isfinite(o).all(), f"{name} [{mode}]: non-finite output"
         res[mode] = (rel_l2(o, ref), float(np.max(np.abs(o - ref) / np.maximum(scale, 1e-300))))
-    (r32, c32), (r16, c16) = res["f32"], res["f16x2"]
-    print(f"{name}: rel_l2 f16x2={r16:.2e} f32={r32:.2e}  cw f16x2={c16:.2e} f32={c32:.2e}")
+    (r32, c32), (r16, c16) = res[base], res["f16x2"]
+    print(f"{name}: rel_l2 f16x2={r16:.2e} {base}={r32:.2e}  cw f16x2={c16:.2e} {base}={c32:.2e}")
     assert r16 <= 2e-6 and r16 <= 1.5 * r32 + 1e-7, (name, r16, r32)
     if cw_bar is not None:
         assert c16 <= cw_bar, (name, c16, c32)
@@ -91,10 +92,12 @@ def test_node_projections_scale_per_row(case):
     _check(f"node_proj_fwd [{case}]", run, ref, scale, cw_bar=None if case == "tiny" else 4e-6)   # tiny: products below the fp32 range in every mode
 
 
+@pytest.mark.parametrize("H", [128, 256])
 @pytest.mark.parametrize("case", ["normal", "rows", "elements"])
-def test_edge_t_kernel_scales_per_row(case):
+def test_edge_t_kernel_scales_per_row(case, H):
     """gnm_edge_t_fused_fwd: t = e W3^T + b3 + B1h[src] + B2h[dst]; the row factors are made one tile ahead, inside the matrix phase
-    of the tile before (edge_t32_b3p_k<MmH2>)."""
+    of the tile before (edge_t32_b3p_k<MmH2>; H = 256: edge_t32_h256p_k<MmH2>, a row = the 64 lanes of one wave, one factor for both
+    contraction halves, the weight's column factors over its whole K = 256)."""
     from gnnome_assembly_amd import _lib, engine
     dev, lib = _dev(), _lib.load()
     rng = np.random.default_rng(2)
@@ -111,7 +114,7 @@ def test_edge_t_kernel_scales_per_row(case):
     scale = np.abs(en).astype(np.float64) @ np.abs(Wn).astype(np.float64).T + np.abs(bn) + np.abs(g1) + np.abs(g2)
 
     def run():
-        need = lib.gnm_rowtile_workspace_bytes(H)
+        need = lib.gnm_rowtile_workspace_bytes(5 * H)
         ws = engine.scratch(dev).ws(need)
         out = torch.empty(E, H, device=dev)
         nb = C.c_int(0)
@@ -119,7 +122,7 @@ def test_edge_t_kernel_scales_per_row(case):
                      engine._ptr(out), engine._ptr(engine.scratch(dev).partials), C.byref(nb), engine._ptr(ws), need, engine._stream())
         torch.cuda.synchronize()
         return out.cpu().numpy()
-    _check(f"edge_t_fused_fwd [{case}]", run, ref, scale)
+    _check(f"edge_t_fused_fwd H={H} [{case}]", run, ref, scale, base="f32" if H == 128 else "bf16x3")
 
 
 @pytest.mark.parametrize("case", ["normal", "tiny_grads", "rows", "groups_apart", "groups_rising", "zero_groups"])
@@ -284,3 +287,46 @@ def test_chained_backward_with_edge_gradients_spread_over_decades(spread):
         #  exact-product one there, and so does this one -- what is bounded is the distance RELATIVE to what fp32 arithmetic shows)
         assert r16 <= 1e-3 and r16 <= 2.0 * r32 + 2e-6, (k, r16, r32)
     print(f"chained backward, edge gradients over {spread} decades: worst rel_l2 vs bf16x3: f16x2 {worst16:.2e}, f32 {worst32:.2e}")
+
+
+@pytest.mark.parametrize("case", ["normal", "tiny_grads", "rows"])
+def test_wide_edge_backward_gt_nn_scales_per_row(case):
+    """gnm_edge_bwd_gt_nn (H = 256): gt = gamma rstd (gu - m1 - that m2), gu = ge [t scale + shift > 0], and ge_out = ge + gt W3 in one pass
+    (edge_gt_nn_h256_k<MmH2>): gt is formed in the kernel, its rows scaled by their own largest magnitude over all 256 columns."""
+    from gnnome_assembly_amd import _lib, engine
+    dev, lib = _dev(), _lib.load()
+    rng = np.random.default_rng(9)
+    E, Hw = 30011, 256
+    gen = {"normal": lambda: rng.standard_normal((E, Hw)),
+           "tiny_grads": lambda: rng.standard_normal((E, Hw)) * 1e-7,
+           "rows": lambda: rng.standard_normal((E, Hw)) * np.exp(rng.uniform(-25, 5, (E, 1)))}[case]().astype(np.float32)
+    tn = rng.standard_normal((E, Hw)).astype(np.float32)
+    stat = np.stack([rng.standard_normal(Hw) * 0.1, 1.0 + rng.random(Hw), 1.0 + rng.random(Hw), rng.standard_normal(Hw) * 0.3]).astype(np.float32)
+    bstat = (np.stack([rng.standard_normal(Hw), rng.standard_normal(Hw)]) * 1e-3 * float(np.abs(gen).mean())).astype(np.float32)
+    gam = (0.5 + rng.random(Hw)).astype(np.float32)
+    Wn = _weights(rng, Hw, Hw, 1)
+    ge, t, st_, bs_, ga_, W3 = (torch.from_numpy(a).to(dev) for a in (gen, tn, stat, bstat, gam, Wn))
+    g64, t64 = gen.astype(np.float64), tn.astype(np.float64)
+    gu = g64 * ((tn * stat[2] + stat[3]) > 0)            # the branch as the kernel takes it: sign of the fp32 fma (no kink within 1 ulp here)
+    gt_ref = (gam.astype(np.float64) * stat[1]) * (gu - bstat[0] - ((t64 - stat[0]) * stat[1]) * bstat[1])
+    ref = g64 + gt_ref @ Wn.astype(np.float64)
+    scale = np.abs(g64) + np.abs(gt_ref) @ np.abs(Wn).astype(np.float64)
+
+    def run():
+        need = lib.gnm_rowtile_workspace_bytes(5 * Hw)
+        ws = engine.scratch(dev).ws(need)
+        gt, out = torch.empty(E, Hw, device=dev), torch.empty(E, Hw, device=dev)
+        engine._call("gnm_edge_bwd_gt_nn", E, Hw, engine._ptr(ge), engine._ptr(t), engine._ptr(st_), engine._ptr(bs_), engine._ptr(ga_), engine._ptr(W3),
+                     engine._ptr(gt), engine._ptr(out), engine._ptr(ws), need, engine._stream())
+        torch.cuda.synchronize()
+        assert rel_l2(gt.cpu().numpy().astype(np.float64), gt_ref) <= 5e-7
+        return out.cpu().numpy()
+    from gnnome_assembly_amd import _lib as L_
+    res = {}
+    for mode in ("bf16x3", "f16x2"):                     # (no fp32-MFMA twin of this kernel: bf16x3, the exact split, is the yardstick)
+        L_.set_matmul_mode(mode)
+        o = run().astype(np.float64)
+        assert np.isfinite(o).all()
+        res[mode] = (rel_l2(o, ref), float(np.max(np.abs(o - ref) / np.maximum(scale, 1e-300))))
+    print(f"edge_bwd_gt_nn [{case}]: rel_l2 f16x2={res['f16x2'][0]:.2e} bf16x3={res['bf16x3'][0]:.2e}  cw f16x2={res['f16x2'][1]:.2e} bf16x3={res['bf16x3'][1]:.2e}")
+    assert res["f16x2"][0] <= 2e-6 and res["f16x2"][0] <= 1.5 * res["bf16x3"][0] + 1e-7 and res["f16x2"][1] <= 4e-6
