@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--inference", action="store_true", help="forward only under no_grad (config 5)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3", "f16x2"],
-                    help="fused-kernel matmul mode (default: GNM_MATMUL or the library default bf16x3); see include/gnm.h")
+                    help="fused-kernel matmul mode (default: GNM_MATMUL or the library default f16x2); see include/gnm.h")
     ap.add_argument("--no-alt-matmul", action="store_true", help="skip the extra measurement in the other matmul mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores)")
     ap.add_argument("--shuffle-nodes", action="store_true",
@@ -127,7 +127,7 @@ def op_model(op: str, N: int, E: int, H: int):
 # number together with `traffic_source`; C-ABI op -> rocprof kernel name(s) of the op in each matmul mode.
 TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
 OP_KERNELS = {
-    "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_tr_k<3>", "edge_bwd_tr_k"]},
+    "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_tr_k<3, false>"], "f16x2": ["edge_bwd_tr_k<3, true>"]},
     "gnm_edge_bwd_chain": ["edge_bwd_chain_k"], "gnm_edge_bwd_chain_src": ["edge_bwd_chain_k"],
     "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true, true, 128>"], "gnm_node_bgrad": ["node_bgrad_k<128>"], "gnm_edge_bwd_top": ["edge_bwd_chain_k"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
@@ -427,7 +427,7 @@ def main():
             alt.append({"matmul": other, "ms_per_step": adt / args.steps * 1e3, "value": aedges * args.steps / adt, "unit": "edges/s"})
         G._lib.set_matmul_mode(mode)
         alt[0]["note"] = ("f16x2: fp32 operands as two fp16 terms of a power-of-two multiple (22 significand bits), 3 MFMAs per product, in "
-                          "the node projections, the edge t kernel and the projection backward, bf16x3 in the rest; bf16x3: fp32 operands "
+                          "every split-mode matrix kernel; bf16x3: fp32 operands "
                           "split exactly into 3 bf16 terms, 6 bf16 MFMAs per product; f32: every contraction on v_mfma_f32_32x32x2_f32.  "
                           "fp32 accumulate in all three; all three pass the whole of tests/test_gpu_parity.py; distance to the fp64 oracle "
                           "per mode: profiles/r05_f16x2_accuracy.txt")
@@ -471,15 +471,11 @@ def main():
     if rank == 0:
         tot = sum(t for _, t in ops.values())
         ranked = sorted(ops.items(), key=lambda kv: -kv[1][1])
-        # fp32-equivalent FLOP/s of an op's matrix arithmetic: six bf16 MFMAs per product (bf16x3), three fp16 (f16x2, in the ops that
-        # have it: include/gnm.h), or the fp32 MFMA rate
-        H2_OPS = ("gnm_node_proj_fwd", "gnm_edge_t_fused_fwd", "gnm_node_proj_bwd_nn", "gnm_tn128", "gnm_node_proj_bwd_tn", "gemm_")
-
+        # fp32-equivalent FLOP/s of an op's matrix arithmetic: six bf16 MFMAs per product (bf16x3), three fp16 (f16x2), or the fp32 MFMA rate
         def mm_peak_of(op):
-            if mode == "f32":
+            if mode == "f32" or op.startswith(("gnm_predictor", "gnm_edge_encoder")):       # those run fp32 MFMAs in every mode
                 return F32_MFMA_PEAK
-            h2 = mode == "f16x2" and op.startswith(H2_OPS) and not op.startswith("gnm_edge_t_fused_fwd[256]")
-            return BF16_MFMA_PEAK / (3 if h2 else 6)
+            return BF16_MFMA_PEAK / (3 if mode == "f16x2" else 6)
         traffic, step_traffic, traffic_src = load_traffic(n, E, H, mode)
         if args.inference:
             step_traffic = None

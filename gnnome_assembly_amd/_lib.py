@@ -144,7 +144,7 @@ DEFAULT_MATMUL_MODE = "f16x2"
 
 def set_matmul_mode(mode: str) -> None:
     """'f16x2' (default: two fp16 terms of a power-of-two multiple, 22 significand bits per operand, three MFMAs per product, in
-    the kernels that have it; bf16x3 in the rest), 'bf16x3' (exact 3-way bf16 split, six bf16 MFMAs per product, fp32
+    every split-mode matrix kernel), 'bf16x3' (exact 3-way bf16 split, six bf16 MFMAs per product, fp32
     accumulate) or 'f32' (fp32 MFMA)."""
     if mode not in MATMUL_MODES:
         raise GnmError(f"matmul mode {mode!r}: expected one of {sorted(MATMUL_MODES)}")

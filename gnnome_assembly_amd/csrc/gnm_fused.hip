@@ -455,7 +455,7 @@ __global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int 
 static void launch_pack_w2_gen(const float* W, int64_t ld, int ncls, int ncg, int nn, void* ws, hipStream_t st);
 
 // 0: fp32 MFMA; 1: bf16x3 split (the default of rounds 2-4: same parity bars, 2.7x the matrix rate);
-// 2: f16x2 in the kernels that have it (MmH2: node projections, edge t, projection backward), bf16x3 in the rest -- the default
+// 2: f16x2 (MmH2 here, the H2 forms of gnm_tr.hip) in every split-mode matrix kernel -- the default
 //    since round 5: every fused step runs at the package power cap, three MFMAs per product instead of six is energy that comes
 //    back as time, and its results are no further from fp64 than those of mode 0 or 1 (profiles/r05_f16x2_accuracy.txt)
 static int g_matmul_mode = 2;
@@ -1864,7 +1864,7 @@ static int edge_t_fused_impl(int64_t E, const float* e_in, const float* W3, cons
 extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const float* W3, const float* b3,
                                     const float* P, const int32_t* isrc, const int32_t* idst, float* t,
                                     double* partials, int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
-  GNM_CHECK_ARG(H == FH || (H == WH && g_matmul_mode), "edge_t_fused_fwd: H=%d (128, and 256 in the bf16x3 matmul mode, are built)", H);
+  GNM_CHECK_ARG(H == FH || (H == WH && g_matmul_mode), "edge_t_fused_fwd: H=%d (128, and 256 in the split matmul modes, are built)", H);
   GNM_CHECK_ARG(E > 0 && e_in && W3 && b3 && P && isrc && idst && t && partials && nblk_out, "edge_t_fused_fwd: null/neg argument");
   if (H == WH) {
     GNM_CHECK_ARG(ws && ws_bytes >= (size_t)16 * MmB3::kPackBytes, "edge_t_fused_fwd: workspace too small");
@@ -1895,7 +1895,7 @@ extern "C" int gnm_edge_t_fused_fwd(int64_t E, int H, const float* e_in, const f
 extern "C" int gnm_edge_bwd_gt_nn(int64_t E, int H, const float* ge, const float* t, const float* stat_e, const float* bstat_e,
                                   const float* gamma_e, const float* W3, float* gt, float* ge_out, void* ws, size_t ws_bytes,
                                   void* stream) {
-  GNM_CHECK_ARG(H == WH && g_matmul_mode, "edge_bwd_gt_nn: H=%d (256 in the bf16x3 matmul mode is what is built)", H);
+  GNM_CHECK_ARG(H == WH && g_matmul_mode, "edge_bwd_gt_nn: H=%d (256 in the split matmul modes is what is built)", H);
   GNM_CHECK_ARG(E > 0 && ge && t && stat_e && bstat_e && gamma_e && W3 && gt && ge_out && ge_out != ge && gt != ge,
                 "edge_bwd_gt_nn: null / aliased argument (ge_out and gt must not be ge)");
   GNM_CHECK_ARG(ws && ws_bytes >= (size_t)16 * MmB3::kPackBytes, "edge_bwd_gt_nn: workspace too small");

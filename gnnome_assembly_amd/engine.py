@@ -633,7 +633,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     return gh_in, ge, g
 
 
-# The chained backward schedule (H = 128, BatchNorm, bf16x3 matmul mode): the fused edge backward of layer i runs in
+# The chained backward schedule (H = 128, BatchNorm, the split matmul modes): the fused edge backward of layer i runs in
 # ONE kernel with the by-destination pass of layer i-1 (gnm_edge_bwd_chain: 5 [E,H] streams instead of 4 + 4, the
 # matrix-core work under the gather arithmetic).  GNM_CHAIN=0 / engine.options(CHAIN=False) goes back to layer_backward.
 _D_CHAIN = os.environ.get("GNM_CHAIN", "1") != "0"

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def matmul_mode(request):
     """Every test of this file runs under ALL THREE matmul modes of the fused kernels (include/gnm.h):
     "f16x2" -- the library default, the mode bench.py's `value` is measured in: two fp16 terms of a power-of-two
-    multiple, three MFMAs per product, in the kernels that have it --, "bf16x3" (the exact three-term split, six MFMAs
+    multiple, three MFMAs per product --, "bf16x3" (the exact three-term split, six MFMAs
     per product; the default of rounds 2-4) and the fp32-MFMA mode.  Tests that never reach a fused kernel are marked
     `mode_independent` and run once."""
     from gnnome_assembly_amd import _lib
