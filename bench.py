@@ -129,7 +129,7 @@ TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
 OP_KERNELS = {
     "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_tr_k<3, false>"], "f16x2": ["edge_bwd_tr_k<3, true>"]},
     "gnm_edge_bwd_chain": ["edge_bwd_chain_k"], "gnm_edge_bwd_chain_src": ["edge_bwd_chain_k"],
-    "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true, true, 128>"], "gnm_node_bgrad": ["node_bgrad_k<128>"], "gnm_edge_bwd_top": ["edge_bwd_chain_k"],
+    "gnm_edge_gate2_fwd": ["edge_gate2_fwd_k<true, true, 128, false>"], "gnm_node_bgrad": ["node_bgrad_k<128>"], "gnm_edge_bwd_top": ["edge_bwd_chain_k"],
     "gnm_edge_bwd_dst": ["edge_bwd_dst_k<128>"], "gnm_edge_bwd_src": ["edge_bwd_src_k<128>"],
     "gnm_edge_gate_fwd": ["edge_gate_fwd_k<128, true>"], "gnm_node_agg_src_fwd": ["node_agg_src_fwd_k<128>"],
     "gnm_edge_t_fused_fwd": {"f32": ["rowtile_nt_k<MmF32, true, 1>"], "bf16x3": ["edge_t32_b3p_k<MmB3>"], "f16x2": ["edge_t32_b3p_k<MmH2>"]},
