@@ -512,6 +512,12 @@ def main():
                         dominant_kernel_launches=k0["launches_per_step"], dominant_kernel_share_of_step=k0["share_of_step"],
                         dominant_kernel_hbm_frac=k0.get("hbm", {}).get("frac"),
                         dominant_kernel_traffic_gb=k0.get("traffic_gb"))
+            # the same kernel priced with SURVEY.md 8(d)'s own per-edge figure instead of this repo's stream count (VERDICT r4
+            # weak #6): a layer's whole backward = 20 H bytes per edge, its whole forward = 12 H, whichever side the op is on
+            bwd_side = "bwd" in k0["op"] or "tn128" in k0["op"]
+            b8d = (20 if bwd_side else 12) * H * E
+            roof.update(dominant_kernel_8d_bytes_per_edge=(20 if bwd_side else 12) * H,
+                        dominant_kernel_hbm_frac_8d=round(b8d / (k0["avg_launch_ms"] / 1e3) / HBM_PEAK, 4))
         res = {
             "metric": "GatedGCN edges/sec fwd+bwd, chr19 assembly graph" if not args.inference
                       else "GatedGCN edges/sec fwd only (inference)",

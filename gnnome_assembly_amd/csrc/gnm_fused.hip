@@ -1788,10 +1788,13 @@ __global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ s
   if (threadIdx.x < 32) st4(out + i0 + threadIdx.x * 4, s_);
 }
 
-// out[m * ldc + n] = sum_b slab[b][m][n] for one 128 x 128 block (a workgroup = one row m)
-__global__ __launch_bounds__(256) void slab_reduce_ld_k(const float* __restrict__ slab, int nslab, float* __restrict__ out, int64_t ldc) {
+// out[m * ldc + n] = sum_b slab[b][m][n] for the 128 x 128 block blockIdx.y = cls of a [ncga x ncgb] grid of blocks (a workgroup
+// = one row m of one block; class cls owns slabs cls * nslab .. and the block (cls / ncgb, cls % ncgb) of C)
+__global__ __launch_bounds__(256) void slab_reduce_ld_k(const float* __restrict__ slab, int nslab, int ncgb, float* __restrict__ out, int64_t ldc) {
   __shared__ __attribute__((aligned(16))) float red[8 * 128];
-  const int m = blockIdx.x;
+  const int m = blockIdx.x, cls = blockIdx.y;
+  slab += (size_t)cls * nslab * FH * FH;
+  out += (int64_t)(cls / ncgb) * FH * ldc + (cls % ncgb) * FH;
   const float4 s_ = slab_reduce_128(slab, nslab, FH * FH, m * FH, red);
   if (threadIdx.x < 32) st4(out + (int64_t)m * ldc + threadIdx.x * 4, s_);
 }
@@ -2177,9 +2180,7 @@ int gemm_b3_try(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64
     float* slab = (float*)ws;
     double* partials = (double*)((char*)ws + (size_t)ncls * nslot * FH * FH * sizeof(float));
     tn_tr_launch(K, A, lda, ncga, B, ldb, ncgb, slab, partials, nslot, cdiv_(ntiles, nslot), st, nullptr, g_matmul_mode == 2);
-    for (int cls = 0; cls < ncls; ++cls)
-      hipLaunchKernelGGL(slab_reduce_ld_k, dim3(FH), dim3(256), 0, st, (const float*)slab + (size_t)cls * nslot * FH * FH,
-                         nslot, C + (int64_t)(cls / ncgb) * FH * ldc + (cls % ncgb) * FH, ldc);
+    hipLaunchKernelGGL(slab_reduce_ld_k, dim3(FH, ncls), dim3(256), 0, st, (const float*)slab, nslot, ncgb, C, ldc);   // one launch for all blocks
     return hipGetLastError() == hipSuccess ? 1 : -2;
   }
   if (!al(C, ldc) || (resid && !al(resid, ldr)) || (bias && (uintptr_t)bias % 16 != 0)) return 0;
