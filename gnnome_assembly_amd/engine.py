@@ -649,7 +649,19 @@ _D_TN_SIDE = os.environ.get("GNM_TN_SIDE", "1") != "0"
 _D_TN_SIDE_CAP = int(os.environ.get("GNM_TN_CAP", "0"))
 # when the deferred weight-gradient kernel of layer i is launched: "next" = at the head of layer i-1's iteration (beside its
 # by-source pass / conversion), "now" = right after layer i's own by-source pass or conversion (beside nn(i), node(i-1))
-_D_TN_AT = os.environ.get("GNM_TN_AT", "now")       # round 5 (NODE_FUSED): "now" 161.4 vs "next" 163.2 ms/step, profiles/r05_ab_tn_at.txt
+# "auto" (default): by graph size -- "now" from TN_AT_NOW_NODES nodes on, "next" below.  At the metric's graph (N = 1.5 M) "now" wins
+# (161.4 vs 163.2 ms/step bf16x3, 153.6-154.2 vs 154.8-155.4 f16x2: profiles/r05_ab_tn_at.txt, r05_ab_schedule_f16x2.txt); on small graphs the
+# HBM-bound window beside nn(i) / node(i-1) is too short for the weight-gradient kernel and "next" wins: N = 750 k 76.8-77.7 vs 77.4-79.0 ms,
+# N = 220 k (the true chr19 size) 24.6-24.7 vs 24.8-24.9, the mini-batch epoch (sub-graphs of N = 150 k) 41.5-42.1 vs 40.5-41.3 M edges/s
+# (profiles/r05_ab_tn_at_sizes.txt)
+_D_TN_AT = os.environ.get("GNM_TN_AT", "auto")
+TN_AT_NOW_NODES = int(os.environ.get("GNM_TN_AT_NOW_NODES", "1100000"))
+
+
+def tn_at(N: int) -> str:
+    """The TN_AT switch of the current options resolved for a graph of N nodes ("auto": by size, see TN_AT_NOW_NODES)."""
+    v = current().TN_AT
+    return ("now" if N >= TN_AT_NOW_NODES else "next") if v == "auto" else v
 # "next" only: the deferred kernel in TWO launches sized to the two HBM-bound windows of an iteration -- the gB1h | gB2h column groups
 # beside this layer's conversion (node_bgrad), the gA1h | gA2h | gA3h groups AFTER this layer's nn (both matrix bound: side by side
 # they only take turns) beside the next layer's BatchNorm_h backward.  GNM_TN_SPLIT=0: one launch at the head of the iteration.
@@ -770,6 +782,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     side = _side_stream(dev) if (current().TN_SIDE and _prof is None and current().ACTIVATIONS != "lean") else None
     main = torch.cuda.current_stream()
     fusedn = current().NODE_FUSED and plan is not None      # the node side without node_bgrad / node_bwd_stats launches (see NODE_FUSED)
+    at_now = tn_at(N) == "now"          # when the deferred weight-gradient kernel is launched (TN_AT; "auto": by graph size)
     pending = None              # (gP, h_in, gW5, gb5) of the layer above: its weight-gradient kernel, not yet launched
     pending2 = None             # the same, when only its first launch (TN_SPLIT) has been issued
     held: List[torch.Tensor] = []   # what the side stream is reading; dropped only after the main stream has waited for it
@@ -812,7 +825,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                       _ptr(s_j.stat_h), _ptr(sc.partials), C.byref(nblk_h), _ptr(ws), need_p, st)
             else:
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
-            if side is not None and current().TN_AT == "now":             # tn012(i) right away, beside node(i-1)'s [N,H] passes
+            if side is not None and at_now:             # tn012(i) right away, beside node(i-1)'s [N,H] passes
                 side_begin()
                 tn128(N, gP, 5 * H, 3, s.h_in, g["W5"], g["b5"], sc3.partials, sc3.ws(need_t), need_t, stream=side)
                 held.extend((gP, s.h_in))
@@ -850,7 +863,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
             split2 = UT is not None
             del Ud, Td, Q
             UT = None
-            if not (side is not None and current().TN_AT == "now"):
+            if not (side is not None and at_now):
                 _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
             if pending2 is not None:        # the other three column groups of the layer above, behind this layer's nn
                 pgP, ph, pW, pb = pending2
@@ -858,7 +871,7 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
                 sc3 = scratch(dev, "tn")
                 tn128(N, pgP, 5 * H, 3, ph, pW, pb, sc3.partials, sc3.ws(need_t), need_t, stream=side)
                 pending2 = None
-            if side is not None and current().TN_AT == "now":
+            if side is not None and at_now:
                 side_begin()
                 sc3 = scratch(dev, "tn")
                 ws3 = sc3.ws(need_p)

@@ -1270,8 +1270,9 @@ def test_round5_node_side_schedule_matches_the_round4_schedule(ids):
     assert not bad, ("round 5 vs round 4", bad)
     s6, _, g6 = run(ACTIVATIONS="lean")
     assert torch.equal(s6, s1) and all(torch.equal(g6[k], g1[k]) for k in g1), "lean activations must be bit-identical"
-    _, _, g7 = run(TN_AT="next")
-    assert all(torch.equal(g7[k], g1[k]) for k in g1), "where the deferred weight-gradient kernel runs must not matter"
+    for at in ("next", "now"):        # the default is "auto" = by graph size (engine.tn_at): both placements explicitly
+        _, _, g7 = run(TN_AT=at)
+        assert all(torch.equal(g7[k], g1[k]) for k in g1), "where the deferred weight-gradient kernel runs must not matter"
 
 
 @pytest.mark.default_mode_only
