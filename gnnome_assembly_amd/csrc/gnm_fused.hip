@@ -450,7 +450,7 @@ __global__ void pack_w3_k(const float* __restrict__ W, int64_t ld, int ncb, int 
 }
 
 // f16x2 fragment pack: block = { h16x8 frag[c][s][lane] (s = hi/lo of W s_n), float inv[32] = 1 / s_n of its 32 output columns }, s_n from
-// the largest magnitude of column n over its whole contraction (launch_col_amax, gnm_tr.hip); element order as pack_w3_k.  Defined with the
+// the largest magnitude of column n over its whole contraction (taken by the pack kernel itself); element order as pack_w3_k.  Defined with the
 // general row GEMM below (pack_w2_gen_k): a single 128-deep weight is its ncg = 1 case.
 static void launch_pack_w2_gen(const float* W, int64_t ld, int ncls, int ncg, int nn, void* ws, hipStream_t st);
 
@@ -1654,17 +1654,34 @@ __global__ void pack_w3_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
 }
 
 // the same for MmH2 (block layout of pack_w2_k); a column's factor is taken over its WHOLE contraction (all ncg groups), so that
-// an accumulator that runs over the groups keeps one unit per column: launch_col_amax (gnm_tr.hip) leaves the columns' largest magnitudes
-// behind the fragment blocks (the workspace is sized for the larger bf16x3 blocks), pack_w2_gen_k reads them
-__global__ void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncls, int ncg, int nn, unsigned char* __restrict__ Wp) {
-  const int total = ncls * ncg * 4 * BKC * 64;
-  const float* amax = reinterpret_cast<const float*>(Wp + (size_t)ncls * ncg * 4 * MmH2::kPackBytes);
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int lane = idx & 63, c = (idx >> 6) % BKC, blk = idx / (64 * BKC);
-    const int wv = blk & 3, cg = (blk >> 2) % ncg, cls = (blk >> 2) / ncg;
+// an accumulator that runs over the groups keeps one unit per column.  One workgroup per fragment block (32 output columns x one
+// 128-deep group): it first takes the largest magnitude of its 32 columns over the whole K = ncg x 128 (32 columns x 8 contraction
+// slices, joined through LDS -- the weight is L2-resident, the ncg-fold re-read is a few hundred KB), then packs.  (Until the end of
+// round 5 the maxima came from a launch of their own, col_amax_k: 26 more launches per step on the critical path of the kernel behind.)
+__global__ __launch_bounds__(256) void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncg, int nn, unsigned char* __restrict__ Wp) {
+  __shared__ float part[8][32];
+  const int blk = blockIdx.x;
+  const int wv = blk & 3, cg = (blk >> 2) % ncg, cls = (blk >> 2) / ncg;
+  {
+    const int c = threadIdx.x & 31, ks = threadIdx.x >> 5;
+    const int64_t n = (int64_t)cls * FH + wv * 32 + c, K = (int64_t)ncg * FH;
+    float m = 0.f;
+    if (nn) {
+      for (int64_t k = ks; k < K; k += 8) m = fmaxf(m, fabsf(W[k * ld + n]));
+    } else {
+      const float* row = W + n * ld;
+      for (int64_t k = ks; k < K; k += 8) m = fmaxf(m, fabsf(row[k]));
+    }
+    part[ks][c] = m;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < BKC * 64; idx += 256) {
+    const int lane = idx & 63, c = idx >> 6;
     const int i = lane & 31, g = lane >> 5;
     const int64_t n = (int64_t)cls * FH + wv * 32 + i;
-    const float m = amax[n];
+    float m = part[0][i];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) m = fmaxf(m, part[q][i]);
     float sc, inv;
     h2_scale(__float_as_uint(m), sc, inv);
     h16x8 hi, lo;
@@ -1685,10 +1702,7 @@ __global__ void pack_w2_gen_k(const float* __restrict__ W, int64_t ld, int ncls,
 }
 
 static void launch_pack_w2_gen(const float* W, int64_t ld, int ncls, int ncg, int nn, void* ws, hipStream_t st) {
-  static_assert(MmB3::kPackBytes - MmH2::kPackBytes >= FH * sizeof(float), "the column maxima fit behind the f16x2 blocks");
-  float* amax = reinterpret_cast<float*>((unsigned char*)ws + (size_t)ncls * ncg * 4 * MmH2::kPackBytes);
-  launch_col_amax(W, ld, ncls * FH, (int64_t)ncg * FH, nn, amax, st);
-  hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, W, ld, ncls, ncg, nn, (unsigned char*)ws);
+  hipLaunchKernelGGL(pack_w2_gen_k, dim3(4 * ncls * ncg), dim3(256), 0, st, W, ld, ncg, nn, (unsigned char*)ws);
 }
 
 // slab[(cg*nslot + slot)][n][c] = sum over the slot's rows of A[row][cg*128+n] * B[row][c];

@@ -239,8 +239,6 @@ struct TnConv {
   float* Xw; int64_t ldxw;                                                            // the formed groups go to Xw[r][cg*128 + c]
 };
 
-// amax[n] = the largest magnitude of column n of a [K, ncols] (nn) or row n of a [ncols, K] (!nn) weight (gnm_tr.hip)
-void launch_col_amax(const float* W, int64_t ld, int ncols, int64_t K, int nn, float* amax, hipStream_t st);
 
 constexpr int kSweepTileRows = 16;      // rows per tile of the sweep kernels (= ER of gnm_tr.hip)
 constexpr int kSweepSlots = 32;         // accumulator slots per workgroup (<= 28 are ever live on the chr19-scale graph)

@@ -298,59 +298,41 @@ __global__ void pack_w3_nn16_k(const float* __restrict__ W, int64_t ld, bf16x8* 
   }
 }
 
-// Largest magnitude per output column of a weight, for the f16x2 packs (a column's factor spans its whole contraction).  The weight is
-// small (<= 1.3 MB, L2-resident) and the launch sits on the critical path of the kernel behind it: 32 columns x 8 contraction slices per
-// workgroup, joined through LDS -- one thread per column (the first version) was a 640-deep serial loop, 0.1 ms per call.
-__global__ __launch_bounds__(256) void col_amax_k(const float* __restrict__ W, int64_t ld, int ncols, int64_t K, int nn, float* __restrict__ amax) {
-  __shared__ float part[8][32];
-  const int c = threadIdx.x & 31, ks = threadIdx.x >> 5;
-  const int n = blockIdx.x * 32 + c;
-  float m = 0.f;
-  if (n < ncols) {
-    if (nn) {
-      for (int64_t k = ks; k < K; k += 8) m = fmaxf(m, fabsf(W[k * ld + n]));
-    } else {
-      const float* row = W + (int64_t)n * ld;
-      for (int64_t k = ks; k < K; k += 8) m = fmaxf(m, fabsf(row[k]));
-    }
-  }
-  part[ks][c] = m;
-  __syncthreads();
-  if (ks == 0 && n < ncols) {
-#pragma unroll
-    for (int q = 1; q < 8; ++q) m = fmaxf(m, part[q][c]);
-    amax[n] = m;
-  }
-}
-void launch_col_amax(const float* W, int64_t ld, int ncols, int64_t K, int nn, float* amax, hipStream_t st) {
-  hipLaunchKernelGGL(col_amax_k, dim3((ncols + 31) / 32), dim3(256), 0, st, W, ld, ncols, K, nn, amax);
-}
-
 // f16x2 form (edge_bwd_chain_k<..., H2>): Wp2[cb][kc][s = hi/lo][lane] (h16x8) of W s_n, s_n = the power of two that puts the largest
-// magnitude of output column n at 2^14 (h2_scale); 1 / s_n of the 128 columns as floats behind the 64 KB of fragments
+// magnitude of output column n at 2^14 (h2_scale); 1 / s_n of the 128 columns as floats behind the 64 KB of fragments.  One workgroup per
+// 16-column block cb (grid = SW / 16): it takes its columns' largest magnitudes itself (16 columns x 16 contraction slices through LDS;
+// a launch of its own until the end of round 5) and packs.
 constexpr size_t kW2Nn16FragBytes = (size_t)(SW / 16) * (SW / 32) * 2 * 64 * 16;
-__global__ void pack_w2_nn16_k(const float* __restrict__ W, int64_t ld, unsigned char* __restrict__ Wp) {
-  const int total = (SW / 16) * (SW / 32) * 64;
-  const float* amax = reinterpret_cast<const float*>(Wp + kW2Nn16FragBytes) + SW;      // launch_col_amax left them behind the 128 factors
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int lane = idx & 63, kc = (idx >> 6) % (SW / 32), cb = idx / (64 * (SW / 32));
-    const int n = lane & 15, g = lane >> 4;
-    const float m = amax[16 * cb + n];
-    float sc, inv;
-    h2_scale(__float_as_uint(m), sc, inv);
-    h16x8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = W[(int64_t)(32 * kc + 8 * g + j) * ld + 16 * cb + n] * sc;
-      const _Float16 h = (_Float16)x;
-      hi[j] = h;
-      lo[j] = (_Float16)(x - (float)h);
-    }
-    h16x8* o = reinterpret_cast<h16x8*>(Wp) + ((int64_t)(cb * (SW / 32) + kc) * 2) * 64 + lane;
-    o[0] = hi;
-    o[64] = lo;
-    if (kc == 0 && g == 0) reinterpret_cast<float*>(Wp + kW2Nn16FragBytes)[16 * cb + n] = inv;
+__global__ __launch_bounds__(256) void pack_w2_nn16_k(const float* __restrict__ W, int64_t ld, unsigned char* __restrict__ Wp) {
+  __shared__ float part[16][16];
+  const int cb = blockIdx.x;
+  {
+    const int c = threadIdx.x & 15, ks = threadIdx.x >> 4;
+    float m = 0.f;
+    for (int k = ks; k < SW; k += 16) m = fmaxf(m, fabsf(W[(int64_t)k * ld + 16 * cb + c]));
+    part[ks][c] = m;
   }
+  __syncthreads();
+  static_assert((SW / 32) * 64 == 256, "one pass of 256 threads packs a 16-column block");
+  const int lane = threadIdx.x & 63, kc = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  float m = part[0][n];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) m = fmaxf(m, part[q][n]);
+  float sc, inv;
+  h2_scale(__float_as_uint(m), sc, inv);
+  h16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = W[(int64_t)(32 * kc + 8 * g + j) * ld + 16 * cb + n] * sc;
+    const _Float16 h = (_Float16)x;
+    hi[j] = h;
+    lo[j] = (_Float16)(x - (float)h);
+  }
+  h16x8* o = reinterpret_cast<h16x8*>(Wp) + ((int64_t)(cb * (SW / 32) + kc) * 2) * 64 + lane;
+  o[0] = hi;
+  o[64] = lo;
+  if (kc == 0 && g == 0) reinterpret_cast<float*>(Wp + kW2Nn16FragBytes)[16 * cb + n] = inv;
 }
 
 template <bool FULL>
@@ -694,8 +676,7 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
                        double* partials, hipStream_t st, bool h2) {
   if (h2) {
-    launch_col_amax(W3, (int64_t)SW, SW, SW, 1, reinterpret_cast<float*>((unsigned char*)wpack + kW2Nn16FragBytes) + SW, st);
-    hipLaunchKernelGGL(pack_w2_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
+    hipLaunchKernelGGL(pack_w2_nn16_k, dim3(SW / 16), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
     const int64_t ntiles = (E + ER - 1) / ER;
     const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_bwd_tr_k<3, true>>());
     hipLaunchKernelGGL((edge_bwd_tr_k<3, true>), dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e,
@@ -1315,8 +1296,7 @@ __global__ __launch_bounds__(256) void zero_empty_segments_k(int64_t N, const in
 // returns the grid size (= number of gW3 slabs / partial rows of both kinds)
 int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hipStream_t st, bool h2) {
   if (W3 && h2) {
-    launch_col_amax(W3, (int64_t)SW, SW, SW, 1, reinterpret_cast<float*>((unsigned char*)wpack + kW2Nn16FragBytes) + SW, st);
-    hipLaunchKernelGGL(pack_w2_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
+    hipLaunchKernelGGL(pack_w2_nn16_k, dim3(SW / 16), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
   }
   else if (W3) hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   ChainArgs a = in;
