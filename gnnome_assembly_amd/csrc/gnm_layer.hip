@@ -440,18 +440,23 @@ __global__ __launch_bounds__(kBlock) void edge_bwd_gt_k(int64_t E, const float* 
 
 // -------------------------------------------------------------------------------------------
 // BatchNorm statistic finalisation: parallel fp64 reduction of the per-workgroup partial rows
-// (fixed order -> deterministic), then a tiny per-channel kernel.
+// (fixed order -> deterministic) and the per-channel arithmetic, one launch.
 // -------------------------------------------------------------------------------------------
-// out[i] = sum_b partials[b*total + i];  one workgroup per 16 columns, 16 row-groups x 16 columns
-__global__ __launch_bounds__(256) void reduce_rows_f64_k(const double* __restrict__ partials, int nblk,
-                                                          int total, double* __restrict__ out) {
+// Reduction AND finalisation in one launch (round 5: two launches, 32 per step, on the critical path of the kernel that needs the
+// statistics): a workgroup owns 8 channels = the 16 columns {c, H + c} of the partial rows, sums them in a fixed order (16 row groups x four
+// independent chains -- a single dependent chain made this 30 us --, joined through LDS: deterministic; the sums are also left in `sums`) and finalises its channels.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_finalize_k(const double* __restrict__ partials, int nblk, int H, double inv_count,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, double eps,
+                                                             double* __restrict__ sums, float* __restrict__ stat,
+                                                             float* __restrict__ ggamma, float* __restrict__ gbeta) {
   __shared__ double red[16][17];
+  __shared__ double fin[16];
   const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
-  const int col = blockIdx.x * 16 + c;
+  const int ch = blockIdx.x * 8 + (c & 7);
+  const int col = (c >> 3) * H + ch, total = 2 * H;
   double acc = 0.0;
-  if (col < total) {
-    // four independent chains keep four loads in flight (a single dependent chain made this 30 us);
-    // the order of the additions is fixed, so the result is still deterministic
+  if (ch < H) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const double* p = partials + col;
     int b = r;
@@ -466,39 +471,32 @@ __global__ __launch_bounds__(256) void reduce_rows_f64_k(const double* __restric
   }
   red[r][c] = acc;
   __syncthreads();
-  if (r == 0 && col < total) {
+  if (r == 0) {
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += red[k][c];
-    out[col] = s;
+    fin[c] = s;
+    if (ch < H) sums[col] = s;
   }
-}
-
-__global__ void bn_finalize_k(const double* __restrict__ sums, double inv_count, int H,
-                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                              double eps, float* __restrict__ stat) {
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    const double mean = sums[c] * inv_count;
-    double var = sums[H + c] * inv_count - mean * mean;   // biased variance, exact sums in fp64
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + eps));
-    const float scale = gamma[c] * rstd;
-    stat[c] = (float)mean;
-    stat[H + c] = rstd;
-    stat[2 * H + c] = scale;
-    stat[3 * H + c] = beta[c] - (float)mean * scale;
-  }
-}
-
-__global__ void bn_bwd_finalize_k(const double* __restrict__ sums, double inv_count, int H,
-                                  float* __restrict__ bstat, float* __restrict__ ggamma,
-                                  float* __restrict__ gbeta) {
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    const double s1 = sums[c], s2 = sums[H + c];
-    bstat[c] = (float)(s1 * inv_count);
-    bstat[H + c] = (float)(s2 * inv_count);
-    gbeta[c] = (float)s1;
-    ggamma[c] = (float)s2;
+  __syncthreads();
+  if (threadIdx.x < 8 && ch < H) {
+    const double s1 = fin[threadIdx.x], s2 = fin[8 + threadIdx.x];
+    if constexpr (BWD) {
+      stat[ch] = (float)(s1 * inv_count);           // bstat
+      stat[H + ch] = (float)(s2 * inv_count);
+      gbeta[ch] = (float)s1;
+      ggamma[ch] = (float)s2;
+    } else {
+      const double mean = s1 * inv_count;
+      double var = s2 * inv_count - mean * mean;   // biased variance, exact sums in fp64
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + eps));
+      const float scale = gamma[ch] * rstd;
+      stat[ch] = (float)mean;
+      stat[H + ch] = rstd;
+      stat[2 * H + ch] = scale;
+      stat[3 * H + ch] = beta[ch] - (float)mean * scale;
+    }
   }
 }
 
@@ -693,11 +691,8 @@ extern "C" int gnm_bn_finalize(const double* partials, int nblk, int64_t count, 
   GNM_CHECK_ARG(partials && nblk > 0 && nblk <= kMaxPartialBlocks && count > 0 && H > 0 && H <= 256 && gamma &&
                     beta && stat, "bn_finalize: bad argument");
   double* sums = const_cast<double*>(partials) + (size_t)kMaxPartialBlocks * 2 * 256;
-  hipLaunchKernelGGL(reduce_rows_f64_k, dim3((2 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream,
-                     partials, nblk, 2 * H, sums);
-  GNM_LAUNCH_CHECK("bn_finalize reduce");
-  hipLaunchKernelGGL(bn_finalize_k, dim3(1), dim3(256), 0, (hipStream_t)stream, sums,
-                     1.0 / (double)count, H, gamma, beta, (double)eps, stat);
+  hipLaunchKernelGGL(bn_reduce_finalize_k<false>, dim3((H + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, nblk, H,
+                     1.0 / (double)count, gamma, beta, (double)eps, sums, stat, (float*)nullptr, (float*)nullptr);
   GNM_LAUNCH_CHECK("bn_finalize");
   return 0;
 }
@@ -707,11 +702,8 @@ extern "C" int gnm_bn_bwd_finalize(const double* partials, int nblk, int64_t cou
   GNM_CHECK_ARG(partials && nblk > 0 && nblk <= kMaxPartialBlocks && count > 0 && H > 0 && H <= 256 && bstat &&
                     ggamma && gbeta, "bn_bwd_finalize: bad argument");
   double* sums = const_cast<double*>(partials) + (size_t)kMaxPartialBlocks * 2 * 256;
-  hipLaunchKernelGGL(reduce_rows_f64_k, dim3((2 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream,
-                     partials, nblk, 2 * H, sums);
-  GNM_LAUNCH_CHECK("bn_bwd_finalize reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(1), dim3(256), 0, (hipStream_t)stream, sums,
-                     1.0 / (double)count, H, bstat, ggamma, gbeta);
+  hipLaunchKernelGGL(bn_reduce_finalize_k<true>, dim3((H + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, nblk, H,
+                     1.0 / (double)count, (const float*)nullptr, (const float*)nullptr, 0.0, sums, bstat, ggamma, gbeta);
   GNM_LAUNCH_CHECK("bn_bwd_finalize");
   return 0;
 }
