@@ -65,6 +65,8 @@ class Options:
             raise _lib.GnmError(f"engine.options: unknown switch {bad}; known: {_OPTION_NAMES}")
         if "ACTIVATIONS" in kw and kw["ACTIVATIONS"] not in ("saved", "lean"):
             raise _lib.GnmError(f"activation mode {kw['ACTIVATIONS']!r}: expected 'saved' or 'lean'")
+        if "TN_AT" in kw and kw["TN_AT"] not in ("now", "next", "auto"):
+            raise _lib.GnmError(f"TN_AT {kw['TN_AT']!r}: expected 'now', 'next' or 'auto'")
         d = {k: getattr(self, k) for k in _OPTION_NAMES}
         d.update(kw)
         return Options(**d)

@@ -278,6 +278,16 @@ def test_schedule_switches_are_an_options_object_scoped_to_the_thread_and_kept_w
         base.replace(NO_SUCH_SWITCH=1)
     with pytest.raises(_lib.GnmError):
         base.replace(ACTIVATIONS="half")
+    with pytest.raises(_lib.GnmError):
+        base.replace(TN_AT="later")
+    # TN_AT = "auto" (the default): where the deferred weight-gradient launch goes is decided by graph size (engine.tn_at)
+    with engine.options(TN_AT="auto"):
+        assert engine.tn_at(engine.TN_AT_NOW_NODES) == "now" and engine.tn_at(engine.TN_AT_NOW_NODES - 1) == "next"
+        assert engine.tn_at(1_500_000) == "now" and engine.tn_at(220_000) == "next"       # the metric's graph / the true chr19 size
+    with engine.options(TN_AT="next"):
+        assert engine.tn_at(1_500_000) == "next"
+    with engine.options(TN_AT="now"):
+        assert engine.tn_at(1000) == "now"
     seen = []
     with engine.options(CHAIN=not base.CHAIN, TN_AT="next") as o:
         assert engine.current() is o and engine.CHAIN == (not base.CHAIN) and o.TN_AT == "next"
