@@ -36,6 +36,13 @@ import json,sys;b=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$
     ab "round-4 schedule and matmul mode (bf16x3, NODE_FUSED=0, TN_AT=next)" GNM_MATMUL=bf16x3 GNM_NODE_FUSED=0 GNM_TN_AT=next
   done
   python tools/matmul_accuracy.py > $O/f16x2_accuracy.log 2>&1; cp gpurun_out/f16x2_accuracy.txt $O/ 2>/dev/null
+  # the schedule by graph size (engine.TN_AT = auto) and kernel tables of the other shapes
+  for R in 110000 375000 750000; do echo "R=$R"; tools/ab_env.sh GNM_TN_AT=now GNM_TN_AT=next 2 --reads $R; done > $O/ab_tn_at_sizes.txt 2>&1
+  tools/ab_minibatch_env.sh GNM_TN_AT=now GNM_TN_AT=next GNM_TN_AT=auto >> $O/ab_tn_at_sizes.txt 2>&1
+  HEAD=45 tools/kernel_stats.sh h256 python $GRAFT_REPO_ROOT/bench.py --hidden 256 --reads 375000 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-matmul --no-alt-orders > /dev/null 2>&1
+  cp $(find gpurun_out/prof_h256 -name "*kernel_stats.csv" | head -1) $O/h256_kernel_stats.csv
+  HEAD=45 tools/kernel_stats.sh r110k python $GRAFT_REPO_ROOT/bench.py --reads 110000 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-matmul --no-alt-orders > /dev/null 2>&1
+  cp $(find gpurun_out/prof_r110k -name "*kernel_stats.csv" | head -1) $O/r110k_kernel_stats.csv
   python tools/power_per_op.py > $O/power_per_op.log 2>&1; cp gpurun_out/power_per_op.txt $O/ 2>/dev/null
   rm -f gpurun_out/power_probe.txt
   python tools/power_probe.py train 10 > /dev/null 2>&1; python tools/power_probe.py forward 6 > /dev/null 2>&1
