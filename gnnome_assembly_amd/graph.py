@@ -353,30 +353,84 @@ def from_dgl(g):
 
 
 _WRAPPED = {}      # id(foreign graph) -> AssemblyGraph, for graph objects that refuse new attributes (dropped by a weakref finalizer)
-# Wrappers by CONTENT.  The reference's loops call g = g.to(device) on every step (train.py:244,297; inference.py:446), and DGL
+# Structure by CONTENT.  The reference's loops call g = g.to(device) on every step (train.py:244,297; inference.py:446), and DGL
 # returns a NEW graph object each time: a cache on the object alone would rebuild the host index, the locality order and both
 # sweep plans (~1.5 s for a chr19-scale graph) per step.  A foreign graph is therefore also looked up by a fingerprint of its edge
-# list (node / edge counts + two position-weighted 64-bit sums over src and dst: three tiny reductions and one synchronisation);
-# the last GNM_GRAPH_CACHE (default 16) wrappers are kept -- a dataset's graphs, each ~45 bytes per edge of device memory.
-_BY_CONTENT = collections.OrderedDict()
+# list (node / edge counts + two position-weighted 64-bit sums over src and dst: three tiny reductions and one synchronisation).
+# What is cached is the IMMUTABLE part only -- edge list, host index, device indices, sweep plans -- as a feature-less
+# AssemblyGraph; a hit is CONFIRMED by comparing the edge lists element for element (a fingerprint collision must never hand a
+# different graph a stale index) and returns a shallow per-caller copy that carries the caller's own ndata / edata (two live
+# graphs of equal structure never see each other's features).  The cache is bounded by entries (GNM_GRAPH_CACHE, default 16;
+# 0 = off) AND by an estimate of the device bytes the entries pin (GNM_GRAPH_CACHE_BYTES, default 8 GiB: index + two plans are
+# ~64 B per edge); graphs below GNM_GRAPH_CACHE_MIN_EDGES (default 65,536: rebuilding is cheaper than a fingerprint's host
+# synchronisation, and never-repeating graphs -- DGL mini-batch sub-graphs -- are of that kind) are neither fingerprinted nor kept.
+_BY_CONTENT = collections.OrderedDict()      # fingerprint -> (structure-only AssemblyGraph, estimated bytes)
 GRAPH_CACHE = int(os.environ.get("GNM_GRAPH_CACHE", "16"))
+GRAPH_CACHE_BYTES = int(os.environ.get("GNM_GRAPH_CACHE_BYTES", str(8 << 30)))
+GRAPH_CACHE_MIN_EDGES = int(os.environ.get("GNM_GRAPH_CACHE_MIN_EDGES", "65536"))
 
 
-def _fingerprint(g):
+def _edge_tensors(g):
     s, d = g.edges()
     if not (torch.is_tensor(s) and torch.is_tensor(d)):
         s, d = torch.as_tensor(np.asarray(s)), torch.as_tensor(np.asarray(d))
+    return s, d
+
+
+def _fingerprint(g):
+    s, d = _edge_tensors(g)
     w = torch.arange(1, 2 * s.numel() + 1, 2, dtype=torch.int64, device=s.device)       # odd weights: order-sensitive
     h = torch.stack(((s.long() * w).sum(), (d.long() * w).sum()))
     return (int(g.num_nodes()), int(s.numel())) + tuple(int(x) for x in h.cpu())
 
 
+def _same_edges(base: "AssemblyGraph", g) -> bool:
+    """Element-for-element comparison of a cached structure's edge list with a foreign graph's (on the device the foreign edge
+    list lives on when the cached graph has a copy there, else on the host)."""
+    s, d = _edge_tensors(g)
+    if s.numel() != base.num_edges():
+        return False
+    have = base._dev_edges.get(s.device)
+    if have is None and s.device.type != "cpu":
+        have = (torch.from_numpy(base._src).to(s.device), torch.from_numpy(base._dst).to(s.device))
+        base._dev_edges[s.device] = have
+    if have is None:
+        have = (torch.from_numpy(base._src), torch.from_numpy(base._dst))
+    return bool(torch.equal(have[0].to(torch.int64), s.to(torch.int64)) and torch.equal(have[1].to(torch.int64), d.to(torch.int64)))
+
+
+def _caller_view(base: "AssemblyGraph", g, device=None) -> "AssemblyGraph":
+    """A shallow copy of a cached structure (every index / plan dict shared) with the CALLER's feature dicts."""
+    ag = AssemblyGraph.__new__(AssemblyGraph)
+    ag.__dict__.update(base.__dict__)
+    ag.ndata = dict(getattr(g, "ndata", {}))
+    ag.edata = dict(getattr(g, "edata", {}))
+    dev = getattr(g, "device", None)
+    if dev is None:
+        s = g.edges()[0]
+        dev = s.device if torch.is_tensor(s) else None
+    if dev is not None and torch.device(dev).type != "cpu":
+        dev = torch.device(dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        ag.device = dev
+    return ag
+
+
+def _cache_put(key, base: "AssemblyGraph") -> None:
+    nbytes = 64 * base.num_edges() + 16 * base.num_nodes()
+    _BY_CONTENT[key] = (base, nbytes)
+    while len(_BY_CONTENT) > 1 and (len(_BY_CONTENT) > GRAPH_CACHE or sum(b for _, b in _BY_CONTENT.values()) > GRAPH_CACHE_BYTES):
+        _BY_CONTENT.popitem(last=False)
+
+
 def as_assembly_graph(g, device=None):
     """What the modules call on their `graph` argument: an AssemblyGraph is returned as it is; any other object with the
-    DGLGraph surface (edges(), num_nodes()) is wrapped (from_dgl: the index is built then) and the wrapper is cached -- on the
-    object, and by the content of its edge list (see _BY_CONTENT: the reference's per-step g.to(device) makes a new object every
-    time) -- so the reference's call sites -- model(g, x, e, pe) with a DGLGraph, train.py:252 -- need only the import change.
-    `device`: where the features of this call live (a foreign graph may not carry a device)."""
+    DGLGraph surface (edges(), num_nodes()) is wrapped (from_dgl: the index is built then) and the wrapper is cached on the
+    object; its STRUCTURE is also cached by the content of its edge list (see _BY_CONTENT: the reference's per-step
+    g.to(device) makes a new object every time) -- so the reference's call sites -- model(g, x, e, pe) with a DGLGraph,
+    train.py:252 -- need only the import change.  `device`: where the features of this call live (a foreign graph may not
+    carry a device)."""
     if isinstance(g, AssemblyGraph):
         return g
     ag = getattr(g, "_gnm_graph", None) or _WRAPPED.get(id(g))
@@ -385,19 +439,22 @@ def as_assembly_graph(g, device=None):
     if ag is None:
         if not (hasattr(g, "edges") and hasattr(g, "num_nodes")):
             raise TypeError(f"graph argument of type {type(g).__name__} has no edges() / num_nodes()")
-        key = _fingerprint(g) if GRAPH_CACHE > 0 else None
-        ag = _BY_CONTENT.get(key) if key is not None else None
-        if ag is None:
+        cached = GRAPH_CACHE > 0 and int(g.num_edges()) >= GRAPH_CACHE_MIN_EDGES
+        key = _fingerprint(g) if cached else None
+        hit = _BY_CONTENT.get(key) if key is not None else None
+        if hit is not None and not _same_edges(hit[0], g):
+            hit = None              # a fingerprint collision: another graph (the entry is replaced below)
+        if hit is None:
             ag = from_dgl(g)
             if key is not None:
-                _BY_CONTENT[key] = ag
-                while len(_BY_CONTENT) > GRAPH_CACHE:
-                    _BY_CONTENT.popitem(last=False)
+                ag.host_index()     # built now (the first forward needs it anyway), so that every later view shares it
+                base = AssemblyGraph.__new__(AssemblyGraph)         # the structure without anybody's features
+                base.__dict__.update(ag.__dict__)
+                base.ndata, base.edata = {}, {}
+                _cache_put(key, base)
         else:
             _BY_CONTENT.move_to_end(key)
-            # same structure, possibly other feature tensors: the wrapper shows the caller's current ndata / edata
-            ag.ndata = dict(getattr(g, "ndata", {}))
-            ag.edata = dict(getattr(g, "edata", {}))
+            ag = _caller_view(hit[0], g)
         _remember(g, ag)
     if device is not None and torch.device(device) != ag.device:
         ag = ag.to(device)

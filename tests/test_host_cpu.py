@@ -224,33 +224,75 @@ def test_from_dgl_and_foreign_graph_wrapping():
     with pytest.raises(TypeError):
         as_assembly_graph(object())
     # the reference's loops do g = g.to(device) every step (train.py:244,297): DGL hands back a NEW object each time -- the
-    # wrapper (host index, locality order, sweep plans) must be found again by the content of the edge list, not rebuilt
-    dg2 = dgl.DGLGraph(s.copy(), d.copy(), n)
-    dg2.edata["y"] = torch.zeros(s.size)
-    w2 = as_assembly_graph(dg2)
-    assert w2 is w1 and torch.equal(w2.edata["y"], dg2.edata["y"]), "same edge list: same wrapper, the caller's current features"
-    p = np.random.default_rng(0).permutation(s.size)
-    w3 = as_assembly_graph(dgl.DGLGraph(s[p], d[p], n))
-    assert w3 is not w1, "another edge-id order is another graph"
-    # an object that takes no attributes and no weak references is wrapped but never cached by id (ids are reused)
-
-    class Frozen:
-        __slots__ = ("s", "d", "n")
-
-        def __init__(self, s_, d_, n_):
-            self.s, self.d, self.n = s_, d_, n_
-
-        def edges(self):
-            return torch.from_numpy(self.s), torch.from_numpy(self.d)
-
-        def num_nodes(self):
-            return self.n
-
-        def num_edges(self):
-            return self.s.size
+    # STRUCTURE (host index, locality order, sweep plans) must be found again by the content of the edge list, not rebuilt;
+    # the features are the caller's own: two live graphs of equal structure never see each other's ndata / edata
     from gnnome_assembly_amd import graph as gmod
-    fz = Frozen(s, d, n)
-    assert as_assembly_graph(fz) is w1 and id(fz) not in gmod._WRAPPED
+    old = gmod.GRAPH_CACHE_MIN_EDGES
+    gmod.GRAPH_CACHE_MIN_EDGES = 0            # the tiny test graph would otherwise be below the caching threshold
+    gmod._BY_CONTENT.clear()
+    try:
+        dgA = dgl.DGLGraph(s.copy(), d.copy(), n)
+        dgA.edata["y"] = torch.full((s.size,), 7.0)
+        wA = as_assembly_graph(dgA)
+        dg2 = dgl.DGLGraph(s.copy(), d.copy(), n)
+        dg2.edata["y"] = torch.zeros(s.size)
+        w2 = as_assembly_graph(dg2)
+        assert w2 is not wA and w2._dev_index is wA._dev_index and w2._plans is wA._plans, "same edge list: shared structure"
+        assert w2.host_index() is wA.host_index()
+        assert torch.equal(w2.edata["y"], dg2.edata["y"]) and torch.equal(wA.edata["y"], dgA.edata["y"]), \
+            "each wrapper carries its own caller's features"
+        assert len(gmod._BY_CONTENT) == 1 and not next(iter(gmod._BY_CONTENT.values()))[0].edata, "the cache keeps no features"
+        p = np.random.default_rng(0).permutation(s.size)
+        w3 = as_assembly_graph(dgl.DGLGraph(s[p], d[p], n))
+        assert w3._dev_index is not wA._dev_index, "another edge-id order is another graph"
+        # a fingerprint collision must not hand a different graph a stale index: force one
+        real = gmod._fingerprint
+        gmod._fingerprint = lambda g: (0, 0, 0, 0)
+        try:
+            gmod._BY_CONTENT.clear()
+            c1 = as_assembly_graph(dgl.DGLGraph(s.copy(), d.copy(), n))
+            c2 = as_assembly_graph(dgl.DGLGraph(s[p], d[p], n))
+            assert c2._dev_index is not c1._dev_index
+            assert np.array_equal(c2.edges()[0].numpy(), s[p]) and np.array_equal(c2.host_index()["perm"],
+                                                                                   G.AssemblyGraph(s[p], d[p], n).host_index()["perm"])
+        finally:
+            gmod._fingerprint = real
+        # bounded by bytes as well as by entries
+        gmod._BY_CONTENT.clear()
+        oldb = gmod.GRAPH_CACHE_BYTES
+        gmod.GRAPH_CACHE_BYTES = 1
+        try:
+            as_assembly_graph(dgl.DGLGraph(s.copy(), d.copy(), n))
+            as_assembly_graph(dgl.DGLGraph(s[p], d[p], n))
+            assert len(gmod._BY_CONTENT) == 1
+        finally:
+            gmod.GRAPH_CACHE_BYTES = oldb
+        # an object that takes no attributes and no weak references is wrapped but never cached by id (ids are reused)
+
+        class Frozen:
+            __slots__ = ("s", "d", "n")
+
+            def __init__(self, s_, d_, n_):
+                self.s, self.d, self.n = s_, d_, n_
+
+            def edges(self):
+                return torch.from_numpy(self.s), torch.from_numpy(self.d)
+
+            def num_nodes(self):
+                return self.n
+
+            def num_edges(self):
+                return self.s.size
+        gmod._BY_CONTENT.clear()
+        w0 = as_assembly_graph(dgl.DGLGraph(s.copy(), d.copy(), n))
+        fz = Frozen(s, d, n)
+        assert as_assembly_graph(fz)._dev_index is w0._dev_index and id(fz) not in gmod._WRAPPED
+    finally:
+        gmod.GRAPH_CACHE_MIN_EDGES = old
+        gmod._BY_CONTENT.clear()
+    # below the threshold a foreign graph is neither fingerprinted nor kept (rebuilding is cheaper than the synchronisation)
+    as_assembly_graph(dgl.DGLGraph(s.copy(), d.copy(), n))
+    assert len(gmod._BY_CONTENT) == 0
 
 
 def test_no_undefined_names_in_the_package():
