@@ -49,9 +49,17 @@ def init_process_group(backend: str | None = None):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    if backend == "nccl" and "GNM_BENCH_DEVICE" not in os.environ:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
-    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    kw = {}
+    if backend == "nccl":
+        if "GNM_BENCH_DEVICE" not in os.environ:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        # bind the communicator to this rank's device up front: barrier() and the first collective then need not GUESS the
+        # device from the rank (torch warns about that guess and, on a node whose ranks are not device-ordered, gets it wrong)
+        kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+    try:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    except TypeError:           # a torch without the device_id keyword
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 
 
@@ -128,12 +136,26 @@ def make_adam(params, lr: float):
     ("foreach") implementation costs ~1 ms of host time per step for this model's 138 tensors -- invisible when the host runs
     steps ahead of the device (full-graph training), 5 % of a 21 ms mini-batch step (profiles/r04_minibatch_breakdown.txt)."""
     params = list(params)
+    opt, impl = None, "default"
     if params and all(p.is_cuda for p in params):
         try:
-            return torch.optim.Adam(params, lr=lr, fused=True)
-        except (RuntimeError, TypeError, ValueError):
-            pass
-    return torch.optim.Adam(params, lr=lr)
+            opt, impl = torch.optim.Adam(params, lr=lr, fused=True), "fused"
+        except (RuntimeError, TypeError, ValueError) as ex:
+            import warnings
+            warnings.warn(f"dp.make_adam: fused Adam is not available here ({ex}); using the default implementation")
+    if opt is None:
+        opt = torch.optim.Adam(params, lr=lr)
+    opt.gnm_impl = impl
+    # replicas must not drift apart through different optimizer arithmetic: every rank has to have made the same choice
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dev = params[0].device if params else None
+        t = torch.tensor([1.0 if impl == "fused" else 0.0], device=dev if dist.get_backend() == "nccl" else None)
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(lo) != float(hi):
+            raise RuntimeError("dp.make_adam: the ranks chose different Adam implementations (fused on some, default on others)")
+    return opt
 
 
 def steps_per_epoch(local_steps: int, device=None) -> int:

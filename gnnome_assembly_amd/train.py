@@ -118,7 +118,9 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
     (dp.shard_graphs; a shard may be empty for validation): the W graphs of a step contribute the mean of their
     gradients, epoch / validation losses and TP..FN counts are summed over the ranks, rank 0 writes the files.
     `hooks` (observers for tests and logging, never needed for training): "after_exchange"(epoch, it, flat) right
-    after the gradient exchange of a full-graph step, "after_epoch"(epoch, model) at the end of every epoch."""
+    after the gradient exchange of a full-graph step, "after_epoch"(epoch, model) at the end of every epoch;
+    "model_factory"(hp) -> nn.Module and "criterion_factory"(pos_weight) -> loss module replace the HIP model / loss (the
+    CPU tier drives THIS loop under eight gloo ranks with a CPU stand-in model: tests/test_dp_gloo.py)."""
     hooks = hooks or {}
     hp = dict(get_hyperparameters())
     hp.update(hyperparameters or {})
@@ -133,17 +135,21 @@ def train(train_samples: Sequence[GraphSample], valid_samples: Sequence[GraphSam
         t = torch.tensor([ratio * len(train_samples), float(len(train_samples))], device=dev, dtype=torch.float64)
         dist.all_reduce(t)
         ratio = float(t[0] / t[1])
-    model = models.GraphGatedGCNModel(hp["node_features"], hp["edge_features"], hp["dim_latent"],
-                                      hp["hidden_edge_features"], hp["num_gnn_layers"], hp["hidden_edge_scores"],
-                                      hp["batch_norm"], hp["nb_pos_enc"]).to(dev)                # train.py:195-198
+    if "model_factory" in hooks:
+        model = hooks["model_factory"](hp).to(dev)
+    else:
+        model = models.GraphGatedGCNModel(hp["node_features"], hp["edge_features"], hp["dim_latent"],
+                                          hp["hidden_edge_features"], hp["num_gnn_layers"], hp["hidden_edge_scores"],
+                                          hp["batch_norm"], hp["nb_pos_enc"]).to(dev)            # train.py:195-198
     if world > 1:
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     best_state = copy.deepcopy(model.state_dict())                                              # train.py:203
-    model.flatten_parameters()
+    models.flatten_parameters(model)
     flat = dp.FlatGradients(model.parameters(), direct_write=True)       # the loop below zero_()s before every backward
     optimizer = dp.make_adam(model.parameters(), hp["lr"])                               # train.py:209
-    criterion = models.BCEWithLogitsLoss(pos_weight=1.0 / ratio)                                # train.py:210-211
+    criterion = (hooks["criterion_factory"](1.0 / ratio) if "criterion_factory" in hooks
+                 else models.BCEWithLogitsLoss(pos_weight=1.0 / ratio))                         # train.py:210-211
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=hp["decay"],
                                                            patience=hp["patience"])             # train.py:212
     hist = History()
