@@ -21,6 +21,12 @@ def load_case(fname):
     return z, sd, H, L, bool(z["batch_norm"])
 
 
+def grad_stride_of(z, H):
+    """Sampling stride of a fixture's grad/* and adam/* arrays (make_golden.py: every grad_stride-th element for the large models)."""
+    sampled = H == 128 or ("grad_sampled" in z.files and bool(z["grad_sampled"]))
+    return int(z["grad_stride"]) if sampled else 1
+
+
 def sd_to_torch(sd, dtype=torch.float32, requires_grad=False):
     return {k: torch.from_numpy(np.asarray(v)).to(dtype).clone().requires_grad_(requires_grad)
             for k, v in sd.items()}

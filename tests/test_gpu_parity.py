@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import golden_files
-from helpers import GOLDEN, load_case, sd_to_torch, rel_l2, assert_parity, tally_clause, RTOL, ATOL
+from helpers import GOLDEN, load_case, grad_stride_of, sd_to_torch, rel_l2, assert_parity, tally_clause, RTOL, ATOL
 
 pytestmark = pytest.mark.gpu
 
@@ -313,7 +313,7 @@ def test_model_matches_golden(fname):
     ours = rel_l2(scores.detach().cpu().numpy(), z["scores64"])
     print(f"{fname}: logits rel_l2 ours={ours:.2e} reference-fp32={ref_noise:.2e}")
     assert abs(loss.item() - float(z["loss64"])) <= 1e-5 * max(1.0, abs(float(z["loss64"])))
-    stride = int(z["grad_stride"]) if H == 128 else 1
+    stride = grad_stride_of(z, H)
     g32 = None if bn else _oracle_grads(z, sd, torch.float32, bn)  # LayerNorm only: the reference arithmetic in fp32 (noise level)
     rows, bad = [], []
     gmax = max(float(np.linalg.norm(z["grad/" + k])) for k, _ in model.named_parameters())

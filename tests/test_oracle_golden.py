@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import golden_files
-from helpers import load_case, sd_to_torch, rel_l2
+from helpers import load_case, grad_stride_of, sd_to_torch, rel_l2
 from oracle import gatedgcn_oracle as orc
 
 
@@ -42,7 +42,7 @@ def test_autograd_grads_and_adam_match_reference(fname):
     p = sd_to_torch(sd, torch.float64, requires_grad=True)
     loss = orc.bce_loss(orc.model_forward(p, src, dst, n, e_raw, pe, bn), y, pw)
     loss.backward()
-    stride = int(z["grad_stride"]) if H == 128 else 1
+    stride = grad_stride_of(z, H)
     grads = {k: v.grad for k, v in p.items()}
     for k in p:
         got = grads[k].numpy().reshape(-1)[::stride]
