@@ -392,6 +392,7 @@ class LayerSaved:
     z: torch.Tensor = None
     stat_h: torch.Tensor = None
     opts: "Options" = None       # the switches the forward ran under: its backward runs under the same (see Options)
+    chunks: list = None          # a layer wider than 256: the saved state of its 256-column problems (see WIDE_CHUNK)
 
 
 def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
@@ -442,15 +443,23 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     lnw = H if ln_width is None else int(ln_width)
     if residual and h_in.shape[1] != H:
         raise _lib.GnmError("layer_forward: a residual layer needs in_channels == out_channels")
+    if H > WIDE_CHUNK:
+        return _wide_layer_forward(idx, N, E, H, prm, h_in, e_in, save, batch_norm, residual, plan)
+    nblk = C.c_int(0)
+    P, t = _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk)
+    return _layer_forward_tail(idx, N, E, H, prm, h_in, e_in, P, t, nblk, save, batch_norm, residual, plan, lnw)
+
+
+def _layer_forward_tail(idx, N, E, H, prm, h_in, e_in, P, t, nblk, save, batch_norm, residual, plan, lnw):
+    """layer_forward behind the two dense products: everything from the gate to h_out.  With BatchNorm this part is separable by
+    COLUMNS (per-channel statistics, per-channel gates): a layer wider than the kernels runs it once per 256-column chunk."""
     res_e = _ptr(e_in) if residual else C.c_void_p(0)
     res_h = _ptr(h_in) if residual else C.c_void_p(0)
     lib = _lib.load()
     dev = h_in.device
     sc = scratch(dev)
     st = _stream()
-    nblk = C.c_int(0)
     f32 = dict(dtype=torch.float32, device=dev)
-    P, t = _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk)
     # gate, edge output, by-destination gated mean                         (:122-130)
     e_out = torch.empty(E, H, **f32)
     hf = torch.empty(N, H, **f32)
@@ -506,6 +515,157 @@ def layer_forward(idx, N: int, E: int, H: int, prm: LayerParams, h_in, e_in, sav
     return h_out, e_out, saved
 
 
+# A layer wider than the widest kernel instantiation (gated_gcn_full.py:44-50 takes any nn.Linear width): the two dense products
+# run at full width on the generic GEMM route, everything between them -- BatchNorm statistics, gate, both aggregations, node
+# update, and the duals of all of it -- is separable by columns and runs once per WIDE_CHUNK-column problem on contiguous copies
+# of the chunk (strided copies in and out: slow by construction, but a legal width no longer raises).  BatchNorm only: LayerNorm's
+# row statistics span the chunks.
+WIDE_CHUNK = 256
+
+
+def _cols(x: torch.Tensor, c0: int, w: int, blocks: int = 1) -> torch.Tensor:
+    """Columns c0 .. c0+w of each of the `blocks` equal blocks of x's rows, as a contiguous [rows, blocks*w] tensor."""
+    R, Hb = x.shape[0], x.shape[1] // blocks
+    return x.view(R, blocks, Hb)[:, :, c0:c0 + w].reshape(R, blocks * w).contiguous()
+
+
+def _put_cols(dst: torch.Tensor, src: torch.Tensor, c0: int, w: int, blocks: int = 1) -> None:
+    R, Hb = dst.shape[0], dst.shape[1] // blocks
+    dst.view(R, blocks, Hb)[:, :, c0:c0 + w] = src.view(R, blocks, w)
+
+
+def _chunk_params(prm: LayerParams, c0: int, w: int) -> LayerParams:
+    """The per-channel parameters of one column chunk (the weights are not read behind the dense products)."""
+    sl = slice(c0, c0 + w)
+    return LayerParams(W5=None, b5=None, W3=None, b3=None, gamma_e=prm.gamma_e[sl], beta_e=prm.beta_e[sl],
+                       gamma_h=prm.gamma_h[sl], beta_h=prm.beta_h[sl])
+
+
+def _wide_layer_forward(idx, N, E, H, prm, h_in, e_in, save, batch_norm, residual, plan):
+    if not batch_norm:
+        raise NotImplementedError(f"GatedGCN_1d with LayerNorm at width {H}: the LayerNorm kernels hold a row in one wavefront "
+                                  f"(widths up to {WIDE_CHUNK}); BatchNorm layers run at any width")
+    if H % WIDE_CHUNK:
+        raise _lib.GnmError(f"layer_forward: a wide layer runs zero-padded to a multiple of {WIDE_CHUNK} (layers.padded_width), got {H}")
+    dev = h_in.device
+    sc = scratch(dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    P = torch.empty(N, 5 * H, **f32)
+    t = torch.empty(E, H, **f32)
+    gemm(NT, h_in, prm.W5, P, bias=prm.b5)                                      # (:107-112)
+    gemm(NT, e_in, prm.W3, t, bias=prm.b3)                                      # (:113)
+    h_out, e_out = torch.empty(N, H, **f32), torch.empty(E, H, **f32)
+    chunks = []
+    w = WIDE_CHUNK
+    for c0 in range(0, H, w):
+        Pc, tc = _cols(P, c0, w, 5), _cols(t, c0, w)
+        hc = _cols(h_in, c0, w) if residual else h_in
+        ec = _cols(e_in, c0, w) if residual else e_in
+        nblk = C.c_int(0)
+        _call("gnm_edge_t_stats_fwd", E, w, _ptr(tc), _ptr(Pc), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(sc.partials), C.byref(nblk),
+              _stream())
+        ho, eo, sv = _layer_forward_tail(idx, N, E, w, _chunk_params(prm, c0, w), hc, ec, Pc, tc, nblk, save, True, residual, plan, w)
+        _put_cols(h_out, ho, c0, w)
+        _put_cols(e_out, eo, c0, w)
+        if save:
+            sv.h_in = sv.e_in = None            # the full-width inputs are kept once, below
+            chunks.append(sv)
+    saved = LayerSaved(opts=current(), h_in=h_in, e_in=e_in, chunks=chunks) if save else None
+    return h_out, e_out, saved
+
+
+def _wide_layer_backward(idx, N, E, H, prm, s: LayerSaved, gh_out, ge, out, residual, plan):
+    dev = gh_out.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    Hin = s.h_in.shape[1]
+    w = WIDE_CHUNK
+    new = lambda key, *shape: out[key] if key in out else torch.empty(*shape, **f32)  # noqa: E731
+    g: Dict[str, torch.Tensor] = {k: new(k, H) for k in ("gamma_e", "beta_e", "gamma_h", "beta_h")}
+    gP = torch.empty(N, 5 * H, **f32)
+    gt = torch.empty(E, H, **f32)
+    ge_tot = ge if residual else None           # the residual path adds the incoming edge gradient: updated in place, chunk by chunk
+    for ci, c0 in enumerate(range(0, H, w)):
+        sl = slice(c0, c0 + w)
+        sc_ = s.chunks[ci]
+        outc = {k: g[k][sl] for k in g}
+        gec = _cols(ge, c0, w)
+        gPc, gec, bstat_e, _ = _bn_backward_mid(idx, N, E, w, _chunk_params(prm, c0, w), sc_, _cols(gh_out, c0, w), gec, outc, plan)
+        gtc = torch.empty(E, w, **f32)
+        _call("gnm_edge_bwd_gt", E, w, _ptr(gec), _ptr(sc_.t), _ptr(sc_.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e[sl]), _ptr(gtc), _stream())
+        _put_cols(gP, gPc, c0, w, 5)
+        _put_cols(gt, gtc, c0, w)
+        if residual:
+            _put_cols(ge_tot, gec, c0, w)
+        s.chunks[ci] = None
+    g["W3"] = new("W3", H, Hin)
+    g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
+    if residual:
+        gemm(NN, gt, prm.W3, ge_tot, resid=ge_tot)
+        ge_in = ge_tot
+    else:
+        ge_in = gemm(NN, gt, prm.W3, torch.empty(E, Hin, **f32))
+    del gt
+    g["W5"] = new("W5", 5 * H, Hin)
+    g["b5"] = gemm_tn_colsum(gP, s.h_in, g["W5"], out.get("b5"))
+    gh_in = torch.empty(N, Hin, **f32)
+    gemm(NN, gP, prm.W5, gh_in, resid=gh_out if residual else None)
+    return gh_in, ge_in, g
+
+
+def _bn_backward_mid(idx, N, E, H, prm, s, gh_out, ge, out, plan):
+    """The BatchNorm layer backward between the dense products (column-separable like _layer_forward_tail): BatchNorm_h backward,
+    the by-destination and by-source passes.  `ge` ([E,H]) is updated in place to ge_tot = ge + gsigma sigma'.  Returns
+    (gP [N,5H], ge, bstat_e, {gamma_h, beta_h, gamma_e, beta_e gradients})."""
+    lib = _lib.load()
+    dev = gh_out.device
+    sc = scratch(dev)
+    st = _stream()
+    nblk = C.c_int(0)
+    f32 = dict(dtype=torch.float32, device=dev)
+    g: Dict[str, torch.Tensor] = {}
+    gP = torch.empty(N, 5 * H, **f32)
+    Q = torch.empty(N, 2 * H, **f32)     # Qf | Qb
+    # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
+    _call("gnm_node_bwd_stats", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
+          C.byref(nblk), st)
+    bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
+    _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
+          _ptr(gh_out), _ptr(s.inv_f), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
+    if plan is not None and H in (128, 256) and current().TWO_SIDED:
+        # the two-sided sweep of the chained schedule's top layer (H = 256: once per 128-column half, row pitch 256; H = 128:
+        # the fp32-MFMA matmul mode, whose edge backward is not chained): by-destination AND by-source sums from one pass over
+        # ge, e_out, t; then the unserved sources and the conversion through m1, m2
+        UT = torch.empty(N, 2 * H, **f32)
+        DT = torch.empty(N, 2 * H, **f32)
+        Ud, Td = DT[:, :H], DT[:, H:]
+        need_f = lib.gnm_edge_bwd_fused_workspace_bytes()
+        ws = sc.ws(need_f)
+        _call("gnm_edge_bwd_top", N, E, H, _ptr(ge), _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(s.P), _ptr(Q), _ptr(s.hf),
+              _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+              _ptr(sc.partials), _ptr(plan["sinfo"]), plan["nodes_per_block"], _ptr(UT), C.byref(nblk), _ptr(ws), need_f, st)
+        _call("gnm_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s.e_out), _ptr(s.t),
+              _ptr(s.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
+              _ptr(gP), _ptr(UT), st)
+        bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
+        _call("gnm_node_bgrad", N, H, _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(idx["in_ptr"]),
+              _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), Ud.stride(0), _ptr(gP), st)
+        del UT, DT
+    else:
+        # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
+        Ud = torch.empty(N, H, **f32)
+        Td = torch.empty(N, H, **f32)
+        _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
+              _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
+              _ptr(sc.partials), C.byref(nblk), st)
+        bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
+        # by-source pass: gA2h, gB1h, gB2h
+        _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
+              _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
+              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), 0, st)
+    del Ud, Td, Q
+    return gP, ge, bstat_e, g
+
+
 @on_device_of(lambda idx, N, E, H, prm, s, gh_out, *a, **k: gh_out)
 @_scoped(5)
 def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True,
@@ -528,12 +688,14 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     nblk = C.c_int(0)
     f32 = dict(dtype=torch.float32, device=dev)
     g: Dict[str, torch.Tensor] = {}
+    if s.chunks is not None:
+        return _wide_layer_backward(idx, N, E, H, prm, s, gh_out, ge, out, residual, plan)
     if s.P is None or s.t is None:      # "lean" activations: rebuild P and t with the kernels that made them
         s.P, s.t = _proj_and_t(idx, N, E, H, prm, s.h_in, s.e_in, C.c_int(0))
-    gP = torch.empty(N, 5 * H, **f32)
-    Q = torch.empty(N, (2 if batch_norm else 4) * H, **f32)     # BatchNorm mode: Qf | Qb; LayerNorm mode keeps Rf, Rb too
     g["W3"] = new("W3", H, Hin)
     if not batch_norm:
+        gP = torch.empty(N, 5 * H, **f32)
+        Q = torch.empty(N, 4 * H, **f32)     # LayerNorm mode: Qf | Qb | Rf | Rb
         # ---- LayerNorm mode: no global barriers, gt is produced by the by-destination pass ----
         _call("gnm_ln_node_bwd", N, H, _ptr(s.z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(gh_out), _ptr(s.hf),
               _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), _ptr(sc.partials), C.byref(nblk), lnw, st)
@@ -553,44 +715,8 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             ge = gemm(NN, gt, prm.W3, torch.empty(E, Hin, **f32))
         del gt
     else:
-        # BatchNorm_h backward statistics, then gz and the per-node gate-gradient factors
-        _call("gnm_node_bwd_stats", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(gh_out), _ptr(sc.partials),
-              C.byref(nblk), st)
-        bstat_h, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
-        _call("gnm_node_bwd_apply", N, H, _ptr(s.z), _ptr(s.stat_h), _ptr(bstat_h), _ptr(prm.gamma_h),
-              _ptr(gh_out), _ptr(s.inv_f), _ptr(s.inv_b), _ptr(gP), _ptr(Q), st)
-        if plan is not None and H in (128, 256) and current().TWO_SIDED:
-            # the two-sided sweep of the chained schedule's top layer (H = 256: once per 128-column half, row pitch 256; H = 128:
-            # the fp32-MFMA matmul mode, whose edge backward is not chained): by-destination AND by-source sums from one pass over
-            # ge, e_out, t; then the unserved sources and the conversion through m1, m2
-            UT = torch.empty(N, 2 * H, **f32)
-            DT = torch.empty(N, 2 * H, **f32)
-            Ud, Td = DT[:, :H], DT[:, H:]
-            need_f = lib.gnm_edge_bwd_fused_workspace_bytes()
-            ws = sc.ws(need_f)
-            _call("gnm_edge_bwd_top", N, E, H, _ptr(ge), _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(s.P), _ptr(Q), _ptr(s.hf),
-                  _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
-                  _ptr(sc.partials), _ptr(plan["sinfo"]), plan["nodes_per_block"], _ptr(UT), C.byref(nblk), _ptr(ws), need_f, st)
-            _call("gnm_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s.e_out), _ptr(s.t),
-                  _ptr(s.stat_e), _ptr(ge), _ptr(Q), _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]),
-                  _ptr(gP), _ptr(UT), st)
-            bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
-            _call("gnm_node_bgrad", N, H, _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e), _ptr(idx["in_ptr"]),
-                  _ptr(idx["out_ptr"]), _ptr(UT), _ptr(Ud), _ptr(Td), Ud.stride(0), _ptr(gP), st)
-            del UT, DT
-        else:
-            # by-destination pass: ge <- ge + gsigma*sigma', gA3h, BatchNorm_e backward statistics
-            Ud = torch.empty(N, H, **f32)
-            Td = torch.empty(N, H, **f32)
-            _call("gnm_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(ge), _ptr(s.P),
-                  _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(Ud), _ptr(Td),
-                  _ptr(sc.partials), C.byref(nblk), st)
-            bstat_e, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
-            # by-source pass: gA2h, gB1h, gB2h
-            _call("gnm_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e),
-                  _ptr(prm.gamma_e), _ptr(ge), _ptr(Q), _ptr(idx["in_ptr"]), _ptr(idx["out_ptr"]),
-                  _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(Ud), _ptr(Td), _ptr(gP), 0, st)
-        del Ud, Td, Q
+        gP, ge, bstat_e, gm = _bn_backward_mid(idx, N, E, H, prm, s, gh_out, ge, out, plan)
+        g.update(gm)
         # gt, B_3 gradients, ge_in = ge_tot + gt W3
         if fused:
             g["b3"] = new("b3", H)
@@ -702,6 +828,12 @@ def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, W, b, pa
     else:
         _lib.check(_lib.load().gnm_tn128(N, _ptr(A), lda, ncg, _ptr(h), _ptr(W), _ptr(b), _ptr(partials), _ptr(ws), need,
                                          C.c_void_p(stream.cuda_stream)), "gnm_tn128")
+
+
+def sweep_width(H: int, batch_norm: bool = True) -> bool:
+    """Does a layer of (kernel) width H run the two-sided sweeps?  128; with BatchNorm also 256 (one sweep per 128-column half) and
+    the wide layers (256-column chunks)."""
+    return H == 128 or (batch_norm and (H == 256 or (H > WIDE_CHUNK and H % WIDE_CHUNK == 0)))
 
 
 def chain_eligible(H: int, batch_norm: bool) -> bool:
@@ -1121,8 +1253,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw, opts=current()) if save else None
-    plan2 = graph.sweep_plan(dev, 2) if (current().TWO_SIDED_FWD and (H in (128, 256) if batch_norm else H == 128)
-                                         and hasattr(graph, "sweep_plan")) else None
+    plan2 = graph.sweep_plan(dev, 2) if (current().TWO_SIDED_FWD and sweep_width(H, batch_norm) and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
         h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width)
         if save:
@@ -1173,7 +1304,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     chained = None
     # layer-by-layer backward on the two-sided sweep (the chained schedule's top-layer kernel for every layer): H = 256, and H = 128
     # where the chained schedule does not apply (fp32-MFMA matmul mode, GNM_CHAIN=0)
-    plan_w = graph.sweep_plan(dev) if (H in (128, 256) and batch_norm and current().TWO_SIDED and not chain_eligible(H, batch_norm)
+    plan_w = graph.sweep_plan(dev) if (batch_norm and sweep_width(H) and current().TWO_SIDED and not chain_eligible(H, batch_norm)
                                        and hasattr(graph, "sweep_plan")) else None
     if chain_eligible(H, batch_norm):
         plan = graph.sweep_plan(dev) if current().TWO_SIDED and hasattr(graph, "sweep_plan") else None

@@ -19,11 +19,14 @@ KERNEL_WIDTHS = (32, 64, 128, 256)      # the hidden sizes the row kernels are i
 
 
 def padded_width(width: int) -> int:
-    """The kernel width a layer of `width` output channels runs on: itself, or the next one up with dead channels."""
+    """The kernel width a layer of `width` output channels runs on: itself, or the next one up with dead channels.  Above the widest
+    instantiation a layer runs as 256-column problems between full-width dense products (engine.WIDE_CHUNK: BatchNorm layers; slow
+    by construction, but nn.Linear(in, out) of gated_gcn_full.py:44-50 takes any width and so does this)."""
     for w in KERNEL_WIDTHS:
         if width <= w:
             return w
-    raise NotImplementedError(f"hidden width {width}: the HIP kernels are built for widths up to {KERNEL_WIDTHS[-1]}")
+    c = engine.WIDE_CHUNK
+    return (width + c - 1) // c * c
 
 
 def _params_of(module: nn.Module, prefix: str = ""):
@@ -96,7 +99,9 @@ class GatedGCN_1d(nn.Module):
         super().__init__()
         if not 0 <= dropout < 1:
             raise ValueError(f"GatedGCN_1d: dropout={dropout}")
-        padded_width(out_channels)           # any width up to 256 (gated_gcn_full.py:44-50 takes any): others run zero-padded
+        if not batch_norm and out_channels > KERNEL_WIDTHS[-1]:
+            raise NotImplementedError(f"GatedGCN_1d(batch_norm=False) at width {out_channels}: the LayerNorm kernels hold a row in one "
+                                      f"wavefront (widths up to {KERNEL_WIDTHS[-1]}); BatchNorm layers run at any width")
         self.in_channels, self.out_channels = in_channels, out_channels
         self.dropout = dropout
         self.batch_norm = batch_norm

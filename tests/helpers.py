@@ -75,11 +75,18 @@ def device_masks(ms, sd, e_raw_np, idx):
     inv[perm] = torch.arange(perm.numel())
     nrank = idx["nrank"].long().cpu() if "nrank" in idx else None      # internal node numbering -> the caller's
     u, w = [], []
-    for s in ms.layers:
+
+    def branches(s):
+        if getattr(s, "chunks", None):        # a layer wider than 256: one saved state per 256-column problem (engine.WIDE_CHUNK)
+            uw = [branches(c) for c in s.chunks]
+            return torch.cat([a for a, _ in uw], 1), torch.cat([b for _, b in uw], 1)
         uu = s.t.double() * s.stat_e[2].double() + s.stat_e[3].double()
-        u.append((uu > 0).cpu()[inv])                 # internal order -> edge-id order
         ww = s.z.double() * s.stat_h[2].double() + s.stat_h[3].double()
-        w.append((ww > 0).cpu() if nrank is None else (ww > 0).cpu()[nrank])
+        return (uu > 0).cpu(), (ww > 0).cpu()
+    for s in ms.layers:
+        um, wm = branches(s)
+        u.append(um[inv])                             # internal order -> edge-id order
+        w.append(wm if nrank is None else wm[nrank])
     hid = (ms.pred.hid > 0).cpu()[inv]
     # encoder: ap = fmaf(w1a, x0, fmaf(w1b, x1, b))  (gnm_encoder.hip) -- inner fma rounded to fp32
     W1, b1 = sd["linear1_edge.weight"].astype(np.float64), sd["linear1_edge.bias"].astype(np.float64)

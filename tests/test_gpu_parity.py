@@ -879,11 +879,12 @@ def test_minibatch_mode_counterpart(tmp_path):
     assert (tmp_path / "checkpoints" / "mb.pt").exists()
 
 
-@pytest.mark.parametrize("H,L,bn", [(256, 2, True), (64, 3, False), (128, 2, False), (32, 1, True), (128, 3, True)])
+@pytest.mark.parametrize("H,L,bn", [(256, 2, True), (64, 3, False), (128, 2, False), (32, 1, True), (128, 3, True), (320, 2, True), (512, 1, True)])
 def test_other_widths_and_norms_vs_oracle(H, L, bn):
     """Widths / depths / norm modes without a golden fixture: the HIP path (generic GEMM + row kernels
     for H != 128 or LayerNorm, fused kernels for H = 128 BatchNorm) against the fp64 oracle, with the
-    fp32 oracle as the noise yardstick for the gradients."""
+    fp32 oracle as the noise yardstick for the gradients.  (320, 512: wider than the widest kernel instantiation -- the
+    layers run as 256-column problems between full-width dense products, 320 zero-padded to 512: engine.WIDE_CHUNK.)"""
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import synth
     from oracle import gatedgcn_oracle as orc

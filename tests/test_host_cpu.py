@@ -97,8 +97,9 @@ def test_module_surface_and_state_dict_schema():
     assert G.layers.GatedGCN_1d(32, 32, True, residual=False).residual is False
     assert G.layers.GatedGCN_1d(32, 48, True).B_3.weight.shape == (48, 32)     # any width up to 256 (run zero-padded to 64)
     assert G.layers.padded_width(96) == 128 and G.layers.padded_width(128) == 128
+    assert G.layers.GatedGCN_1d(32, 300, True).B_3.weight.shape == (300, 32)   # wider than the widest kernel: 256-column chunks
     with pytest.raises(NotImplementedError):
-        G.layers.GatedGCN_1d(32, 300, True)                            # wider than the widest kernel instantiation
+        G.layers.GatedGCN_1d(32, 300, False)                           # ... BatchNorm only (LayerNorm rows span the chunks)
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -356,3 +357,18 @@ def test_schedule_switches_are_an_options_object_scoped_to_the_thread_and_kept_w
     finally:
         engine.set_activation_mode(base.ACTIVATIONS)
     assert engine.current().ACTIVATIONS == base.ACTIVATIONS
+
+
+def test_widths_above_the_widest_kernel_are_legal_for_batchnorm_layers():
+    """gated_gcn_full.py:44-50: nn.Linear(in, out) takes any width.  BatchNorm layers above 256 run as 256-column problems
+    (engine.WIDE_CHUNK; parity on the GPU tier: test_other_widths_and_norms_vs_oracle[320-2-True], [512-1-True]); LayerNorm rows
+    span the chunks and are refused at construction with a message that says so."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import layers
+    assert [layers.padded_width(w) for w in (1, 32, 33, 96, 128, 200, 256, 257, 320, 512, 513)] == \
+        [32, 32, 64, 128, 128, 256, 256, 512, 512, 512, 768]
+    m = G.GraphGatedGCNModel(1, 2, 320, 16, 2, 64, True, 16)
+    assert m.gnn.convs[0].A_1.weight.shape == (320, 320) and m.predictor.W1.weight.shape == (64, 960)
+    with pytest.raises(NotImplementedError, match="LayerNorm"):
+        G.GraphGatedGCNModel(1, 2, 512, 16, 1, 64, False, 16)
+    G.layers.GatedGCN_1d(48, 256, False)          # LayerNorm up to the widest kernel width stays legal
