@@ -1833,11 +1833,17 @@ int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t
 // that had lost their A/B (the round-1 split-mode edge backward / weight gradient / VALU encoders, the unpipelined t kernels,
 // the role-split chained kernel): their numbers are in profiles/r02_ab_kernels.txt, r03_chain_phases.txt, r04_ab_*.txt.
 static int g_eb_variant = 1;     // edge_bwd_tr_k: 1 = LDS stash + pinned prefetch (default), 2 = registers, unpinned (within 1 %)
+// round 6: workgroups per CU of the two-sided forward sweep (2 = default).  1 = the occupancy a sweep that ALSO carried the B_3 product
+// (W3 stationary: +32 registers per thread, over the 128 of four waves per SIMD) would be confined to: the measured price of
+// "t never materialised" in the forward sweep (profiles/r06_ab_gate2_occupancy.txt).  The caller passes the plan built for that partition.
+static int g_gate2_wg = 2;
 namespace gnm {
 int eb_variant() { return g_eb_variant; }
+int gate2_wg() { return g_gate2_wg; }
 }
 extern "C" int gnm_debug_set_variant(const char* what, int v) {
   if (what && !strcmp(what, "edge_bwd")) { g_eb_variant = v; return 0; }
+  if (what && !strcmp(what, "gate2_wg") && (v == 1 || v == 2)) { g_gate2_wg = v; return 0; }
   ::gnm::set_error("debug_set_variant: unknown switch");
   return -1;
 }

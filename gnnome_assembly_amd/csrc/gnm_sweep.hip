@@ -21,6 +21,7 @@
 
 namespace gnm {
 
+int gate2_wg();          // gnm_fused.hip: gnm_debug_set_variant("gate2_wg", 1 | 2)
 constexpr int GT = 512;                     // threads per workgroup (8 waves), two workgroups per CU
 constexpr int GR = kSweepTileRows;          // rows per tile
 typedef unsigned int u32x4g_ __attribute__((ext_vector_type(4)));
@@ -339,9 +340,9 @@ static int edge_gate2_fwd_impl(int64_t N, int64_t E, int H, const float* t, cons
   a.margin = kSweepMargin;
   a.gamma = ln_gamma; a.beta = ln_beta; a.width = ln_width;
   int grid = 0;
-  gnm_sweep_partition(N, 2, &a.nodes_per_block, &grid);
+  gnm_sweep_partition(N, gate2_wg(), &a.nodes_per_block, &grid);
   GNM_CHECK_ARG(plan_nodes_per_block == a.nodes_per_block, "edge_gate2_fwd: the sweep plan was built for %lld nodes per workgroup, the "
-                "kernel uses %lld (gnm_sweep_partition(N, 2))", (long long)plan_nodes_per_block, (long long)a.nodes_per_block);
+                "kernel uses %lld (gnm_sweep_partition(N, %d))", (long long)plan_nodes_per_block, (long long)a.nodes_per_block, gate2_wg());
   // 32-bit buffer offsets: the rows of one workgroup (x 4 H bytes) and its node range + margins (x 4 H bytes)
   GNM_CHECK_ARG((a.nodes_per_block + 2 * kSweepMargin) * H * 4 < (int64_t)INT32_MAX && (E / grid + 64) * H * 4 < (int64_t)INT32_MAX,
                 "edge_gate2_fwd: a workgroup's share exceeds the 32-bit buffer offsets");

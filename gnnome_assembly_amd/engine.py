@@ -830,6 +830,11 @@ def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, W, b, pa
                                          C.c_void_p(stream.cuda_stream)), "gnm_tn128")
 
 
+# workgroups per CU of the two-sided forward sweep (the partition its plan is built for); 1 only together with
+# GNM_VARIANTS=gate2_wg=1: the occupancy experiment of profiles/r06_ab_gate2_occupancy.txt
+GATE2_WG = int(os.environ.get("GNM_GATE2_WG", "2"))
+
+
 def sweep_width(H: int, batch_norm: bool = True) -> bool:
     """Does a layer of (kernel) width H run the two-sided sweeps?  128; with BatchNorm also 256 (one sweep per 128-column half) and
     the wide layers (256-column chunks)."""
@@ -1253,7 +1258,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
     ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw, opts=current()) if save else None
-    plan2 = graph.sweep_plan(dev, 2) if (current().TWO_SIDED_FWD and sweep_width(H, batch_norm) and hasattr(graph, "sweep_plan")) else None
+    plan2 = graph.sweep_plan(dev, GATE2_WG) if (current().TWO_SIDED_FWD and sweep_width(H, batch_norm) and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
         h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width)
         if save:
