@@ -132,10 +132,121 @@ def main():
             torch.cuda.synchronize()
             outs.append((mode, out.cpu().numpy()))
         lines.append(report(name, outs, ref, scale))
+    wide(dev, lib, rng, lines)
     _lib.set_matmul_mode(_lib.DEFAULT_MATMUL_MODE)
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     open(os.path.join(REPO, "gpurun_out", "f16x2_accuracy.txt"), "w").write(__doc__.strip() + "\n\n" + "\n".join(lines) + "\n")
     print("\n".join(lines))
+
+
+def wide(dev, lib, rng, lines):
+    """Round 6: the kernels of the reference's default width, H = 256 -- the fused t kernel (edge_t32_h256p_k), the
+    fused gt + NN kernel (edge_gt_nn_h256_k) and the general row GEMM / weight-gradient kernels the 256-wide node side runs on
+    (gemm_rows_b3_k NT K = 256, NN K = 1280; tn_tr_k classes, 20 k rows), each against fp64; the f32 column is the route the fp32-MFMA
+    mode takes for the same product (generic fp32 GEMM + elementwise kernel)."""
+    P_ = engine._ptr
+    W = 256
+    N, E, Nn = 20011, 50021, 9973
+    lines.append("")
+    lines.append("H = 256 ------------------------------------------------------------------------------------------------")
+    # ---- generic row GEMMs
+    for title, mode_, shp in (("gemm NT  P = h W5^T   [N,256] x [1280,256]^T", engine.NT, (N, 5 * W, W)),
+                              ("gemm NN  gh = gP W5   [N,1280] x [1280,256]", engine.NN, (N, W, 5 * W)),
+                              ("gemm TN  gW5 = gP^T h   [N,1280]^T x [N,256]", engine.TN, (5 * W, W, N))):
+        lines.append(title)
+        M_, N_, K_ = shp
+        for name, spread in (("normal", None), ("rows over 13 decades", (-25, 5))):
+            if mode_ == engine.TN:
+                An = rng.standard_normal((K_, M_))
+                Bn = rng.standard_normal((K_, N_))
+                if spread:
+                    An = An * np.exp(rng.uniform(*spread, (K_, 1)))
+                ref = An.astype(np.float32).astype(np.float64).T @ Bn.astype(np.float32).astype(np.float64)
+                scale = np.abs(An.astype(np.float32)).astype(np.float64).T @ np.abs(Bn.astype(np.float32)).astype(np.float64)
+            else:
+                An = rng.standard_normal((M_, K_))
+                if spread:
+                    An = An * np.exp(rng.uniform(*spread, (M_, 1)))
+                Bn = (rng.standard_normal((N_, K_) if mode_ == engine.NT else (K_, N_)) / 16)
+                a64, b64 = An.astype(np.float32).astype(np.float64), Bn.astype(np.float32).astype(np.float64)
+                ref = a64 @ (b64.T if mode_ == engine.NT else b64)
+                scale = np.abs(a64) @ (np.abs(b64).T if mode_ == engine.NT else np.abs(b64))
+            A, B = (torch.from_numpy(a.astype(np.float32)).to(dev) for a in (An, Bn))
+            outs = []
+            for mode in MODES:
+                _lib.set_matmul_mode(mode)
+                out = engine.gemm(mode_, A, B, torch.empty(M_, N_, device=dev))
+                torch.cuda.synchronize()
+                outs.append((mode, out.cpu().numpy()))
+            lines.append(report(name, outs, ref, scale))
+    # ---- fused t at H = 256
+    lines.append("gnm_edge_t_fused_fwd[256]   t = e W3^T + b3 + B1h[src] + B2h[dst]   [E,256] x [256,256]^T   (f32: gemm NT + gnm_edge_t_stats_fwd)")
+    for name, mk in (("normal", lambda: rng.standard_normal((E, W))),
+                     ("rows over 26 decades", lambda: rng.standard_normal((E, W)) * np.exp(rng.uniform(-30, 30, (E, 1)))),
+                     ("elements over 10 decades", lambda: rng.standard_normal((E, W)) * np.exp(rng.uniform(-12, 12, (E, W))))):
+        en = mk().astype(np.float32)
+        Wn = weights(rng, W, W, 0)
+        bn = rng.standard_normal(W).astype(np.float32)
+        Pn = rng.standard_normal((Nn, 5 * W)).astype(np.float32)
+        src = rng.integers(0, Nn, E).astype(np.int32)
+        dst = np.sort(rng.integers(0, Nn, E)).astype(np.int32)
+        e, W3, b3, Pt, s_, d_ = (torch.from_numpy(a).to(dev) for a in (en, Wn, bn, Pn, src, dst))
+        ref = en.astype(np.float64) @ Wn.astype(np.float64).T + bn + Pn[src, 3 * W:4 * W] + Pn[dst, 4 * W:5 * W]
+        scale = np.abs(en).astype(np.float64) @ np.abs(Wn).astype(np.float64).T + np.abs(bn) + np.abs(Pn[src, 3 * W:4 * W]) + np.abs(Pn[dst, 4 * W:5 * W])
+        outs = []
+        for mode in MODES:
+            _lib.set_matmul_mode(mode)
+            out = torch.empty(E, W, device=dev)
+            part = torch.zeros(4096 * 2 * W, dtype=torch.float64, device=dev)
+            nb = C.c_int(0)
+            if mode == "f32":
+                engine.gemm(engine.NT, e, W3, out, bias=b3)
+                engine._call("gnm_edge_t_stats_fwd", E, W, P_(out), P_(Pt), P_(s_), P_(d_), P_(part), C.byref(nb), engine._stream())
+            else:
+                need = lib.gnm_rowtile_workspace_bytes(5 * W)
+                ws = engine.scratch(dev).ws(need)
+                engine._call("gnm_edge_t_fused_fwd", E, W, P_(e), P_(W3), P_(b3), P_(Pt), P_(s_), P_(d_), P_(out), P_(part), C.byref(nb), P_(ws), need,
+                             engine._stream())
+            torch.cuda.synchronize()
+            outs.append((mode, out.cpu().numpy()))
+        lines.append(report(name, outs, ref, scale))
+    # ---- fused gt + NN at H = 256
+    lines.append("gnm_edge_bwd_gt_nn[256]   ge_in = ge + gt W3, gt = c (gu - m1 - that m2)   [E,256] x [256,256]   (f32: gnm_edge_bwd_gt + gemm NN)")
+    for name, gscale in (("normal", lambda: 1.0), ("gradients of 1e-7", lambda: 1e-7),
+                         ("rows over 13 decades", lambda: np.exp(rng.uniform(-25, 5, (E, 1))))):
+        gen = (rng.standard_normal((E, W)) * gscale()).astype(np.float32)
+        tn = rng.standard_normal((E, W)).astype(np.float32)
+        Wn = weights(rng, W, W, 1)
+        gam = (1.0 + 0.1 * rng.standard_normal(W)).astype(np.float32)
+        mu, rstd = (0.1 * rng.standard_normal(W)).astype(np.float32), (1.0 + 0.1 * rng.random(W)).astype(np.float32)
+        shift = (0.1 * rng.standard_normal(W)).astype(np.float32)
+        stat = np.stack([mu, rstd, gam * rstd, shift - mu * gam * rstd]).astype(np.float32)
+        m1 = (np.abs(gen).mean() * 0.01 * rng.standard_normal(W)).astype(np.float32)
+        m2 = (np.abs(gen).mean() * 0.01 * rng.standard_normal(W)).astype(np.float32)
+        bst = np.stack([m1, m2]).astype(np.float32)
+        ge, t, W3, g_, st_, bs_ = (torch.from_numpy(a).to(dev) for a in (gen, tn, Wn, gam, stat, bst))
+        t64, ge64 = tn.astype(np.float64), gen.astype(np.float64)
+        u32 = np.float32(tn) * stat[2] + stat[3]                 # the kernels decide the branch on the fp32 fma; ties are measure zero here
+        gu = ge64 * (u32 > 0)
+        that = (t64 - mu) * rstd.astype(np.float64)
+        gt64 = (gam.astype(np.float64) * rstd) * (gu - m1 - that * m2)
+        ref = ge64 + gt64 @ Wn.astype(np.float64)
+        scale = np.abs(ge64) + np.abs(gt64) @ np.abs(Wn.astype(np.float64))
+        outs = []
+        for mode in MODES:
+            _lib.set_matmul_mode(mode)
+            gt = torch.empty(E, W, device=dev)
+            out = torch.empty(E, W, device=dev)
+            if mode == "f32":
+                engine._call("gnm_edge_bwd_gt", E, W, P_(ge), P_(t), P_(st_), P_(bs_), P_(g_), P_(gt), engine._stream())
+                engine.gemm(engine.NN, gt, W3, out, resid=ge)
+            else:
+                need = lib.gnm_rowtile_workspace_bytes(5 * W)
+                ws = engine.scratch(dev).ws(need)
+                engine._call("gnm_edge_bwd_gt_nn", E, W, P_(ge), P_(t), P_(st_), P_(bs_), P_(g_), P_(W3), P_(gt), P_(out), P_(ws), need, engine._stream())
+            torch.cuda.synchronize()
+            outs.append((mode, out.cpu().numpy()))
+        lines.append(report(name, outs, ref, scale))
 
 
 if __name__ == "__main__":
