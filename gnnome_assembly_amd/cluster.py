@@ -28,6 +28,7 @@ import os
 import numpy as np
 import torch
 
+from . import engine
 from .graph import AssemblyGraph
 
 __all__ = ["node_order", "partition_graph", "edge_cut", "induced_subgraph", "ClusterBatchLoader", "NID", "EID"]
@@ -193,28 +194,37 @@ class ClusterBatchLoader:
                 yield self._build(ids)
             return
         self.graph.index(dev)                       # the parent's index (cached) before anything runs on the side stream
-        with torch.cuda.device(dev):
-            main = torch.cuda.current_stream(dev)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-            side = self._side
-            side.wait_stream(main)                  # the parent graph's tensors are ready
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
 
-            def build(ids):
+        def build(ids):
+            # device and stream contexts are entered HERE only -- never held across a yield (a generator that yields inside
+            # `with torch.cuda.device(...)` leaks the context into its consumer until it is closed) -- and the consumer's stream is
+            # looked up at every hand-over: whatever stream is current in the caller when it asks for a batch is the one that
+            # waits for the build and that the batch's tensors are recorded on
+            with torch.cuda.device(dev):
+                consumer = torch.cuda.current_stream(dev)
+                side.wait_stream(consumer)          # parent features written on the caller's stream since the last batch are visible
                 with torch.cuda.stream(side):
                     sub = self._build(ids)
                     sub.index(dev)
                     if hasattr(sub, "sweep_plan"):
                         sub.sweep_plan(dev, 1)
-                        sub.sweep_plan(dev, 2)
+                        sub.sweep_plan(dev, engine.GATE2_WG)
                     ev = torch.cuda.Event()
                     ev.record(side)
+            return sub, ev
+
+        def hand_over(sub, ev):
+            with torch.cuda.device(dev):
+                consumer = torch.cuda.current_stream(dev)
+                consumer.wait_event(ev)
                 for t in _graph_tensors(sub):
-                    t.record_stream(main)
-                return sub, ev
-            nxt = build(batches[0]) if batches else None
-            for k in range(len(batches)):
-                sub, ev = nxt
-                main.wait_event(ev)
-                yield sub                           # the caller issues batch k's kernels, then asks for the next batch:
-                nxt = build(batches[k + 1]) if k + 1 < len(batches) else None       # built while those kernels run
+                    t.record_stream(consumer)
+            return sub
+        nxt = build(batches[0]) if batches else None
+        for k in range(len(batches)):
+            sub = hand_over(*nxt)
+            yield sub                               # the caller issues batch k's kernels, then asks for the next batch:
+            nxt = build(batches[k + 1]) if k + 1 < len(batches) else None           # built while those kernels run

@@ -121,6 +121,14 @@ def _scoped(saved_arg: Optional[int] = None):
         def w(*a, opts: Optional[Options] = None, **k):
             if opts is None and saved_arg is not None and len(a) > saved_arg:
                 opts = getattr(a[saved_arg], "opts", None)
+                scoped = getattr(_tls, "opts", None)
+                if opts is not None and scoped is not None and scoped is not opts and repr(scoped) != repr(opts):
+                    # `with engine.options(...)` around a backward only: the saved forward options win (the backward kernels must
+                    # match the activations the forward kept) -- say so instead of silently comparing two identical paths
+                    import warnings
+                    warnings.warn("engine: this backward runs under the options its forward saved "
+                                  f"({opts!r}); the options scoped around the backward call ({scoped!r}) are ignored -- scope the "
+                                  "forward, or pass opts= explicitly", stacklevel=2)
             if opts is None:
                 return fn(*a, **k)
             with use(opts):
@@ -393,6 +401,7 @@ class LayerSaved:
     stat_h: torch.Tensor = None
     opts: "Options" = None       # the switches the forward ran under: its backward runs under the same (see Options)
     chunks: list = None          # a layer wider than 256: the saved state of its 256-column problems (see WIDE_CHUNK)
+    matmul: str = None           # the matmul mode (process-wide, not an Option) the forward ran in: its backward must run in the same
 
 
 def _proj_and_t(idx, N, E, H, prm, h_in, e_in, nblk):
@@ -511,7 +520,7 @@ def _layer_forward_tail(idx, N, E, H, prm, h_in, e_in, P, t, nblk, save, batch_n
     if save:
         lean = current().ACTIVATIONS == "lean"
         saved = LayerSaved(opts=current(), h_in=h_in, e_in=e_in, P=None if lean else P, t=None if lean else t, stat_e=stat_e, e_out=e_out,
-                           hf=hf, inv_f=inv_f, hb=hb, inv_b=inv_b, z=z, stat_h=stat_h)
+                           hf=hf, inv_f=inv_f, hb=hb, inv_b=inv_b, z=z, stat_h=stat_h, matmul=_lib.get_matmul_mode())
     return h_out, e_out, saved
 
 
@@ -570,8 +579,17 @@ def _wide_layer_forward(idx, N, E, H, prm, h_in, e_in, save, batch_norm, residua
         if save:
             sv.h_in = sv.e_in = None            # the full-width inputs are kept once, below
             chunks.append(sv)
-    saved = LayerSaved(opts=current(), h_in=h_in, e_in=e_in, chunks=chunks) if save else None
+    saved = LayerSaved(opts=current(), h_in=h_in, e_in=e_in, chunks=chunks, matmul=_lib.get_matmul_mode()) if save else None
     return h_out, e_out, saved
+
+
+def _same_matmul_mode(s) -> None:
+    """A lean-mode backward rebuilds P and t with the forward's kernels, and the chained / two-sided schedules exist in the split
+    modes only: a backward in another matmul mode than its forward would silently mix arithmetic."""
+    m = getattr(s, "matmul", None)
+    if m is not None and m != _lib.get_matmul_mode():
+        raise _lib.GnmError(f"backward in matmul mode {_lib.get_matmul_mode()!r} of a forward that ran in {m!r}: "
+                            "gnm_set_matmul_mode is process-wide, change it between steps, not inside one")
 
 
 def _wide_layer_backward(idx, N, E, H, prm, s: LayerSaved, gh_out, ge, out, residual, plan):
@@ -688,6 +706,7 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     nblk = C.c_int(0)
     f32 = dict(dtype=torch.float32, device=dev)
     g: Dict[str, torch.Tensor] = {}
+    _same_matmul_mode(s)
     if s.chunks is not None:
         return _wide_layer_backward(idx, N, E, H, prm, s, gh_out, ge, out, residual, plan)
     if s.P is None or s.t is None:      # "lean" activations: rebuild P and t with the kernels that made them
@@ -1198,6 +1217,7 @@ class ModelSaved:
     layers: List[LayerSaved] = field(default_factory=list)
     pred: PredSaved = None
     opts: "Options" = None
+    matmul: str = None
 
 
 def stacked(ts):
@@ -1257,7 +1277,7 @@ def model_forward(graph, e_raw, pe, P: Dict[str, torch.Tensor], num_layers: int,
         a1 = torch.empty(E, Q, **f32)
         gemm(NT, e_int, P["linear1_edge.weight"], a1, bias=P["linear1_edge.bias"], relu=True)
         gemm(NT, a1, P["linear2_edge.weight"], e, bias=P["linear2_edge.bias"])
-    ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw, opts=current()) if save else None
+    ms = ModelSaved(pe=pe, e_int=e_int, a1=a1, e_raw=e_raw, opts=current(), matmul=_lib.get_matmul_mode()) if save else None
     plan2 = graph.sweep_plan(dev, GATE2_WG) if (current().TWO_SIDED_FWD and sweep_width(H, batch_norm) and hasattr(graph, "sweep_plan")) else None
     for i in range(num_layers):
         h, e, ls = layer_forward(idx, N, E, H, layer_params(P, i), h, e, save, batch_norm, plan=plan2, ln_width=ln_width)
@@ -1292,6 +1312,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     contiguous tensor of the parameter's shape, e.g. the .grad views of dp.FlatGradients) the kernels write the
     gradients straight into those tensors and the same tensors are returned."""
     dev = ms.pe.device
+    _same_matmul_mode(ms)
     idx = graph.index(dev)
     N, E = graph.num_nodes(), graph.num_edges()
     H = P["linear_pe.weight"].shape[0]
@@ -1378,4 +1399,5 @@ def bce_with_logits(scores, y, pos_weight: float):
     return loss, gs
 
 
-_default = Options(**{k: globals()["_D_" + k] for k in _OPTION_NAMES})
+_default = Options(**{k: (globals()["_D_" + k] if k not in ("ACTIVATIONS", "TN_AT") else {"ACTIVATIONS": "saved", "TN_AT": "auto"}[k])
+                      for k in _OPTION_NAMES}).replace(ACTIVATIONS=_D_ACTIVATIONS, TN_AT=_D_TN_AT)     # environment values are validated
