@@ -4,6 +4,8 @@ libgnm.so (HIP, gfx950).  Per-edge tensors at these module boundaries are in the
 edge-id order, as with DGL."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -16,13 +18,19 @@ __all__ = ["GatedGCN_1d", "GraphGatedGCN", "ScorePredictor", "NodeEncoder", "Edg
 
 
 KERNEL_WIDTHS = (32, 64, 128, 256)      # the hidden sizes the row kernels are instantiated for (GNM_DISPATCH_H)
+# The widths the MODULES run on.  64 is left out since round 6: a 64-wide layer has only the round-1 schedule (generic GEMMs at K = 64,
+# separate by-destination / by-source passes), and at the metric's graph that is SLOWER than the same model zero-padded to 128 on the
+# fused kernels, the two-sided sweeps and the chained backward -- 222 against ~160 ms per step at L = 8, 50.7 against ~31 at
+# BASELINE config 1's H = 64 / L = 1 (profiles/r06_h64_padded.txt) -- although the padded model moves twice the bytes.  32-wide layers
+# stay native (141 ms).  GNM_NATIVE_64=1 / layers.RUN_WIDTHS = KERNEL_WIDTHS: the 64-wide kernels again (they stay built and tested).
+RUN_WIDTHS = KERNEL_WIDTHS if os.environ.get("GNM_NATIVE_64", "0") == "1" else (32, 128, 256)
 
 
 def padded_width(width: int) -> int:
     """The kernel width a layer of `width` output channels runs on: itself, or the next one up with dead channels.  Above the widest
     instantiation a layer runs as 256-column problems between full-width dense products (engine.WIDE_CHUNK: BatchNorm layers; slow
     by construction, but nn.Linear(in, out) of gated_gcn_full.py:44-50 takes any width and so does this)."""
-    for w in KERNEL_WIDTHS:
+    for w in RUN_WIDTHS:
         if width <= w:
             return w
     c = engine.WIDE_CHUNK

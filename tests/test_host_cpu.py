@@ -95,7 +95,7 @@ def test_module_surface_and_state_dict_schema():
     wide = G.layers.GatedGCN_1d(32, 64, True)                         # in != out: the residual is dropped (gated_gcn_full.py:41-42)
     assert wide.residual is False and wide.B_3.weight.shape == (64, 32)
     assert G.layers.GatedGCN_1d(32, 32, True, residual=False).residual is False
-    assert G.layers.GatedGCN_1d(32, 48, True).B_3.weight.shape == (48, 32)     # any width up to 256 (run zero-padded to 64)
+    assert G.layers.GatedGCN_1d(32, 48, True).B_3.weight.shape == (48, 32)     # any width (run zero-padded to the next of layers.RUN_WIDTHS)
     assert G.layers.padded_width(96) == 128 and G.layers.padded_width(128) == 128
     assert G.layers.GatedGCN_1d(32, 300, True).B_3.weight.shape == (300, 32)   # wider than the widest kernel: 256-column chunks
     with pytest.raises(NotImplementedError):
@@ -365,8 +365,8 @@ def test_widths_above_the_widest_kernel_are_legal_for_batchnorm_layers():
     span the chunks and are refused at construction with a message that says so."""
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import layers
-    assert [layers.padded_width(w) for w in (1, 32, 33, 96, 128, 200, 256, 257, 320, 512, 513)] == \
-        [32, 32, 64, 128, 128, 256, 256, 512, 512, 512, 768]
+    assert [layers.padded_width(w) for w in (1, 32, 33, 64, 96, 128, 200, 256, 257, 320, 512, 513)] == \
+        [32, 32, 128, 128, 128, 128, 256, 256, 512, 512, 512, 768]      # 64 runs padded to 128 (layers.RUN_WIDTHS: measured faster)
     m = G.GraphGatedGCNModel(1, 2, 320, 16, 2, 64, True, 16)
     assert m.gnn.convs[0].A_1.weight.shape == (320, 320) and m.predictor.W1.weight.shape == (64, 960)
     with pytest.raises(NotImplementedError, match="LayerNorm"):

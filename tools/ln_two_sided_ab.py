@@ -47,6 +47,14 @@ def main():
                     step()
                 torch.cuda.synchronize()
                 lines.append(f"{'two-sided forward sweep' if two else 'separate passes       '}  {(time.perf_counter() - t0) * 100:.2f}")
+    # per-op times of one (serialised, event-bracketed) step under the default switches
+    engine.profile_ops(True)
+    step()
+    ops = engine.profile_ops(False)
+    lines.append("# per-op times of one step (ms; calls):")
+    for k, (c, t) in sorted(ops.items(), key=lambda kv: -kv[1][1]):
+        lines.append(f"#   {t:8.2f}  x{c:3d}  {k}")
+    lines.append(f"#   {sum(t for _, t in ops.values()):8.2f}  total")
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     open(os.path.join(REPO, "gpurun_out", "ln_two_sided.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
