@@ -125,7 +125,7 @@ def op_model(op: str, N: int, E: int, H: int):
 # The committed PMC pass (tools/collect_traffic.sh + tools/traffic_summary.py): HBM bytes per kernel launch on
 # this workload.  PMC counters cannot be collected from inside this process, so the bench line carries the
 # number together with `traffic_source`; C-ABI op -> rocprof kernel name(s) of the op in each matmul mode.
-TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_traffic.json")
 OP_KERNELS = {
     "gnm_edge_bwd_fused": {"f32": ["edge_bwd_fused32_k"], "bf16x3": ["edge_bwd_tr_k<3, false>"], "f16x2": ["edge_bwd_tr_k<3, true>"]},
     "gnm_edge_bwd_chain": ["edge_bwd_chain_k"], "gnm_edge_bwd_chain_src": ["edge_bwd_chain_k"],
@@ -430,7 +430,7 @@ def main():
                           "every split-mode matrix kernel; bf16x3: fp32 operands "
                           "split exactly into 3 bf16 terms, 6 bf16 MFMAs per product; f32: every contraction on v_mfma_f32_32x32x2_f32.  "
                           "fp32 accumulate in all three; all three pass the whole of tests/test_gpu_parity.py; distance to the fp64 oracle "
-                          "per mode: profiles/r05_f16x2_accuracy.txt")
+                          "per mode: profiles/r06_f16x2_accuracy.txt")
         dbg("alt matmul run done")
     # the "lean" activation mode (engine.set_activation_mode): one step, for its time and its peak memory
     alt_act = None
