@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNM_LIBRARY") or os.path.join(_HERE, "libgnm.so")   # GNM_LIBRARY: A/B against another build (tools)
 
 _lib = None
-ABI_VERSION = 6     # GNM_ABI_VERSION of include/gnm.h
+ABI_VERSION = 7     # GNM_ABI_VERSION of include/gnm.h
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -77,6 +77,7 @@ SIGNATURES = {
     "gnm_ln_edge_gate2_fwd": (_i32, [_i64, _i64, _i32] + [_p] * 4 + [_i32] + [_p] * 6 + [_i64, _i64] + [_p] * 11 + [_pi, _p]),
     "gnm_edge_bwd_fused_workspace_bytes": (_sz, []),
     "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gnm_edge_bwd_fused_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_encoder_fwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_encoder_bwd_workspace_bytes": (_sz, []),
     "gnm_edge_encoder_bwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

@@ -1827,7 +1827,7 @@ void tn_tr_launch(int64_t M, const float* A, int64_t lda, int ncg, const void* B
 size_t edge_bwd_tr_pack_bytes();
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
-                       double* partials, hipStream_t st, bool h2 = false);
+                       double* partials, hipStream_t st, bool h2 = false, bool given = false);
 }
 // kernel-generation switches for same-process A/B runs (gnm_debug_set_variant, GNM_VARIANTS).  Round 5 removed the generations
 // that had lost their A/B (the round-1 split-mode edge backward / weight gradient / VALU encoders, the unpipelined t kernels,
@@ -2129,6 +2129,27 @@ extern "C" int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_o
                 gnm_edge_bwd_fused_workspace_bytes());
   return g_matmul_mode ? edge_bwd_fused_impl<MmB3>(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, gW3, gb3, partials, ws, stream)
                        : edge_bwd_fused_impl<MmF32>(E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e, W3, gW3, gb3, partials, ws, stream);
+}
+
+// gt GIVEN (the LayerNorm backward, whose gt comes out of its by-destination pass): gW3 = gt^T e_in, gb3 = sum gt, ge_out = ge + gt W3 in one
+// pass over gt, ge, e_in -- the two generic GEMMs + column sum of the LayerNorm mode at H = 128.  Split matmul modes only (-4 otherwise:
+// the caller keeps the generic route).
+extern "C" int gnm_edge_bwd_fused_gt(int64_t E, int H, const float* ge, float* ge_out, const float* gt, const float* e_in,
+                                     const float* W3, float* gW3, float* gb3, double* partials, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  GNM_CHECK_ARG(H == FH, "edge_bwd_fused_gt: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(E > 0 && ge && ge_out && gt && e_in && W3 && gW3 && gb3 && partials, "edge_bwd_fused_gt: null/neg argument");
+  GNM_CHECK_ARG(gt != ge_out, "edge_bwd_fused_gt: gt and ge_out must not alias");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "edge_bwd_fused_gt: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  if (!g_matmul_mode) { ::gnm::set_error("edge_bwd_fused_gt: built for the split matmul modes (1, 2) only"); return -4; }
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  const int grid = edge_bwd_tr_launch(E, ge, ge_out, gt, e_in, nullptr, nullptr, nullptr, W3, ws, slab, partials, st, g_matmul_mode == 2, true);
+  GNM_LAUNCH_CHECK("edge_bwd_fused_gt (tr)");
+  hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3);
+  GNM_LAUNCH_CHECK("edge_bwd_fused_gt slab reduce");
+  return gnm_reduce_partials(partials, grid, 1, FH, gb3, stream) ? -3 : 0;
 }
 
 static int tn_colgroups(int64_t N, const float* A, int64_t lda, int ncg, const float* B, float* gW, float* gb,

@@ -340,6 +340,9 @@ struct tile_tag { static constexpr bool full = FULL; };
 
 // VAR bit 0: residual ge rows and the fp64 column sums wait in LDS (1) or in registers (0);
 //     bit 1: the prefetch is pinned right behind the first barrier (1) or left to hipcc's scheduler (0)
+//     bit 2 (round 6): gt is GIVEN -- `t` points at the [E,128] gt rows another kernel formed (the LayerNorm backward: its gt comes out
+//           of the by-destination pass, row statistics and all), stat / bstat / gamma are not read; everything else -- gW3 += gt^T e_in,
+//           gb3 += sum gt, ge_out = ge + gt W3 -- as before: the LayerNorm mode's two generic GEMMs + column sum in one pass
 // H2 (round 5): the f16x2 form, as in edge_bwd_chain_k<..., H2> (the NN product per row of gt and column of W3, the TN product through the
 // workgroup's reference exponent; a thread owns two rows of a tile here)
 template <int VAR, bool H2 = false>
@@ -369,14 +372,17 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
   const int64_t nfull = tb1 < E / ER ? tb1 : E / ER;        // tiles [tb0, nfull) are full
   const int lrow = tid >> 5, lc4 = (tid & 31) * 4;           // rows lrow and lrow + 8 of a tile
   const int64_t Elast = E - 1;
-  for (int c = tid; c < SW; c += kBlock) {
-    cs[c] = stat[c];
-    cs[SW + c] = stat[SW + c];
-    cs[2 * SW + c] = stat[2 * SW + c];
-    cs[3 * SW + c] = stat[3 * SW + c];
-    cs[4 * SW + c] = bstat[c];
-    cs[5 * SW + c] = bstat[SW + c];
-    cs[6 * SW + c] = gamma[c] * stat[SW + c];
+  constexpr bool GIVEN = (VAR & 4) != 0;
+  if constexpr (!GIVEN) {
+    for (int c = tid; c < SW; c += kBlock) {
+      cs[c] = stat[c];
+      cs[SW + c] = stat[SW + c];
+      cs[2 * SW + c] = stat[2 * SW + c];
+      cs[3 * SW + c] = stat[3 * SW + c];
+      cs[4 * SW + c] = bstat[c];
+      cs[5 * SW + c] = bstat[SW + c];
+      cs[6 * SW + c] = gamma[c] * stat[SW + c];
+    }
   }
   W3Frag wf;
   h16x8 wfh[H2 ? 2 : 1][H2 ? SW / 32 : 1][2];       // H2: [nb][kc][hi/lo] = 64 VGPRs
@@ -453,17 +459,25 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     {
       double c0 = cg0, c1 = cg1, c2 = cg2, c3 = cg3;
       if (STASH) { c0 = cgs[0]; c1 = cgs[1]; c2 = cgs[2]; c3 = cgs[3]; }
-      const float4 mu = ld4(cs + lc4), rs = ld4(cs + SW + lc4), sc = ld4(cs + 2 * SW + lc4),
-                   sh = ld4(cs + 3 * SW + lc4), m1 = ld4(cs + 4 * SW + lc4), m2 = ld4(cs + 5 * SW + lc4),
-                   cc = ld4(cs + 6 * SW + lc4);
+      float4 mu = f4(0.f), rs = f4(0.f), sc = f4(0.f), sh = f4(0.f), m1 = f4(0.f), m2 = f4(0.f), cc = f4(0.f);
+      if constexpr (!GIVEN) {
+        mu = ld4(cs + lc4); rs = ld4(cs + SW + lc4); sc = ld4(cs + 2 * SW + lc4);
+        sh = ld4(cs + 3 * SW + lc4); m1 = ld4(cs + 4 * SW + lc4); m2 = ld4(cs + 5 * SW + lc4);
+        cc = ld4(cs + 6 * SW + lc4);
+      }
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int row = lrow + 8 * it;
         const bool ok = FULL || (r0 + row < E);
         if (STASH) st4(og + row * EOP + lc4, pg[it]);   // this thread read exactly these og elements in the previous epilogue
         else gk[it] = pg[it];
-        const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
-        float4 gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
+        float4 gt;
+        if constexpr (GIVEN) {
+          gt = pt[it];
+        } else {
+          const float4 gu = gate4(fma4(pt[it], sc, sh), pg[it]);
+          gt = cc * (gu - m1 - ((pt[it] - mu) * rs) * m2);
+        }
         float4 ev = pe_[it];
         if (!ok) { gt = f4(0.f); ev = f4(0.f); }
         c0 += (double)gt.x; c1 += (double)gt.y; c2 += (double)gt.z; c3 += (double)gt.w;
@@ -674,17 +688,27 @@ size_t edge_bwd_tr_pack_bytes() { return (size_t)(SW / 16) * (SW / 32) * 3 * 64 
 // returns the grid size (= number of slabs / partial rows written)
 int edge_bwd_tr_launch(int64_t E, const float* ge, float* ge_out, const float* t, const float* e_in, const float* stat_e,
                        const float* bstat_e, const float* gamma_e, const float* W3, void* wpack, float* slab,
-                       double* partials, hipStream_t st, bool h2) {
+                       double* partials, hipStream_t st, bool h2, bool given) {
   if (h2) {
     hipLaunchKernelGGL(pack_w2_nn16_k, dim3(SW / 16), dim3(256), 0, st, W3, (int64_t)SW, (unsigned char*)wpack);
     const int64_t ntiles = (E + ER - 1) / ER;
     const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_bwd_tr_k<3, true>>());
-    hipLaunchKernelGGL((edge_bwd_tr_k<3, true>), dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e,
-                       (const bf16x8*)wpack, slab, partials, (ntiles + grid - 1) / grid);
+    if (given)
+      hipLaunchKernelGGL((edge_bwd_tr_k<7, true>), dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e,
+                         (const bf16x8*)wpack, slab, partials, (ntiles + grid - 1) / grid);
+    else
+      hipLaunchKernelGGL((edge_bwd_tr_k<3, true>), dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e,
+                         (const bf16x8*)wpack, slab, partials, (ntiles + grid - 1) / grid);
     return grid;
   }
   hipLaunchKernelGGL(pack_w3_nn16_k, dim3(8), dim3(256), 0, st, W3, (int64_t)SW, (bf16x8*)wpack);
   const int64_t ntiles = (E + ER - 1) / ER;
+  if (given) {
+    const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_bwd_tr_k<3>>());
+    hipLaunchKernelGGL(edge_bwd_tr_k<7>, dim3(grid), dim3(kBlock), 0, st, E, ge, ge_out, t, e_in, stat_e, bstat_e, gamma_e,
+                       (const bf16x8*)wpack, slab, partials, (ntiles + grid - 1) / grid);
+    return grid;
+  }
   const int var = eb_variant();      // 1: LDS stash + pinned prefetch (default); 2: registers, unpinned (A/B: within 1 % of each other)
   const int grid = persistent_grid(ntiles, 16, occ_blocks<edge_bwd_tr_k<3>>());
 #define GNM_EB_LAUNCH(V)                                                                                               \

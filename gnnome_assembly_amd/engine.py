@@ -260,6 +260,29 @@ def _side_stream(device):
     return _side_streams[device]
 
 
+_side_held: Dict[torch.device, list] = {}       # what the side stream of a device is reading (kept alive until the main stream has waited)
+
+
+def side_begin(device):
+    """The side stream of `device`, ready for one more launch: the main stream first waits for what ran there before (a layer ago:
+    free) -- which also makes the held tensors safe to drop -- and the side stream for the main stream's work so far."""
+    device = torch.device(device)
+    side = _side_stream(device)
+    main = torch.cuda.current_stream(device)
+    main.wait_stream(side)
+    _side_held.setdefault(device, []).clear()
+    side.wait_stream(main)
+    return side
+
+
+def side_drain(device) -> None:
+    """The main stream waits for the side stream's work (layer_backward(..., defer_tn=True)); the held tensors are released."""
+    device = torch.device(device)
+    if device in _side_streams:
+        torch.cuda.current_stream(device).wait_stream(_side_streams[device])
+    _side_held.get(device, []).clear()
+
+
 # ---------------------------------------------------------------------------------------
 # thin wrappers
 # ---------------------------------------------------------------------------------------
@@ -688,12 +711,14 @@ def _bn_backward_mid(idx, N, E, H, prm, s, gh_out, ge, out, plan):
 @_scoped(5)
 def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved, gh_out, ge, batch_norm: bool = True,
                    out: Optional[Dict[str, torch.Tensor]] = None, residual: bool = True, plan: Optional[dict] = None,
-                   ln_width: Optional[int] = None):
+                   ln_width: Optional[int] = None, defer_tn: bool = False):
     """Backward of layer_forward.  `ge` ([E,H], internal order) holds d loss / d e_out on entry
     and is OVERWRITTEN with d loss / d e_in (residual layers; without the residual the returned ge is a fresh [E,Hin]
     tensor).  Returns (gh_in, ge, grads dict).  `out` (optional) names the tensors
     the parameter gradients are written INTO (keys W5 b5 W3 b3 gamma_e beta_e gamma_h beta_h; contiguous blocks,
-    e.g. views of a flat gradient buffer) instead of fresh allocations."""
+    e.g. views of a flat gradient buffer) instead of fresh allocations.
+    defer_tn (H = 128 fused route): the node-projection weight gradient may run on the side stream; the CALLER then calls
+    side_drain(device) before anything reads W5 / b5 gradients (model_backward does, after the last layer)."""
     out = out or {}
     Hin = s.h_in.shape[1]
     lnw = H if ln_width is None else int(ln_width)
@@ -727,11 +752,20 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         _call("gnm_ln_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q), _ptr(idx["out_ptr"]),
               _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
         del Q
-        g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
-        if residual:
-            gemm(NN, gt, prm.W3, ge, resid=ge)
+        if fused and Hin == H and _lib.split_mode():
+            # round 6: gW3 = gt^T e_in, gb3 = sum gt and ge_in = ge + gt W3 from ONE pass over gt, ge, e_in (the fused edge backward
+            # with gt given) instead of gemm_tn_colsum + gemm NN with the residual add
+            g["b3"] = new("b3", H)
+            need = lib.gnm_edge_bwd_fused_workspace_bytes()
+            ws = sc.ws(need)
+            _call("gnm_edge_bwd_fused_gt", E, H, _ptr(ge), _ptr(ge), _ptr(gt), _ptr(s.e_in), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]),
+                  _ptr(sc.partials), _ptr(ws), need, st)
         else:
-            ge = gemm(NN, gt, prm.W3, torch.empty(E, Hin, **f32))
+            g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
+            if residual:
+                gemm(NN, gt, prm.W3, ge, resid=ge)
+            else:
+                ge = gemm(NN, gt, prm.W3, torch.empty(E, Hin, **f32))
         del gt
     else:
         gP, ge, bstat_e, gm = _bn_backward_mid(idx, N, E, H, prm, s, gh_out, ge, out, plan)
@@ -772,8 +806,18 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
         need = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
         ws = sc.ws(need)
         _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh_out), _ptr(gh_in), _ptr(ws), need, st)
-        _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
-              _ptr(sc.partials), _ptr(ws), need, 0, st)
+        if defer_tn and current().TN_SIDE and _prof is None and current().ACTIVATIONS != "lean":
+            # the weight gradient has no consumer before the optimizer step: on the side stream, beside the next layer's HBM-bound
+            # node / by-destination passes (what the chained schedule does with its deferred kernel); the caller drains (side_drain)
+            side = side_begin(dev)
+            sc3 = scratch(dev, "tn")
+            ws3 = sc3.ws(need)
+            _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc3.partials),
+                                                _ptr(ws3), need, current().TN_SIDE_CAP, C.c_void_p(side.cuda_stream)), "gnm_node_proj_bwd_tn")
+            _side_held[torch.device(dev)].extend((gP, s.h_in, g["W5"], g["b5"]))
+        else:
+            _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
+                  _ptr(sc.partials), _ptr(ws), need, 0, st)
     else:
         g["b5"] = gemm_tn_colsum(gP, s.h_in, g["W5"], out.get("b5"))
         gemm(NN, gP, prm.W5, gh_in, resid=gh_out if residual else None)
@@ -1342,7 +1386,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
             gl = chained[i]
         else:
             gh, ge, gl = layer_backward(idx, N, E, H, layer_params(P, i), ms.layers[i], gh, ge, batch_norm, lout, plan=plan_w,
-                                        ln_width=ln_width)
+                                        ln_width=ln_width, defer_tn=True)
             ms.layers[i] = None     # release this layer's activations
         for j, k in enumerate(LIN5):
             G[p + k + ".weight"] = gl["W5"][j * H:(j + 1) * H]
@@ -1357,6 +1401,8 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
         G[p + "B_3.weight"], G[p + "B_3.bias"] = gl["W3"], gl["b3"]
         G[p + "bn_e.weight"], G[p + "bn_e.bias"] = gl["gamma_e"], gl["beta_e"]
         G[p + "bn_h.weight"], G[p + "bn_h.bias"] = gl["gamma_h"], gl["beta_h"]
+    if chained is None:
+        side_drain(dev)             # the deferred weight-gradient launches of layer_backward(defer_tn=True)
     # encoders backward
     lib = _lib.load()
     G["linear_pe.weight"] = tgt("linear_pe.weight", P["linear_pe.weight"])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 6   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed, gnm_ln_edge_gate2_fwd */
+#define GNM_ABI_VERSION 7   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed, gnm_ln_edge_gate2_fwd; 7: gnm_edge_bwd_fused_gt (gt given: the LayerNorm backward's fused edge pass), gnm_debug_set_variant("gate2_wg") */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -399,6 +399,11 @@ int gnm_edge_bwd_fused(int64_t E, int H, const float* ge, float* ge_out, const f
                        const float* stat_e, const float* bstat_e, const float* gamma_e,
                        const float* W3, float* gW3, float* gb3, double* partials, void* ws,
                        size_t ws_bytes, void* stream);
+/* The same pass with gt GIVEN (round 6; H = 128, split matmul modes): the LayerNorm backward (layers/gated_gcn_full.py:58-59 selects
+ * nn.LayerNorm) forms gt in its by-destination pass; this replaces its gemm_tn_colsum(gt, e_in) + gemm NN(gt, W3) + residual add:
+ * gW3 = gt^T e_in, gb3 = sum gt, ge_out = ge + gt W3 (ge_out may alias ge, not gt).   autograd of gated_gcn_full.py:113 */
+int gnm_edge_bwd_fused_gt(int64_t E, int H, const float* ge, float* ge_out, const float* gt, const float* e_in,
+                          const float* W3, float* gW3, float* gb3, double* partials, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- edge-feature encoder (full_graph.py:24-26), H = 128 or 256, edge_features F = 2, hidden Q = 16 ----
  * fwd: e0[j] = W2 relu(W1 e_raw[perm j] + b1) + b2, internal order, one pass writing [E,H]

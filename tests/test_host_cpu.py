@@ -27,7 +27,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gnm_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.gnm_abi_version() == _lib.ABI_VERSION == 7
     assert lib.gnm_max_partial_blocks() == 2048
 
 
