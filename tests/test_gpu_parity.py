@@ -116,7 +116,7 @@ def _cmp(name, got, want, rows):
 def test_library_loaded_and_device():
     from gnnome_assembly_amd import _lib
     lib = _lib.load()
-    assert lib.gnm_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.gnm_abi_version() == _lib.ABI_VERSION == 7
     assert lib.gnm_num_cus() >= 64
     print("CUs:", lib.gnm_num_cus(), torch.cuda.get_device_name(0))
 

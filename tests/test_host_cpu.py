@@ -372,3 +372,14 @@ def test_widths_above_the_widest_kernel_are_legal_for_batchnorm_layers():
     with pytest.raises(NotImplementedError, match="LayerNorm"):
         G.GraphGatedGCNModel(1, 2, 512, 16, 1, 64, False, 16)
     G.layers.GatedGCN_1d(48, 256, False)          # LayerNorm up to the widest kernel width stays legal
+
+
+def test_a_backward_in_another_matmul_mode_than_its_forward_is_refused():
+    """the matmul mode is process-wide, not an Option; a forward records it with its activations and the backward checks it
+    (a lean-mode backward rebuilds P and t with the forward's kernels; the chained schedule exists in the split modes only)."""
+    from gnnome_assembly_amd import _lib, engine
+    s = engine.LayerSaved(matmul="f32" if _lib.get_matmul_mode() != "f32" else "f16x2")
+    with pytest.raises(_lib.GnmError, match="matmul mode"):
+        engine._same_matmul_mode(s)
+    engine._same_matmul_mode(engine.LayerSaved(matmul=_lib.get_matmul_mode()))
+    engine._same_matmul_mode(engine.LayerSaved())          # no record (a state built by hand): unchecked
