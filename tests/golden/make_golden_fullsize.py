@@ -32,22 +32,29 @@ from oracle import gatedgcn_oracle as orc       # noqa: E402
 R, H, L, SEED, STRIDE = 750000, 128, 8, 0, 97
 
 
-def _case(reads):
+# round 6: the reference's DEFAULT model shape (hyperparameters.py:8,13: dim_latent 256, num_gnn_layers 16) at the true chr19 size
+# (R = 110 k reads), logits only:   python tests/golden/make_golden_fullsize.py --case h256l16_r110k
+CASES = {"r750k": (750000, 128, 8, "fullsize_logits_r750k.npz"),
+         "h256l16_r110k": (110000, 256, 16, "fullsize_logits_h256l16_r110k.npz")}
+
+
+def _case(reads, H_=H, L_=L):
     src, dst, n = synth.make_graph(reads, SEED)
     inp = synth.make_inputs(src, dst, n, SEED)
-    sd = {k: torch.from_numpy(np.asarray(v)).double() for k, v in synth.synth_state_dict(H, L, SEED).items()}
+    sd = {k: torch.from_numpy(np.asarray(v)).double() for k, v in synth.synth_state_dict(H_, L_, SEED).items()}
     return src, dst, n, inp, sd
 
 
-def logits():
-    src, dst, n, inp, sd = _case(R)
+def logits(case="r750k"):
+    R, H, L, fname = CASES[case]
+    src, dst, n, inp, sd = _case(R, H, L)
     t0 = time.perf_counter()
     with torch.no_grad():
         s = orc.model_forward(sd, torch.from_numpy(src), torch.from_numpy(dst), n, torch.from_numpy(inp["e"]).double(),
                               torch.from_numpy(inp["pe"]).double()).squeeze(-1).numpy()
     secs = time.perf_counter() - t0
     idx = np.arange(0, s.size, STRIDE, dtype=np.int64)
-    out = os.path.join(HERE, "fullsize_logits_r750k.npz")
+    out = os.path.join(HERE, fname)
     np.savez_compressed(out, reads=R, H=H, L=L, seed=SEED, stride=STRIDE, edges=s.size, logits=s[idx],
                         norm2=float(np.linalg.norm(s)), mean=float(s.mean()), oracle_seconds=secs, threads=torch.get_num_threads())
     print(f"wrote {out}: {idx.size} of {s.size} logits (fp64 oracle, {secs:.0f} s on {torch.get_num_threads()} threads), |s|_2 = {np.linalg.norm(s):.6f}")
@@ -105,5 +112,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--grads", action="store_true")
     ap.add_argument("--selftest", action="store_true")
+    ap.add_argument("--case", default="r750k", choices=sorted(CASES), help="which logits fixture to write")
     a = ap.parse_args()
-    selftest() if a.selftest else grads() if a.grads else logits()
+    selftest() if a.selftest else grads() if a.grads else logits(a.case)
