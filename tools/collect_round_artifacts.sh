@@ -1,7 +1,9 @@
 # Round artifacts on the GPU box (run through gpurun): everything that is copied into profiles/ afterwards.
-#   TAG=r06 tools/collect_round_artifacts.sh          (FAST=1: skip the full GPU test tier and the sweeps)
+#   TAG=r06 tools/collect_round_artifacts.sh          (FAST=1: skip the full GPU test tier and the sweeps;
+#                                                      PART=1 / PART=2: the first / second half only -- a gpurun call is limited to an hour)
 set -x
 T=${TAG:-r06}; O=gpurun_out/$T; mkdir -p $O
+if [ "$PART" != "2" ]; then
 if [ -z "$FAST" ]; then
   python -m pytest tests -q -m gpu > $O/gputest.log 2>&1; tail -3 $O/gputest.log
   cp gpurun_out/logit_parity_fullsize.txt gpurun_out/grad_parity_fullsize.txt gpurun_out/rccl_smoke.log gpurun_out/grad_clauses.json gpurun_out/grad_clauses.txt gpurun_out/cabi_host_step.txt gpurun_out/dp2_train_config4.log gpurun_out/accuracy_e2e.txt $O/ 2>/dev/null
@@ -22,7 +24,8 @@ python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 BENCH=1 tools/pmc_run.sh $T --no-alt-orders > $O/sq_pmc_bench.txt 2>&1
 python tools/minibatch_epoch.py > $O/minibatch.log 2>&1; cp gpurun_out/minibatch.json $O/ 2>/dev/null
 python tools/minibatch_breakdown.py > $O/minibatch_breakdown.txt 2>&1
-if [ -z "$FAST" ]; then
+fi
+if [ -z "$FAST" ] && [ "$PART" != "1" ]; then
   OUTDIR=traffic_shuf EXTRA="--shuffle-nodes" tools/collect_traffic.sh > $O/traffic_shuf.log 2>&1
   python tools/traffic_summary.py gpurun_out/traffic_shuf $O/traffic_shuffled.json $(cat .git_head) > $O/traffic_shuffled.txt 2>&1
   for R in 110000 375000 500000 1000000; do python bench.py --reads $R --steps 5 --warmup 2 --no-cpu-baseline --no-alt-orders > $O/train_R$R.json 2>/dev/null; done
