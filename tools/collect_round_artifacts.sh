@@ -48,6 +48,8 @@ import json,sys;b=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$
   { for LL in 1 8; do echo "H = 64, L = $LL"; tools/ab_env.sh GNM_NATIVE_64=1 GNM_NATIVE_64=0 2 --hidden 64 --layers $LL; done; } > $O/h64_padded.txt 2>&1
   OPS="gnm_edge_gate2_fwd gnm_edge_t_fused_fwd" tools/ab_ops.sh "GNM_GATE2_WG=2" "GNM_GATE2_WG=1 GNM_VARIANTS=gate2_wg=1" 2 > $O/ab_gate2_occupancy.txt 2>&1
   python tools/ln_two_sided_ab.py > /dev/null 2>&1; cp gpurun_out/ln_two_sided.txt $O/ 2>/dev/null
+  # the reference's default configuration end to end: mini-batch mode (500 parts, 50 per batch), dim_latent 256, num_gnn_layers 16, the true chr19 size
+  python tools/minibatch_epoch.py --hidden 256 --layers 16 --reads 110000 --epochs 4 > $O/minibatch_h256l16.log 2>&1; cp gpurun_out/minibatch_h256l16.json $O/ 2>/dev/null
   python bench.py --hidden 512 --layers 2 --reads 200000 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-matmul --no-alt-orders > $O/h512_l2_R200k.json 2>/dev/null
   # the schedule by graph size (engine.TN_AT = auto) and kernel tables of the other shapes
   for R in 110000 375000 750000; do echo "R=$R"; tools/ab_env.sh GNM_TN_AT=now GNM_TN_AT=next 2 --reads $R; done > $O/ab_tn_at_sizes.txt 2>&1

@@ -25,11 +25,13 @@ def main():
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--shuffle-nodes", action="store_true")
     ap.add_argument("--method", default="locality")
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=8)     # --hidden 256 --layers 16: the reference's default model (hyperparameters.py:8,13)
     a = ap.parse_args()
     import gnnome_assembly_amd as G
     from gnnome_assembly_amd import cluster, dp, synth
     dev = torch.device("cuda:0")
-    H, L = 128, 8
+    H, L = a.hidden, a.layers
     src, dst, n = synth.make_graph(a.reads, seed=0)
     inp = synth.make_inputs(src, dst, n, seed=0)
     pe_np = inp["pe"]
@@ -91,7 +93,8 @@ def main():
                    "on the device (graph.tensor_index) and run the separate-pass schedule (no sweep plan for device-born graphs)"}
     print(json.dumps(res))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(REPO, "gpurun_out", "minibatch" + ("_shuffled" if a.shuffle_nodes else "") + ".json"), "w") as f:
+    tag = ("_shuffled" if a.shuffle_nodes else "") + (f"_h{H}l{L}" if (H, L) != (128, 8) else "")
+    with open(os.path.join(REPO, "gpurun_out", "minibatch" + tag + ".json"), "w") as f:
         json.dump(res, f, indent=1)
 
 
