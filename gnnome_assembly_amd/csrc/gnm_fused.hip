@@ -2061,6 +2061,45 @@ extern "C" int gnm_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const fl
   return 0;
 }
 
+// The LayerNorm form of gnm_edge_bwd_top (round 6; H = 128, with a sweep plan): gnm_ln_edge_bwd_dst + gnm_ln_edge_bwd_src as ONE two-sided sweep.
+// ge <- ge + gsigma sigma' in place; gt [E,H] = LNbwd(gu) written for gnm_edge_bwd_fused_gt; gP[:, H:5H] = gA2h | gA3h | gB1h | gB2h for the
+// nodes the plan serves (the rest: gnm_ln_edge_bwd_src_fix); partials: (sum gu, sum gu that) = the LayerNorm weight / bias gradient sums.
+// Q is gnm_ln_node_bwd's [N,4H] = Qf | Rf | Qb | Rb.                                   autograd of gated_gcn_full.py:120-143 under nn.LayerNorm
+extern "C" int gnm_ln_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const float* e_out, const float* t, const float* gamma_e,
+                                   const float* beta_e, int width, const float* P, const float* Q, const float* hf, const float* hb,
+                                   const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, float* gP, float* gt,
+                                   double* partials, const uint32_t* sinfo, int64_t plan_nodes_per_block, int* nblk_out, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "ln_edge_bwd_top: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(width >= 1 && width <= H, "ln_edge_bwd_top: width must be in [1, H]");
+  GNM_CHECK_ARG(N > 0 && E > 0 && ge && e_out && t && gamma_e && beta_e && P && Q && hf && hb && isrc && idst && in_ptr && gP && gt &&
+                    partials && sinfo && nblk_out, "ln_edge_bwd_top: null argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "ln_edge_bwd_top: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  int64_t npb = 0;
+  gnm_sweep_partition(N, 1, &npb, nullptr);
+  GNM_CHECK_ARG((npb + 2 * kSweepMargin) * 5 * H * 4 < (int64_t)INT32_MAX, "ln_edge_bwd_top: %lld nodes per workgroup exceed the 32-bit buffer offsets",
+                (long long)npb);
+  GNM_CHECK_ARG(plan_nodes_per_block == npb, "ln_edge_bwd_top: the sweep plan was built for %lld nodes per workgroup, the kernel uses %lld",
+                (long long)plan_nodes_per_block, (long long)npb);
+  ChainArgs a{};
+  a.E = E; a.N = N; a.hfull = H;
+  a.ge = ge; a.ge_out = ge; a.e_mid = e_out;
+  a.slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  a.t_lo = t; a.P_lo = P; a.Q_lo = Q; a.q_pitch = 4 * H; a.qb_off = 2 * H; a.hf_lo = hf; a.hb_lo = hb;
+  a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
+  a.gP_lo = gP; a.Ud_lo = gP + 4 * H; a.Td_lo = gP + 4 * H; a.ud_pitch = 5 * H;     // sum_dst gt = gB2h, straight into its column group
+  a.UT_lo = gP + 3 * H; a.ut_pitch = 5 * H;                                            // sum_src gt = gB1h
+  a.partials_lo = partials;
+  a.sinfo = sinfo; a.margin = kSweepMargin;
+  a.ln_gamma = gamma_e; a.ln_beta = beta_e; a.ln_width = width; a.gt_out = gt;
+  const int g = edge_bwd_chain_launch(a, nullptr, nullptr, (hipStream_t)stream);
+  GNM_CHECK_ARG(g > 0, "ln_edge_bwd_top: no kernel for this configuration");
+  *nblk_out = g;
+  GNM_LAUNCH_CHECK("ln_edge_bwd_top");
+  return 0;
+}
+
 extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
                                   const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
                                   const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,

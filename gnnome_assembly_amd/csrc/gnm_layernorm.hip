@@ -218,6 +218,39 @@ __global__ __launch_bounds__(kBlock) void ln_edge_bwd_src_k(
   }
 }
 
+// the by-source sums of the nodes the sweep plan does not serve (gnm_ln_edge_bwd_top): ln_edge_bwd_src_k over a node list
+template <int H>
+__global__ __launch_bounds__(kBlock) void ln_edge_bwd_src_fix_k(
+    int64_t nfix, const int32_t* __restrict__ fix_nodes, const float* __restrict__ e_out, const float* __restrict__ gt,
+    const float* __restrict__ Q, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos,
+    const int32_t* __restrict__ out_dst, float* __restrict__ gP) {
+  constexpr int G = H / 4, RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / G, c4 = (lane % G) * 4;
+  for (int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave; i < nfix; i += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t v = fix_nodes[i];
+    if (v < 0) continue;                      // a list compacted on the device carries -1 behind its last entry
+    const int a = out_ptr[v], b = out_ptr[v + 1];
+    float4 a2acc = f4(0.f), gts = f4(0.f);
+    for (int64_t m = a + sub; m < b; m += RPW) {
+      const int64_t j = out_pos[m], d = out_dst[m];
+      const float4 sg = sigmoid4(ld4_nt(e_out + j * H + c4));
+      a2acc = fma4(sg, ld4(Q + d * (4 * H) + c4), a2acc);
+      gts += ld4_nt(gt + j * H + c4);
+    }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+      a2acc += shfl_xor4(a2acc, off);
+      gts += shfl_xor4(gts, off);
+    }
+    if (sub == 0) {
+      st4_nt(gP + v * (5 * H) + H + c4, a2acc);
+      st4_nt(gP + v * (5 * H) + 3 * H + c4, gts);
+    }
+  }
+}
+
 }  // namespace gnm
 
 using namespace gnm;
@@ -318,5 +351,22 @@ extern "C" int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_o
                        out_ptr, out_pos, out_dst, gP, cdivl(N, grid));
   });
   GNM_LAUNCH_CHECK("ln_edge_bwd_src");
+  return 0;
+}
+
+extern "C" int gnm_ln_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int64_t N, int64_t E, int H, const float* e_out,
+                                       const float* gt, const float* Q, const int32_t* out_ptr, const int32_t* out_pos,
+                                       const int32_t* out_dst, float* gP, void* stream) {
+  GNM_CHECK_ARG(nfix >= 0 && (nfix == 0 || fix_nodes) && N >= 0 && E >= 0 && e_out && gt && Q && out_ptr && out_pos && out_dst && gP,
+                "ln_edge_bwd_src_fix: null/neg argument");
+  if (nfix == 0) return 0;
+  GNM_DISPATCH_H(H, {
+    int64_t grid = cdivl(nfix, kWavesPerBlock);
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(ln_edge_bwd_src_fix_k<HH>, dim3((int)grid), dim3(kBlock), 0, (hipStream_t)stream, nfix, fix_nodes, e_out, gt, Q,
+                       out_ptr, out_pos, out_dst, gP);
+  });
+  GNM_LAUNCH_CHECK("ln_edge_bwd_src_fix");
   return 0;
 }

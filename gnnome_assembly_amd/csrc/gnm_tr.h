@@ -230,6 +230,12 @@ struct ChainArgs {
   // Ud_lo / Td_lo may be the two halves of ONE [N,2H] array (ud_pitch = 2H) or two [N,H] arrays (ud_pitch = H)
   const uint32_t* sinfo; float* UT_lo; int64_t margin; int ud_pitch;
   int hfull;       // row pitch of the layer-(i-1) tensors (0 / 128: 128; 256: the top sweep of a 256-wide layer, one half per launch)
+  // round 6, the LayerNorm form of the sweep without a layer above (edge_bwd_chain_k<..., LN>; gnm_ln_edge_bwd_top): row statistics
+  // instead of stat_lo, gt = LNbwd(gu) formed per row and WRITTEN (gt_out), the sums by destination / by source are gB2h / gB1h
+  // themselves (no BatchNorm-backward means to wait for)
+  const float* ln_gamma; const float* ln_beta; int ln_width; float* gt_out;
+  int ut_pitch;    // row pitch of UT_lo (0: 2 H = [Us | Ts]); the LayerNorm form sends its by-source sum of gt straight into gP[:, 3H:4H]
+  int q_pitch, qb_off;   // Q_lo row pitch and the offset of Qb in a row (0, 0: 2 H and H = [Qf | Qb]; gnm_ln_node_bwd writes Qf | Rf | Qb | Rb: 4 H, 2 H)
 };
 
 // tn_tr_k<., CONV> (gnm_tr.hip): the two column groups of the A operand are formed from raw sums

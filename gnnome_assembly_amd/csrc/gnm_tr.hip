@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "gnm_tr.h"
+#include "gnm_ln.h"
 
 namespace gnm {
 
@@ -775,11 +776,16 @@ struct W3Frag16 { bf16x8 w[SW / 32][3]; };     // 16 output columns of W3: [kc][
 // keeps one unit across rows through this workgroup's reference exponent, exactly as tn_tr_k<., ., true> (see there): rows staged
 // with the reference of the tiles before, the tile's own maximum taken by every wave after the staging barrier, a tile with a row
 // 2^10 above the reference staged again (gt stays in registers until then, the e row is still in its prefetch registers).
-template <int ABL, bool SRC, bool WSKIP = true, bool HI = true, int HF = SW, bool H2 = false>
+// LN (round 6; HI = false, SRC, HF = 128): the LayerNorm form of the sweep without a layer above.  The row statistics are taken by the 32 lanes
+// that hold the row (gnm_ln.h, the expressions of ln_edge_bwd_dst_k); gt = LNbwd(gu) is complete inside the row, so it is formed here, written
+// once for the fused edge pass (gnm_edge_bwd_fused_gt) and summed by destination (the "Ud" walker -> gB2h) and by source (the "Us" run sums
+// -> gB1h) directly; the "Td" / "Ts" sums do not exist; the column sums (sum gu, sum gu that) are the LayerNorm weight / bias gradients.
+template <int ABL, bool SRC, bool WSKIP = true, bool HI = true, int HF = SW, bool H2 = false, bool LN = false>
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   static_assert(HF == SW || !HI, "the chained (matrix) half of the kernel is built for 128-wide layers only");
   static_assert(HI || !H2, "f16x2 belongs to the matrix half");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[SRC ? CH_LDS_SRC : CH_LDS];
+  static_assert(!LN || (!HI && SRC && HF == SW), "the LayerNorm sweep: no layer above, two-sided, 128 wide");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(SRC ? CH_LDS_SRC : CH_LDS) + (LN ? ER * SW * 4 : 0)];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
   float* og = reinterpret_cast<float*>(lds + 6 * EIMG);                  // residual ge rows, then ge + gt W3 (row layout)
@@ -794,6 +800,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   unsigned* si = reinterpret_cast<unsigned*>(sd + 3 * 2 * ER);           // SRC: ring of 3 tiles x [plan word 16]
   float* v5 = reinterpret_cast<float*>(si + 3 * ER);                     // SRC: sigma * Qf[dst]
   float* slots = v5 + ER * SW;                                           // SRC: [3 sums][kSweepSlots][128]
+  float* v6 = slots + 3 * kSweepSlots * SW;                              // LN: gu (v2 holds gt there)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lg = lane >> 5;
@@ -814,10 +821,15 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       cs[5 * SW + c] = a.bstat_hi[SW + c];
       cs[6 * SW + c] = a.gamma_hi[c] * a.stat_hi[SW + c];
     }
-    cl[c] = a.stat_lo[c];
-    cl[SW + c] = a.stat_lo[HF + c];
-    cl[2 * SW + c] = a.stat_lo[2 * HF + c];
-    cl[3 * SW + c] = a.stat_lo[3 * HF + c];
+    if constexpr (LN) {
+      cl[2 * SW + c] = a.ln_gamma[c];
+      cl[3 * SW + c] = a.ln_beta[c];
+    } else {
+      cl[c] = a.stat_lo[c];
+      cl[SW + c] = a.stat_lo[HF + c];
+      cl[2 * SW + c] = a.stat_lo[2 * HF + c];
+      cl[3 * SW + c] = a.stat_lo[3 * HF + c];
+    }
   }
   W3Frag16 wf;
   h16x8 wfh[H2 ? SW / 32 : 1][2];           // H2: 16 output columns of W3 s_n: [kc][hi/lo] = 32 VGPRs
@@ -861,7 +873,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   // the expensive part) are taken beside them by threads 128-255 (waves 2 and 3), four rows of a tile each.
   // (round 3: one role per WAVE -- lanes 0-31 of waves 0, 1, 2 -- so that the walkers' output is a wave-uniform buffer
   //  resource; the BatchNorm sums moved to waves 4-7)
-  const bool walker = wave < 3 && lane < 32, bnsum = tid >= 256;   // BatchNorm sums: waves 4-7, two rows of a tile each
+  const bool walker = wave < 3 && lane < 32 && !(LN && wave == 1), bnsum = tid >= 256;   // BatchNorm sums: waves 4-7, two rows of a tile each (LN: no Td)
   const int role = wave, wc4 = (tid & 31) * 4;
   const int brow = 2 * ((tid - 256) >> 5);                         // first of this thread's two rows (0, 2, .. 14)
   int cur = -1;                             // node whose segment is being summed (wave-uniform)
@@ -883,8 +895,12 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   const int nspan = (int)(v1n - v0 + 2 * a.margin);
   const __amdgpu_buffer_rsrc_t srs_g = __builtin_amdgcn_make_buffer_rsrc(
       SRC ? a.gP_lo + vbase * (5 * HF) + HF : a.gP_lo, 0, SRC ? nspan * 5 * HF * 4 : 0, 0x00020000);
+  const int utp = a.ut_pitch ? a.ut_pitch : 2 * HF;                  // row pitch of the by-source sums' array
   const __amdgpu_buffer_rsrc_t srs_u = __builtin_amdgcn_make_buffer_rsrc(
-      SRC ? a.UT_lo + vbase * (2 * HF) : a.gP_lo, 0, SRC ? nspan * 2 * HF * 4 : 0, 0x00020000);
+      SRC ? a.UT_lo + vbase * utp : a.gP_lo, 0, SRC ? nspan * utp * 4 : 0, 0x00020000);
+  const int qp = a.q_pitch ? a.q_pitch : 2 * HF, qbo = a.q_pitch ? a.qb_off : HF;      // Q_lo row layout (see ChainArgs)
+  const float4 ln_live = LN ? live_mask((tid & 31) * 4, a.ln_width) : f4(1.f);
+  const float ln_inv_w = LN ? 1.0f / (float)a.ln_width : 0.f;
   __syncthreads();
 
   float4 pg, pt, pe_, pl;                    // the next tile's row of ge'(i), t(i), e_out(i-1), t(i-1)
@@ -924,9 +940,9 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   };
   auto gather = [&](int64_t s, int64_t d) __attribute__((always_inline)) {   // node rows of the edge s -> d
     ga2 = ld4(a.P_lo + s * (5 * HF) + HF + lc4);
-    gqb = ld4(a.Q_lo + s * (2 * HF) + HF + lc4);
+    gqb = ld4(a.Q_lo + s * qp + qbo + lc4);
     ghb = ld4(a.hb_lo + s * HF + lc4);
-    gqf = ld4(a.Q_lo + d * (2 * HF) + lc4);
+    gqf = ld4(a.Q_lo + d * qp + lc4);
     ghf = ld4(a.hf_lo + d * HF + lc4);
     ga3 = ld4(a.P_lo + d * (5 * HF) + 2 * HF + lc4);
   };
@@ -946,6 +962,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     // steady-state iteration leaves behind -- row loads | 1 store | 16 walker stores (threads 0-95) | 6 gathers -- so that phase 0
     // waits with a COUNTED vmcnt for the row loads only and the gathers / stores stay in flight.
     st4(dummy_row, f4(0.f));
+    if constexpr (LN) st4(dummy_row + SW * 17, f4(0.f));          // the LayerNorm form stores two rows per tile (ge_tot, gt)
     if (walker) {
 #pragma unroll
       for (int r = 0; r < ER; ++r) st4(dummy_row + SW * (1 + r), f4(0.f));
@@ -1119,8 +1136,23 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       const bool live = row < nvalid;        // rows past the chunk repeat its last row's indices: their terms are zeroed HERE
       st4_nt(live ? a.ge_out + (r0 + row) * HF + lc4 : dummy_row, g);
       st4(v1 + row * SW + lc4, live ? sg * gqb : f4(0.f));
-      st4(v2 + row * SW + lc4, live ? gate4(fma4(tt, sc, sh), g) : f4(0.f));
-      st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
+      if constexpr (LN) {
+        // ln_edge_bwd_dst_k's arithmetic: that and rstd from the row's own statistics, gt = LNbwd(gu) complete inside the row
+        float rstd;
+        const float4 th = row_normalize<SW>(tt, ln_live, ln_inv_w, rstd);
+        const float4 gu = gate4(fma4(th, sc, sh), g);               // sc = gamma, sh = beta
+        const float4 ag = sc * gu;
+        const float m1r = row_sum<32>(hsum4(ag)) * ln_inv_w;
+        const float m2r = row_sum<32>(hsum4(ag * th)) * ln_inv_w;
+        const float4 gtv = (ag - f4(m1r) * ln_live - th * m2r) * rstd;
+        st4_nt(live ? a.gt_out + (r0 + row) * HF + lc4 : dummy_row + SW * 17, gtv);
+        st4(v2 + row * SW + lc4, live ? gtv : f4(0.f));
+        st4(v3 + row * SW + lc4, live ? th : f4(0.f));
+        st4(v6 + row * SW + lc4, live ? gu : f4(0.f));
+      } else {
+        st4(v2 + row * SW + lc4, live ? gate4(fma4(tt, sc, sh), g) : f4(0.f));
+        st4(v3 + row * SW + lc4, live ? (tt - mu) * rs : f4(0.f));
+      }
       if constexpr (SRC) st4(v5 + row * SW + lc4, live ? sg * gqf : f4(0.f));
     }
     __syncthreads();   // per-edge terms of the tile are in v1 / v2 / v3
@@ -1164,7 +1196,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     if (!(ABL & 1) && bnsum) {                       // LDS reads and fp64 arithmetic only (rows past the chunk hold zeros)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const float4 x = ld4(v2 + (brow + q) * SW + wc4);
+        const float4 x = ld4((LN ? v6 : v2) + (brow + q) * SW + wc4);
         const float4 th = ld4(v3 + (brow + q) * SW + wc4);
         s_gu[0] += (double)x.x; s_gu[1] += (double)x.y; s_gu[2] += (double)x.z; s_gu[3] += (double)x.w;
         s_gut[0] += (double)x.x * (double)th.x; s_gut[1] += (double)x.y * (double)th.y;
@@ -1225,11 +1257,11 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
           const bool out = lead && (w[u] & kSweepClose);
           const int sn = sdk[rr[u]] - (int)vbase;
           const int og_ = out ? (sn * (5 * HF) + wc4) * 4 : (int)0x80000000;
-          const int ou_ = out ? (sn * (2 * HF) + wc4) * 4 : (int)0x80000000;
+          const int ou_ = out ? (sn * utp + wc4) * 4 : (int)0x80000000;
           if (!(ABL & 16) && __builtin_amdgcn_ballot_w64(out) != 0) {
             __builtin_amdgcn_raw_buffer_store_b128(bits4(s1[u]), srs_g, og_, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(bits4(s2[u]), srs_u, ou_, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(bits4(s3[u]), srs_u, ou_, HF * 4, 0);
+            if constexpr (!LN) __builtin_amdgcn_raw_buffer_store_b128(bits4(s3[u]), srs_u, ou_, HF * 4, 0);
           }
         }
       }
@@ -1348,6 +1380,11 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
   }
 #endif
   if (!a.t_hi) {                                     // top of the stack: the sweep without a layer above
+    if (a.ln_gamma) {                                // ... in its LayerNorm form (two-sided only)
+      if (!a.sinfo || !a.gt_out || !a.ln_beta) return -1;
+      hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, false, SW, false, true>), dim3(grid), dim3(CT), 0, st, a);
+      return grid;
+    }
     if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, false>), dim3(grid), dim3(CT), 0, st, a);
     else hipLaunchKernelGGL((edge_bwd_chain_k<0, false, true, false>), dim3(grid), dim3(CT), 0, st, a);
     return grid;

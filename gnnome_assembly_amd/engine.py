@@ -39,12 +39,12 @@ _D_ACTIVATIONS = os.environ.get("GNM_ACTIVATIONS", "saved").strip().lower()
 
 
 _OPTION_NAMES = ("FUSED", "ACTIVATIONS", "CHAIN", "TN_SIDE", "TN_SIDE_CAP", "SRC_SIDE_CAP", "TN_AT", "TN_SPLIT", "TWO_SIDED", "TWO_SIDED_FWD", "WIDE_FUSED",
-                 "NODE_FUSED")
+                 "NODE_FUSED", "LN_SWEEP")
 
 
 class Options:
     """The schedule switches of a pass (FUSED, ACTIVATIONS, CHAIN, TN_SIDE, TN_SIDE_CAP, SRC_SIDE_CAP, TN_AT, TN_SPLIT, TWO_SIDED,
-    TWO_SIDED_FWD, WIDE_FUSED, NODE_FUSED; what each selects is described where its default is defined below) as ONE immutable
+    TWO_SIDED_FWD, WIDE_FUSED, NODE_FUSED, LN_SWEEP; what each selects is described where its default is defined below) as ONE immutable
     object.  They choose between schedules that compute the same thing (tests and bench.py A/B them).  model_forward /
     layer_forward read the object that is current in the calling thread -- `current()`: the innermost `with options(...)` /
     `with use(opts)` of THIS thread, else the process defaults (environment, `set_default`) -- and the autograd functions of
@@ -745,12 +745,24 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
               _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), _ptr(sc.partials), C.byref(nblk), lnw, st)
         _, g["gamma_h"], g["beta_h"] = bn_bwd_finalize(sc.partials, nblk.value, N, H, dev, out.get("gamma_h"), out.get("beta_h"))
         gt = torch.empty(E, H, **f32)
-        _call("gnm_ln_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(prm.gamma_e), _ptr(prm.beta_e),
-              _ptr(ge), _ptr(s.P), _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt),
-              _ptr(sc.partials), C.byref(nblk), lnw, st)
-        _, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
-        _call("gnm_ln_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q), _ptr(idx["out_ptr"]),
-              _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
+        if plan is not None and H == 128 and current().TWO_SIDED and current().LN_SWEEP:
+            # round 6: by-destination AND by-source sums from ONE two-sided sweep (the LayerNorm form of the top sweep: gt is complete
+            # inside a row, so gB1h / gB2h come out of the sweep directly), then the plan's unserved sources by gathers
+            need_f = lib.gnm_edge_bwd_fused_workspace_bytes()
+            ws = sc.ws(need_f)
+            _call("gnm_ln_edge_bwd_top", N, E, H, _ptr(ge), _ptr(s.e_out), _ptr(s.t), _ptr(prm.gamma_e), _ptr(prm.beta_e), lnw,
+                  _ptr(s.P), _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt),
+                  _ptr(sc.partials), _ptr(plan["sinfo"]), plan["nodes_per_block"], C.byref(nblk), _ptr(ws), need_f, st)
+            _call("gnm_ln_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q),
+                  _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
+            _, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
+        else:
+            _call("gnm_ln_edge_bwd_dst", N, E, H, _ptr(s.e_out), _ptr(s.t), _ptr(prm.gamma_e), _ptr(prm.beta_e),
+                  _ptr(ge), _ptr(s.P), _ptr(Q), _ptr(idx["isrc"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt),
+                  _ptr(sc.partials), C.byref(nblk), lnw, st)
+            _, g["gamma_e"], g["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, out.get("gamma_e"), out.get("beta_e"))
+            _call("gnm_ln_edge_bwd_src", N, E, H, _ptr(s.e_out), _ptr(gt), _ptr(Q), _ptr(idx["out_ptr"]),
+                  _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP), st)
         del Q
         if fused and Hin == H and _lib.split_mode():
             # round 6: gW3 = gt^T e_in, gb3 = sum gt and ge_in = ge + gt W3 from ONE pass over gt, ge, e_in (the fused edge backward
@@ -881,6 +893,9 @@ _D_WIDE_FUSED = os.environ.get("GNM_WIDE_FUSED", "1") != "0"
 # (gnm_tn128_bgrad, which also writes them for the projection backward behind it), the BatchNorm_h backward sums of the layer
 # below in the epilogue of the projection backward (gnm_node_proj_bwd_nn_stats).  GNM_NODE_FUSED=0: the round-4 schedule.
 _D_NODE_FUSED = os.environ.get("GNM_NODE_FUSED", "1") != "0"
+# Round 6, LayerNorm models at H = 128 with a sweep plan: the backward's by-destination and by-source passes as ONE two-sided sweep
+# (gnm_ln_edge_bwd_top + gnm_ln_edge_bwd_src_fix).  GNM_LN_SWEEP=0: gnm_ln_edge_bwd_dst + gnm_ln_edge_bwd_src.
+_D_LN_SWEEP = os.environ.get("GNM_LN_SWEEP", "1") != "0"
 
 
 def tn128(N: int, A: torch.Tensor, lda: int, ncg: int, h: torch.Tensor, W, b, partials, ws, need, stream=None, tag: str = None):
@@ -1374,7 +1389,7 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     chained = None
     # layer-by-layer backward on the two-sided sweep (the chained schedule's top-layer kernel for every layer): H = 256, and H = 128
     # where the chained schedule does not apply (fp32-MFMA matmul mode, GNM_CHAIN=0)
-    plan_w = graph.sweep_plan(dev) if (batch_norm and sweep_width(H) and current().TWO_SIDED and not chain_eligible(H, batch_norm)
+    plan_w = graph.sweep_plan(dev) if (sweep_width(H, batch_norm) and current().TWO_SIDED and not chain_eligible(H, batch_norm)
                                        and hasattr(graph, "sweep_plan")) else None
     if chain_eligible(H, batch_norm):
         plan = graph.sweep_plan(dev) if current().TWO_SIDED and hasattr(graph, "sweep_plan") else None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 7   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed, gnm_ln_edge_gate2_fwd; 7: gnm_edge_bwd_fused_gt (gt given: the LayerNorm backward's fused edge pass), gnm_debug_set_variant("gate2_wg") */
+#define GNM_ABI_VERSION 7   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed, gnm_ln_edge_gate2_fwd; 7: gnm_edge_bwd_fused_gt (gt given: the LayerNorm backward's fused edge pass), gnm_ln_edge_bwd_top / gnm_ln_edge_bwd_src_fix (its two-sided sweep), gnm_debug_set_variant("gate2_wg") */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -275,6 +275,18 @@ int gnm_ln_edge_bwd_dst(int64_t N, int64_t E, int H, const float* e_out, const f
 int gnm_ln_edge_bwd_src(int64_t N, int64_t E, int H, const float* e_out, const float* gt, const float* Q,
                         const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst,
                         float* gP, void* stream);
+/* round 6 (ABI 7), H = 128 with a sweep plan: gnm_ln_edge_bwd_dst + gnm_ln_edge_bwd_src as ONE two-sided sweep (the LayerNorm form of
+ * gnm_edge_bwd_top): ge <- ge + gsigma sigma' in place, gt [E,H] written for gnm_edge_bwd_fused_gt, gP[:, H:5H] = gA2h | gA3h | gB1h | gB2h
+ * of the nodes the plan serves, partials = (sum gu, sum gu that); then the plan's unserved sources by gathers.  Q = gnm_ln_node_bwd's [N,4H].
+ * ws >= gnm_edge_bwd_fused_workspace_bytes().                        autograd of gated_gcn_full.py:120-143 under nn.LayerNorm (:57-59) */
+int gnm_ln_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const float* e_out, const float* t, const float* gamma_e,
+                        const float* beta_e, int width, const float* P, const float* Q, const float* hf, const float* hb,
+                        const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, float* gP, float* gt,
+                        double* partials, const uint32_t* sinfo, int64_t plan_nodes_per_block, int* nblk_out, void* ws,
+                        size_t ws_bytes, void* stream);
+int gnm_ln_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int64_t N, int64_t E, int H, const float* e_out,
+                            const float* gt, const float* Q, const int32_t* out_ptr, const int32_t* out_pos,
+                            const int32_t* out_dst, float* gP, void* stream);
 
 /* ---- fused W-stationary MFMA kernels (H = 128 only; other H use the unfused entry points) ---
  * edge_t_fused_fwd: t = e_in W3^T + b3 + B1h[isrc] + B2h[idst] and the BatchNorm partials in ONE

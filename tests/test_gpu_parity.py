@@ -1689,6 +1689,60 @@ def _adversarial_graphs():
 
 
 @pytest.mark.default_mode_only
+@pytest.mark.parametrize("ids", ["generator", "shuffled"])
+def test_layernorm_two_sided_backward_sweep_matches_the_separate_passes(ids):
+    """Round 6, batch_norm=False at H = 128: gnm_ln_edge_bwd_top + gnm_ln_edge_bwd_src_fix (the LayerNorm form of the two-sided top
+    sweep: by-destination AND by-source sums of one pass, gt complete inside its row) against gnm_ln_edge_bwd_dst + gnm_ln_edge_bwd_src.
+    The forward is the same under both switches, so the gradients differ by summation order only: every tensor within 1e-5 rel-L2 (or
+    under the absolute floor), two runs of the sweep bit-identical.  Also with a zero-padded width (96 -> 128: dead channels stay out of
+    the row statistics inside the sweep too)."""
+    import gnnome_assembly_amd as G
+    from gnnome_assembly_amd import engine, synth
+    dev = _dev()
+    for H in (128, 96):
+        L, seed = 3, 13
+        src, dst, n = synth.make_graph(16000, seed)
+        inp = synth.make_inputs(src, dst, n, seed)
+        pe_np = inp["pe"]
+        if ids == "shuffled":
+            p = np.random.default_rng(5).permutation(n).astype(np.int32)
+            src, dst = p[src], p[dst]
+            pe_s = np.empty_like(pe_np)
+            pe_s[p] = pe_np
+            pe_np = pe_s
+        model = G.GraphGatedGCNModel(1, 2, H, 16, L, 64, False, 16)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(H, L, seed).items()})
+        model.to(dev)
+        g = G.AssemblyGraph(src, dst, n).to(dev)
+        e, pe, y = torch.from_numpy(inp["e"]).to(dev), torch.from_numpy(pe_np).to(dev), torch.from_numpy(inp["y"]).to(dev)
+        crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
+        assert g.sweep_plan(dev, 1) is not None
+
+        def run(sweep):
+            with engine.options(LN_SWEEP=sweep):
+                model.zero_grad(set_to_none=True)
+                s = model(g, None, e, pe)
+                loss = crit(s.squeeze(-1), y)
+                loss.backward()
+                torch.cuda.synchronize()
+                return s.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters()}
+        s0, g0 = run(False)
+        s1, g1 = run(True)
+        s2, g2 = run(True)
+        assert torch.equal(s0, s1) and torch.equal(s1, s2), "the forward does not depend on the backward's schedule"
+        assert all(torch.equal(g1[k], g2[k]) for k in g1), "the sweep is not run-to-run deterministic"
+        gmax = max(float(v.abs().max()) for v in g0.values())
+        worst = 0.0
+        for k in g0:
+            a, b = g1[k].double(), g0[k].double()
+            rr = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            ok = rr <= 1e-5 or float((a - b).abs().max()) <= 1e-6 * gmax
+            worst = max(worst, rr if float(b.norm()) > 1e-6 * gmax else 0.0)
+            assert ok, (H, k, rr, float((a - b).abs().max()), gmax)
+        print(f"LayerNorm two-sided backward sweep vs separate passes [{ids}, H = {H}]: worst gradient rel_l2 = {worst:.2e}")
+
+
+@pytest.mark.default_mode_only
 @pytest.mark.parametrize("H", [128, 256])
 def test_two_sided_sweeps_on_graphs_without_a_band(H):
     """(H = 256: the same sweeps once per 128-column half, row pitch 256.)
