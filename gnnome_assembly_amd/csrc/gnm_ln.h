@@ -8,10 +8,32 @@ namespace gnm {
 
 constexpr float kEpsLN = 1e-5f;   // nn.LayerNorm default
 
+// Sum over the G consecutive lanes that hold one row (G = H / 4), the total in every one of them.
+// Round 6: the butterfly v += xor-partner(v) was five ds_bpermute_b32 round trips through the LDS crossbar per sum (hipcc's __shfl_xor), four
+// sums per row in the backward -- the reason the LayerNorm sweeps ran 15-25 % behind their BatchNorm twins.  The same butterfly on the
+// data-parallel primitives: quad_perm / row_half_mirror / row_mirror (a DPP operand of the add) inside a 16-lane row, gfx950's
+// v_permlane16_swap across the two rows of a 32-lane group.  Every step adds the same two partial sums as the xor butterfly did (after a
+// step all lanes of a group hold the group's sum, so "the mirrored lane" and "the xor partner" carry the same value) and fp32 addition is
+// commutative: bit-identical results.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+  return v + __builtin_bit_cast(float, o);
+}
 template <int G>
 __device__ __forceinline__ float row_sum(float v) {
-#pragma unroll
-  for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "a row is held by 8, 16, 32 or 64 lanes");
+  v = dpp_add_f32<0xB1>(v);                    // quad_perm [1,0,3,2]
+  v = dpp_add_f32<0x4E>(v);                    // quad_perm [2,3,0,1]
+  v = dpp_add_f32<0x141>(v);                   // row_half_mirror: the other quad of the 8
+  if constexpr (G >= 16) v = dpp_add_f32<0x140>(v);      // row_mirror: the other 8 of the 16
+  if constexpr (G >= 32) {
+    typedef unsigned u32x2_ln_ __attribute__((ext_vector_type(2)));
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    const u32x2_ln_ sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);     // (rows 0 0 2 2, rows 1 1 3 3)
+    v = __builtin_bit_cast(float, sw.x) + __builtin_bit_cast(float, sw.y);
+  }
+  if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float hsum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }

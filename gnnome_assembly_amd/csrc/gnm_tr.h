@@ -86,6 +86,27 @@ __device__ __forceinline__ unsigned row32_max_bits(unsigned m) {
 __device__ __forceinline__ unsigned max_abs4_bits(const float4& v) {
   return __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
+// max of a SIGNED int over the 16 lanes of a DPP row / over 32 consecutive lanes (the tile-wide largest EA + EB of the f16x2 TN scheme: every
+// 16- or 32-lane group holds all the tile's rows, so every wave ends with the same number).  Round 6: these were __shfl_xor butterflies =
+// four or five dependent ds_bpermute_b32 round trips per tile and wave.
+template <int CTRL>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ int row16_max_i32(int m) {
+  m = dpp_max_i32<0xB1>(m);
+  m = dpp_max_i32<0x4E>(m);
+  m = dpp_max_i32<0x141>(m);
+  return dpp_max_i32<0x140>(m);
+}
+__device__ __forceinline__ int row32_max_i32(int m) {
+  m = row16_max_i32(m);
+  typedef unsigned u32x2i_ __attribute__((ext_vector_type(2)));
+  const u32x2i_ sw = __builtin_amdgcn_permlane16_swap((unsigned)m, (unsigned)m, false, false);
+  const int a = (int)sw.x, b = (int)sw.y;
+  return a > b ? a : b;
+}
 // s = 2^(14 - floor(log2 m)), inv = 1 / s; magnitudes below 2^-111 (and zero rows) share s = 2^125
 __device__ __forceinline__ void h2_scale(unsigned mbits, float& s, float& inv) {
   int e = (int)(mbits >> 23) & 0xff;

@@ -142,9 +142,7 @@ __global__ __launch_bounds__(kBlock, OCC) void tn_tr_k(int64_t M, const float* _
     int Rnext = Rref;
     if constexpr (H2) {
       // the tile's largest EA + EB: lane l holds row l & 31's, the maximum over the wave is the same number in every wave
-      int m = rexp[lane & 31];
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) { const int x = __shfl_xor(m, o); m = x > m ? x : m; }
+      const int m = row32_max_i32(rexp[lane & 31]);
       const bool redo = rexp[TRR] != 0;       // (uniform: written before the barrier)
       if (redo) {                             // rare: the tile is staged again in the unit of its own maximum
         const float f = pow2_biased(127 + (Rref == kNoRef ? -127 : Rref - m));      // the accumulators so far move to it (<= 1, exact)
@@ -506,9 +504,7 @@ __global__ __launch_bounds__(kBlock, 2) void edge_bwd_tr_k(
     __syncthreads();   // images and residual rows ready
     int Rnext = Rref;
     if constexpr (H2) {
-      int m = rexp[lane & (ER - 1)];
-#pragma unroll
-      for (int o = 1; o < ER; o <<= 1) { const int x = __shfl_xor(m, o); m = x > m ? x : m; }
+      const int m = row16_max_i32(rexp[lane & (ER - 1)]);
       if (rexp[2 * ER] != 0) {                    // rare: the tile is staged again in the unit of its own maximum
         const float f = pow2_biased(127 + (Rref == kNoRef ? -127 : Rref - m));
 #pragma unroll
@@ -1013,9 +1009,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
     __syncthreads();   // images, residual rows, the next tile's indices ready
     int Rnext = Rref;
     if constexpr (H2) {
-      int m = rexp[lane & (ER - 1)];              // the tile's largest EA + EB: the same number in every wave
-#pragma unroll
-      for (int o = 1; o < ER; o <<= 1) { const int x = __shfl_xor(m, o); m = x > m ? x : m; }
+      const int m = row16_max_i32(rexp[lane & (ER - 1)]);     // the tile's largest EA + EB: the same number in every wave
       if (rexp[2 * ER] != 0) {                    // rare (the first tile; a three-decade jump): staged again in the unit of its own maximum
         const float f = pow2_biased(127 + (Rref == kNoRef ? -127 : Rref - m));
 #pragma unroll
