@@ -79,6 +79,8 @@ SIGNATURES = {
     "gnm_edge_bwd_fused": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_edge_bwd_fused_gt": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gnm_ln_edge_bwd_top": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _sz, _p]),
+    "gnm_ln_edge_bwd_chain": (_i32, [_i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64,
+                                     _p, _p, _sz, _p]),
     "gnm_ln_edge_bwd_src_fix": (_i32, [_i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_encoder_fwd": (_i32, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gnm_edge_encoder_bwd_workspace_bytes": (_sz, []),

@@ -204,8 +204,6 @@ class ClusterBatchLoader:
             # looked up at every hand-over: whatever stream is current in the caller when it asks for a batch is the one that
             # waits for the build and that the batch's tensors are recorded on
             with torch.cuda.device(dev):
-                consumer = torch.cuda.current_stream(dev)
-                side.wait_stream(consumer)          # parent features written on the caller's stream since the last batch are visible
                 with torch.cuda.stream(side):
                     sub = self._build(ids)
                     sub.index(dev)
@@ -223,6 +221,12 @@ class ClusterBatchLoader:
                 for t in _graph_tensors(sub):
                     t.record_stream(consumer)
             return sub
+        # The side stream waits for the caller's stream ONCE, here: the parent graph's tensors as they are when the iteration starts.
+        # (Waiting before every build -- tried in round 6 on ADVICE r5 -- makes build k+1 wait for batch k's training kernels: the overlap
+        # this loader exists for is gone, 43 -> 38 M edges/s on the mini-batch epoch.)  The contract instead: the parent's ndata / edata
+        # are read-only while its batches are being iterated, as in the reference's loop (train.py:296-343 only reads them).
+        with torch.cuda.device(dev):
+            side.wait_stream(torch.cuda.current_stream(dev))
         nxt = build(batches[0]) if batches else None
         for k in range(len(batches)):
             sub = hand_over(*nxt)

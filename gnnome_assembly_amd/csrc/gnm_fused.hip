@@ -2100,6 +2100,51 @@ extern "C" int gnm_ln_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const
   return 0;
 }
 
+// The CHAINED LayerNorm backward (round 6; H = 128, split matmul modes, with a sweep plan): gnm_edge_bwd_fused_gt of layer i (its gt GIVEN:
+// gt_hi, written by layer i's own sweep a launch earlier) and gnm_ln_edge_bwd_top of layer i-1 in one sweep -- read ge'(i), gt(i),
+// e_mid = e_in(i) = e_out(i-1), t(i-1); write ge'(i-1) (in place) and gt(i-1): 6 [E,H] streams instead of 4 + 5.
+extern "C" int gnm_ln_edge_bwd_chain(int64_t N, int64_t E, int H, float* ge, const float* gt_hi, const float* e_mid, const float* W3_hi,
+                                     float* gW3_hi, float* gb3_hi, double* partials_hi, const float* t_lo, const float* gamma_lo,
+                                     const float* beta_lo, int width, const float* P_lo, const float* Q_lo, const float* hf_lo,
+                                     const float* hb_lo, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, float* gP_lo,
+                                     float* gt_lo, double* partials_lo, const uint32_t* sinfo, int64_t plan_nodes_per_block,
+                                     int* nblk_out, void* ws, size_t ws_bytes, void* stream) {
+  GNM_CHECK_ARG(H == FH, "ln_edge_bwd_chain: H=%d (only 128 is built)", H);
+  GNM_CHECK_ARG(g_matmul_mode >= 1, "ln_edge_bwd_chain: only built for the split matmul modes");
+  GNM_CHECK_ARG(width >= 1 && width <= H, "ln_edge_bwd_chain: width must be in [1, H]");
+  GNM_CHECK_ARG(N > 0 && E > 0 && ge && gt_hi && e_mid && W3_hi && gW3_hi && gb3_hi && partials_hi && t_lo && gamma_lo && beta_lo && P_lo &&
+                    Q_lo && hf_lo && hb_lo && isrc && idst && in_ptr && gP_lo && gt_lo && partials_lo && sinfo && nblk_out &&
+                    partials_hi != partials_lo && gt_hi != gt_lo, "ln_edge_bwd_chain: null / aliased argument");
+  GNM_CHECK_ARG(ws && ws_bytes >= gnm_edge_bwd_fused_workspace_bytes(), "ln_edge_bwd_chain: workspace %zu < %zu", ws_bytes,
+                gnm_edge_bwd_fused_workspace_bytes());
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)((char*)ws + gnm_rowtile_workspace_bytes(FH));
+  int64_t npb = 0;
+  gnm_sweep_partition(N, 1, &npb, nullptr);
+  GNM_CHECK_ARG((npb + 2 * kSweepMargin) * 5 * FH * 4 < (int64_t)INT32_MAX, "ln_edge_bwd_chain: %lld nodes per workgroup exceed the 32-bit buffer offsets",
+                (long long)npb);
+  GNM_CHECK_ARG(plan_nodes_per_block == npb, "ln_edge_bwd_chain: the sweep plan was built for %lld nodes per workgroup, the kernel uses %lld",
+                (long long)plan_nodes_per_block, (long long)npb);
+  ChainArgs a{};
+  a.E = E; a.N = N; a.hfull = H;
+  a.ge = ge; a.ge_out = ge; a.t_hi = gt_hi; a.e_mid = e_mid;
+  a.slab = slab; a.partials = partials_hi;
+  a.t_lo = t_lo; a.P_lo = P_lo; a.Q_lo = Q_lo; a.q_pitch = 4 * H; a.qb_off = 2 * H; a.hf_lo = hf_lo; a.hb_lo = hb_lo;
+  a.isrc = isrc; a.idst = idst; a.in_ptr = in_ptr;
+  a.gP_lo = gP_lo; a.Ud_lo = gP_lo + 4 * H; a.Td_lo = gP_lo + 4 * H; a.ud_pitch = 5 * H;
+  a.UT_lo = gP_lo + 3 * H; a.ut_pitch = 5 * H;
+  a.partials_lo = partials_lo;
+  a.sinfo = sinfo; a.margin = kSweepMargin;
+  a.ln_gamma = gamma_lo; a.ln_beta = beta_lo; a.ln_width = width; a.gt_out = gt_lo;
+  const int grid = edge_bwd_chain_launch(a, W3_hi, ws, st, g_matmul_mode == 2);
+  GNM_CHECK_ARG(grid > 0, "ln_edge_bwd_chain: no kernel for this configuration");
+  GNM_LAUNCH_CHECK("ln_edge_bwd_chain");
+  hipLaunchKernelGGL(slab_reduce_k, dim3(FH * FH / 128), dim3(256), 0, st, (const float*)slab, grid, FH * FH, gW3_hi);
+  GNM_LAUNCH_CHECK("ln_edge_bwd_chain slab reduce");
+  *nblk_out = grid;
+  return gnm_reduce_partials(partials_hi, grid, 1, FH, gb3_hi, stream) ? -3 : 0;
+}
+
 extern "C" int gnm_edge_bwd_chain(int64_t N, int64_t E, int H, const float* ge, float* ge_out, const float* t_hi,
                                   const float* e_mid, const float* stat_hi, const float* bstat_hi, const float* gamma_hi,
                                   const float* W3_hi, float* gW3_hi, float* gb3_hi, double* partials_hi,

@@ -780,7 +780,9 @@ template <int ABL, bool SRC, bool WSKIP = true, bool HI = true, int HF = SW, boo
 __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   static_assert(HF == SW || !HI, "the chained (matrix) half of the kernel is built for 128-wide layers only");
   static_assert(HI || !H2, "f16x2 belongs to the matrix half");
-  static_assert(!LN || (!HI && SRC && HF == SW), "the LayerNorm sweep: no layer above, two-sided, 128 wide");
+  static_assert(!LN || (SRC && HF == SW), "the LayerNorm sweep: two-sided, 128 wide");
+  // LN && HI (the chained LayerNorm backward): layer i's gt is GIVEN -- t_hi points at the gt rows layer i's own sweep wrote a launch
+  // earlier (LayerNorm's gt needs no global statistics), stat_hi / bstat_hi / gamma_hi are not read -- and layer i-1's gt is written
   __shared__ __attribute__((aligned(16))) unsigned char lds[(SRC ? CH_LDS_SRC : CH_LDS) + (LN ? ER * SW * 4 : 0)];
   unsigned char* ig = lds;                                               // gt images
   unsigned char* ie = lds + 3 * EIMG;                                    // e_in(i) = e_out(i-1) images
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
   const int64_t ntile = (re - rb + ER - 1) / ER;
   const int row = tid >> 5, lc4 = (tid & 31) * 4;                        // this thread's row of every tile
   for (int c = tid; c < SW; c += CT) {
-    if constexpr (HI) {
+    if constexpr (HI && !LN) {
       cs[c] = a.stat_hi[c];
       cs[SW + c] = a.stat_hi[SW + c];
       cs[2 * SW + c] = a.stat_hi[2 * SW + c];
@@ -978,8 +980,13 @@ __global__ __launch_bounds__(CT, 2) void edge_bwd_chain_k(const ChainArgs a) {
       st4(tl + row * SW + lc4, pl);
       st4(ef + row * SW + lc4, pe_);                  // for the sigmoid of the by-destination pass (cheaper than re-joining the split images)
       if constexpr (HI) {
-        const float4 gu = gate4(fma4(pt, sc, sh), pg);
-        float4 gt = cc * (gu - m1 - ((pt - mu) * rs) * m2);
+        float4 gt;
+        if constexpr (LN) {
+          gt = pt;                                       // given (see the static_assert above)
+        } else {
+          const float4 gu = gate4(fma4(pt, sc, sh), pg);
+          gt = cc * (gu - m1 - ((pt - mu) * rs) * m2);
+        }
         if (row >= nvalid) gt = f4(0.f);               // rows past the chunk contribute nothing to gW3 / gb3
         cg0 += (double)gt.x; cg1 += (double)gt.y; cg2 += (double)gt.z; cg3 += (double)gt.w;
         if constexpr (H2) {
@@ -1381,6 +1388,12 @@ int edge_bwd_chain_launch(const ChainArgs& in, const float* W3, void* wpack, hip
     }
     if (a.sinfo) hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, false>), dim3(grid), dim3(CT), 0, st, a);
     else hipLaunchKernelGGL((edge_bwd_chain_k<0, false, true, false>), dim3(grid), dim3(CT), 0, st, a);
+    return grid;
+  }
+  if (a.ln_gamma) {                                  // the chained LayerNorm backward (two-sided only): layer i's gt given in t_hi
+    if (!a.sinfo || !a.gt_out || !a.ln_beta) return -1;
+    if (h2) hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, true, SW, true, true>), dim3(grid), dim3(CT), 0, st, a);
+    else hipLaunchKernelGGL((edge_bwd_chain_k<0, true, true, true, SW, false, true>), dim3(grid), dim3(CT), 0, st, a);
     return grid;
   }
   if (h2) {

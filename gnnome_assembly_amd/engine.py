@@ -1150,6 +1150,118 @@ def layers_backward_chained(idx, N: int, E: int, H: int, P: Dict[str, torch.Tens
     return gh, ge, grads
 
 
+def ln_chain_eligible(H: int, batch_norm: bool) -> bool:
+    """The chained LayerNorm backward (round 6): H = 128, split matmul modes, the two-sided LayerNorm sweep switched on."""
+    o = current()
+    return (not batch_norm) and o.CHAIN and o.FUSED and o.TWO_SIDED and o.LN_SWEEP and H == 128 and _lib.split_mode()
+
+
+def layers_backward_chained_ln(idx, N: int, E: int, H: int, P: Dict[str, torch.Tensor], L: int, saved: List[LayerSaved], gh, ge,
+                               outs: List[Optional[Dict[str, torch.Tensor]]], plan: dict, lnw: int):
+    """Backward of an L-layer LayerNorm stack (batch_norm=False), chained like layers_backward_chained.  LayerNorm has no global
+    statistics, so the schedule is shorter than BatchNorm's -- no finalisation between a layer's passes, no conversion of raw sums:
+        node(L-1), sweep(L-1) [+ fix];   then for i = L-1 .. 0:   nn(i), tn(i) [side stream],
+                                              i > 0:  node(i-1), CHAIN[fused(i) with gt(i) given + sweep(i-1)] [+ fix(i-1)]
+                                              i = 0:  fused(0) with gt(0) given
+    The sweep of layer i writes gt(i) once; the chained kernel of the next iteration reads it back as layer i's given gt (6 [E,H]
+    streams per layer where the layer-by-layer schedule moves 9).  Returns (gh_in of layer 0, ge_in of layer 0, [grads dict per layer])."""
+    lib = _lib.load()
+    dev = gh.device
+    sc, sc2 = scratch(dev), scratch(dev, "side")
+    st = _stream()
+    f32 = dict(dtype=torch.float32, device=dev)
+    grads: List[Dict[str, torch.Tensor]] = [dict() for _ in range(L)]
+    prms = [None] * L
+    need_f = lib.gnm_edge_bwd_fused_workspace_bytes()
+    need_p = lib.gnm_node_proj_bwd_workspace_bytes(5 * H)
+
+    def tgt(i, key, *shape):
+        o = outs[i] or {}
+        return o[key] if key in o else torch.empty(*shape, **f32)
+
+    def ensure(i):
+        if prms[i] is None:
+            prms[i] = layer_params(P, i)
+        s = saved[i]
+        _same_matmul_mode(s)
+        if s.P is None or s.t is None:      # "lean" activations
+            s.P, s.t = _proj_and_t(idx, N, E, H, prms[i], s.h_in, s.e_in, C.c_int(0))
+        return prms[i], s
+
+    def node(i, gh_out):
+        prm, s = ensure(i)
+        o = outs[i] or {}
+        gP = torch.empty(N, 5 * H, **f32)
+        Q = torch.empty(N, 4 * H, **f32)
+        nb = C.c_int(0)
+        _call("gnm_ln_node_bwd", N, H, _ptr(s.z), _ptr(prm.gamma_h), _ptr(prm.beta_h), _ptr(gh_out), _ptr(s.hf),
+              _ptr(s.inv_f), _ptr(s.hb), _ptr(s.inv_b), _ptr(gP), _ptr(Q), _ptr(sc.partials), C.byref(nb), lnw, st)
+        _, grads[i]["gamma_h"], grads[i]["beta_h"] = bn_bwd_finalize(sc.partials, nb.value, N, H, dev, o.get("gamma_h"), o.get("beta_h"))
+        return gP, Q
+
+    def fix_and_finalize(j, s_j, gt_j, Q_j, gP_j, nblk):
+        o = outs[j] or {}
+        _call("gnm_ln_edge_bwd_src_fix", plan["nfix"], _ptr(plan["fix_nodes"]), N, E, H, _ptr(s_j.e_out), _ptr(gt_j), _ptr(Q_j),
+              _ptr(idx["out_ptr"]), _ptr(idx["out_pos"]), _ptr(idx["out_dst"]), _ptr(gP_j), st)
+        _, grads[j]["gamma_e"], grads[j]["beta_e"] = bn_bwd_finalize(sc.partials, nblk.value, E, H, dev, o.get("gamma_e"), o.get("beta_e"))
+
+    i = L - 1
+    prm, s = ensure(i)
+    gP, Q = node(i, gh)
+    gt = torch.empty(E, H, **f32)
+    nblk = C.c_int(0)
+    ws = sc.ws(max(need_f, need_p))
+    _call("gnm_ln_edge_bwd_top", N, E, H, _ptr(ge), _ptr(s.e_out), _ptr(s.t), _ptr(prm.gamma_e), _ptr(prm.beta_e), lnw,
+          _ptr(s.P), _ptr(Q), _ptr(s.hf), _ptr(s.hb), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt),
+          _ptr(sc.partials), _ptr(plan["sinfo"]), plan["nodes_per_block"], C.byref(nblk), _ptr(ws), need_f, st)
+    fix_and_finalize(i, s, gt, Q, gP, nblk)
+    del Q
+    use_side = current().TN_SIDE and _prof is None and current().ACTIVATIONS != "lean"
+    while True:
+        prm, s = prms[i], saved[i]
+        g = grads[i]
+        g["W5"], g["b5"] = tgt(i, "W5", 5 * H, H), tgt(i, "b5", 5 * H)
+        gh_in = torch.empty(N, H, **f32)
+        ws = sc.ws(max(need_f, need_p))
+        _call("gnm_node_proj_bwd_nn", N, H, 5 * H, _ptr(gP), _ptr(prm.W5), _ptr(gh), _ptr(gh_in), _ptr(ws), need_p, st)
+        if use_side:
+            side = side_begin(dev)
+            sc3 = scratch(dev, "tn")
+            ws3 = sc3.ws(need_p)
+            _lib.check(lib.gnm_node_proj_bwd_tn(N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc3.partials),
+                                                _ptr(ws3), need_p, current().TN_SIDE_CAP, C.c_void_p(side.cuda_stream)), "gnm_node_proj_bwd_tn")
+            _side_held[torch.device(dev)].extend((gP, s.h_in, g["W5"], g["b5"]))
+        else:
+            _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]), _ptr(sc.partials), _ptr(ws),
+                  need_p, 0, st)
+        del gP
+        gh = gh_in
+        g["W3"], g["b3"] = tgt(i, "W3", H, H), tgt(i, "b3", H)
+        if i == 0:
+            _call("gnm_edge_bwd_fused_gt", E, H, _ptr(ge), _ptr(ge), _ptr(gt), _ptr(s.e_in), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]),
+                  _ptr(sc.partials), _ptr(ws), need_f, st)
+            saved[0] = None
+            side_drain(dev)
+            break
+        j = i - 1
+        prm_j, s_j = ensure(j)
+        gP, Q = node(j, gh)
+        gt_j = torch.empty(E, H, **f32)
+        ws = sc.ws(max(need_f, need_p))
+        _call("gnm_ln_edge_bwd_chain", N, E, H, _ptr(ge), _ptr(gt), _ptr(s.e_in), _ptr(prm.W3), _ptr(g["W3"]), _ptr(g["b3"]),
+              _ptr(sc2.partials), _ptr(s_j.t), _ptr(prm_j.gamma_e), _ptr(prm_j.beta_e), lnw, _ptr(s_j.P), _ptr(Q), _ptr(s_j.hf),
+              _ptr(s_j.hb), _ptr(idx["isrc"]), _ptr(idx["idst"]), _ptr(idx["in_ptr"]), _ptr(gP), _ptr(gt_j), _ptr(sc.partials),
+              _ptr(plan["sinfo"]), plan["nodes_per_block"], C.byref(nblk), _ptr(ws), need_f, st)
+        fix_and_finalize(j, s_j, gt_j, Q, gP, nblk)
+        del Q
+        saved[i] = None         # release layer i's activations
+        if current().ACTIVATIONS == "lean":
+            s_j.P = None
+        gt = gt_j
+        i = j
+    return gh, ge, grads
+
+
 # ---------------------------------------------------------------------------------------
 # predictor (score_predictor.py:12-25), split-W1 form
 # ---------------------------------------------------------------------------------------
@@ -1394,6 +1506,9 @@ def model_backward(graph, P: Dict[str, torch.Tensor], num_layers: int, ms: Model
     if chain_eligible(H, batch_norm):
         plan = graph.sweep_plan(dev) if current().TWO_SIDED and hasattr(graph, "sweep_plan") else None
         gh, ge, chained = layers_backward_chained(idx, N, E, H, P, num_layers, ms.layers, gh, ge, louts, plan)
+    elif ln_chain_eligible(H, batch_norm) and plan_w is not None:
+        gh, ge, chained = layers_backward_chained_ln(idx, N, E, H, P, num_layers, ms.layers, gh, ge, louts, plan_w,
+                                                     H if ln_width is None else int(ln_width))
     for i in reversed(range(num_layers)):
         p = f"gnn.convs.{i}."
         lout = louts[i]

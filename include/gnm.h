@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNM_ABI_VERSION 7   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed, gnm_ln_edge_gate2_fwd; 7: gnm_edge_bwd_fused_gt (gt given: the LayerNorm backward's fused edge pass), gnm_ln_edge_bwd_top / gnm_ln_edge_bwd_src_fix (its two-sided sweep), gnm_debug_set_variant("gate2_wg") */
+#define GNM_ABI_VERSION 7   /* 2: per-call max_blocks_per_cu (edge_bwd_src, node_proj_bwd_tn), locality order; 3: sweep plans, two-sided sweeps; 4: H = 256 fused kernels; 5: LayerNorm entry points take the real width, node_bgrad its row pitch, fused node-side entry points, composite layer entry points; 6: matmul mode 2 (f16x2, the default), the pre-split image entry points (gnm_*_s3) and the Bs argument of gnm_tn128_bgrad removed, gnm_ln_edge_gate2_fwd; 7: gnm_edge_bwd_fused_gt (gt given: the LayerNorm backward's fused edge pass), gnm_ln_edge_bwd_top / gnm_ln_edge_bwd_src_fix (its two-sided sweep), gnm_ln_edge_bwd_chain (its chained form), gnm_debug_set_variant("gate2_wg") */
 
 /* GEMM operand modes: C[M,N] = op(A) * op(B) (+bias +resid, relu) */
 #define GNM_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major  : y = x W^T   (nn.Linear forward)   */
@@ -287,6 +287,15 @@ int gnm_ln_edge_bwd_top(int64_t N, int64_t E, int H, float* ge, const float* e_o
 int gnm_ln_edge_bwd_src_fix(int64_t nfix, const int32_t* fix_nodes, int64_t N, int64_t E, int H, const float* e_out,
                             const float* gt, const float* Q, const int32_t* out_ptr, const int32_t* out_pos,
                             const int32_t* out_dst, float* gP, void* stream);
+/* The chained form (split matmul modes): gnm_edge_bwd_fused_gt of layer i (gt_hi: the gt layer i's own sweep wrote) AND gnm_ln_edge_bwd_top of
+ * layer i-1 in one sweep: ge (in place) holds d loss / d e_out(i) on entry and ge_tot(i-1) on exit, gt_lo receives layer i-1's gt; gW3_hi / gb3_hi
+ * the B_3 gradients of layer i.  partials_hi [grid][128] and partials_lo [grid][2][128] must differ.      train.py:257 under nn.LayerNorm */
+int gnm_ln_edge_bwd_chain(int64_t N, int64_t E, int H, float* ge, const float* gt_hi, const float* e_mid, const float* W3_hi,
+                          float* gW3_hi, float* gb3_hi, double* partials_hi, const float* t_lo, const float* gamma_lo,
+                          const float* beta_lo, int width, const float* P_lo, const float* Q_lo, const float* hf_lo,
+                          const float* hb_lo, const int32_t* isrc, const int32_t* idst, const int32_t* in_ptr, float* gP_lo,
+                          float* gt_lo, double* partials_lo, const uint32_t* sinfo, int64_t plan_nodes_per_block,
+                          int* nblk_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- fused W-stationary MFMA kernels (H = 128 only; other H use the unfused entry points) ---
  * edge_t_fused_fwd: t = e_in W3^T + b3 + B1h[isrc] + B2h[idst] and the BatchNorm partials in ONE

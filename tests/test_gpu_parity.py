@@ -1718,8 +1718,8 @@ def test_layernorm_two_sided_backward_sweep_matches_the_separate_passes(ids):
         crit = G.BCEWithLogitsLoss(float(inp["pos_weight"]))
         assert g.sweep_plan(dev, 1) is not None
 
-        def run(sweep):
-            with engine.options(LN_SWEEP=sweep):
+        def run(sweep, chain=True):
+            with engine.options(LN_SWEEP=sweep, CHAIN=chain):
                 model.zero_grad(set_to_none=True)
                 s = model(g, None, e, pe)
                 loss = crit(s.squeeze(-1), y)
@@ -1727,19 +1727,23 @@ def test_layernorm_two_sided_backward_sweep_matches_the_separate_passes(ids):
                 torch.cuda.synchronize()
                 return s.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters()}
         s0, g0 = run(False)
-        s1, g1 = run(True)
-        s2, g2 = run(True)
-        assert torch.equal(s0, s1) and torch.equal(s1, s2), "the forward does not depend on the backward's schedule"
+        s1, g1 = run(True, chain=False)         # the sweep, layer by layer (gnm_ln_edge_bwd_top + gnm_edge_bwd_fused_gt)
+        s2, g2 = run(True, chain=False)
+        s3, g3 = run(True)                      # the chained schedule (gnm_ln_edge_bwd_chain: fused(i) with gt given + sweep(i-1))
+        s4, g4 = run(True)
+        assert torch.equal(s0, s1) and torch.equal(s1, s2) and torch.equal(s2, s3), "the forward does not depend on the backward's schedule"
         assert all(torch.equal(g1[k], g2[k]) for k in g1), "the sweep is not run-to-run deterministic"
+        assert all(torch.equal(g3[k], g4[k]) for k in g3), "the chained LayerNorm backward is not run-to-run deterministic"
         gmax = max(float(v.abs().max()) for v in g0.values())
-        worst = 0.0
-        for k in g0:
-            a, b = g1[k].double(), g0[k].double()
-            rr = float((a - b).norm() / b.norm().clamp_min(1e-30))
-            ok = rr <= 1e-5 or float((a - b).abs().max()) <= 1e-6 * gmax
-            worst = max(worst, rr if float(b.norm()) > 1e-6 * gmax else 0.0)
-            assert ok, (H, k, rr, float((a - b).abs().max()), gmax)
-        print(f"LayerNorm two-sided backward sweep vs separate passes [{ids}, H = {H}]: worst gradient rel_l2 = {worst:.2e}")
+        for what, gx in (("sweep", g1), ("chained", g3)):
+            worst = 0.0
+            for k in g0:
+                a, b = gx[k].double(), g0[k].double()
+                rr = float((a - b).norm() / b.norm().clamp_min(1e-30))
+                ok = rr <= 1e-5 or float((a - b).abs().max()) <= 1e-6 * gmax
+                worst = max(worst, rr if float(b.norm()) > 1e-6 * gmax else 0.0)
+                assert ok, (what, H, k, rr, float((a - b).abs().max()), gmax)
+            print(f"LayerNorm backward, {what} vs separate passes [{ids}, H = {H}]: worst gradient rel_l2 = {worst:.2e}")
 
 
 @pytest.mark.default_mode_only
