@@ -31,7 +31,9 @@ __device__ __forceinline__ float row_sum(float v) {
     typedef unsigned u32x2_ln_ __attribute__((ext_vector_type(2)));
     const unsigned b = __builtin_bit_cast(unsigned, v);
     const u32x2_ln_ sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);     // (rows 0 0 2 2, rows 1 1 3 3)
-    v = __builtin_bit_cast(float, sw.x) + __builtin_bit_cast(float, sw.y);
+    // (the elements go through scalars first: __builtin_bit_cast applied to sw.x / sw.y directly makes hipcc 7.2 read element 0 twice)
+    const unsigned lo_ = sw.x, hi_ = sw.y;
+    v = __uint_as_float(lo_) + __uint_as_float(hi_);
   }
   if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;

@@ -421,6 +421,32 @@ def test_fused_bce_matches_torch():
 # -----------------------------------------------------------------------------------------
 
 @pytest.mark.mode_independent
+@pytest.mark.parametrize("H,width", [(32, 32), (32, 20), (64, 64), (64, 48), (128, 128), (128, 96), (256, 256), (256, 200)])
+def test_layernorm_row_statistics_at_every_kernel_width(H, width):
+    """The row sums of the LayerNorm kernels (gnm_ln.h row_sum: DPP adds inside a 16-lane row, v_permlane16_swap across the two rows of a
+    32-lane group, one shuffle across the halves of a wave) at every kernel width and at a zero-padded real width, through
+    gnm_ln_node_update_fwd against numpy in fp64.  (Round 6: the first DPP version read one half of the swap twice at 32 and 64 lanes
+    per row -- a 10 % error the schedule-against-schedule tests could not see; this one does.)"""
+    import ctypes as C
+    from gnnome_assembly_amd import engine
+    dev = _dev()
+    rng = np.random.default_rng(H + width)
+    N = 1003
+    z = rng.standard_normal((N, H)).astype(np.float32) * np.exp(rng.uniform(-3, 3, (N, 1))).astype(np.float32)
+    z[:, width:] = 0
+    ga = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    zt, gt, bt = (torch.from_numpy(a).to(dev) for a in (z, ga, be))
+    out = torch.empty(N, H, device=dev)
+    engine._call("gnm_ln_node_update_fwd", N, H, engine._ptr(zt), engine._ptr(gt), engine._ptr(bt), C.c_void_p(0), engine._ptr(out), width,
+                 engine._stream())
+    torch.cuda.synchronize()
+    zz = z[:, :width].astype(np.float64)
+    ref = np.maximum((zz - zz.mean(1, keepdims=True)) / np.sqrt(zz.var(1, keepdims=True) + 1e-5) * ga[:width] + be[:width], 0)
+    assert rel_l2(out.cpu().numpy()[:, :width], ref) <= 5e-7
+
+
+@pytest.mark.mode_independent
 def test_standalone_layer_dropout():
     """gated_gcn_full.py:154: dropout on the node output after the residual, training mode only (never enabled by the
     model).  Kept elements are the p = 0 output scaled by 1/(1-p), e is untouched, eval mode is the p = 0 output."""
