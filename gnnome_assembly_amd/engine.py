@@ -275,6 +275,21 @@ def side_begin(device):
     return side
 
 
+def tn_on_side(device, A, B, C_, out, first: bool) -> None:
+    """gemm_tn_colsum(A, B, C_, out) on the side stream of `device` (a weight gradient: no consumer before the optimizer step), its
+    operands held until the main stream has waited for it.  first: the first deferred launch since the main stream last waited
+    (side_begin); a further one only makes the side stream wait for the main stream's work so far."""
+    device = torch.device(device)
+    if first:
+        side = side_begin(device)
+    else:
+        side = _side_stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        gemm_tn_colsum(A, B, C_, out, sc_key="tn")
+    _side_held[device].extend((A, B, C_, out))
+
+
 def side_drain(device) -> None:
     """The main stream waits for the side stream's work (layer_backward(..., defer_tn=True)); the held tensors are released."""
     device = torch.device(device)
@@ -318,9 +333,11 @@ def gemm(mode: int, A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, bias=Non
 
 
 @on_device_of(lambda A, *a, **k: A)
-def gemm_tn_colsum(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_tn_colsum(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, out: Optional[torch.Tensor] = None,
+                   sc_key: str = "main") -> torch.Tensor:
     """C = A^T B and the column sums of A (weight and bias gradient of a Linear: A = grad of its output [rows, out],
-    B = its input [rows, in]); returns the column sums."""
+    B = its input [rows, in]); returns the column sums.  sc_key: which scratch workspace the call uses (a launch on the side
+    stream must not share the main stream's)."""
     lib = _lib.load()
     _chk_dev(A, B, C_, out)
     for t in (A, B, C_):
@@ -333,7 +350,7 @@ def gemm_tn_colsum(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, out: Opti
     if out is None:
         out = torch.empty(M, dtype=torch.float32, device=A.device)
     need = lib.gnm_gemm_tn_colsum_workspace_bytes(M, N, K)
-    ws = scratch(A.device).ws(need) if need else None
+    ws = scratch(A.device, sc_key).ws(need) if need else None
     _call("gnm_gemm_tn_colsum", M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_), C_.stride(0), _ptr(out),
           _ptr(ws), need, _stream(), tag=f"gemm_TN+colsum[{M}x{N}x{K}]" if _prof is not None else None)
     return out
@@ -723,6 +740,10 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
     Hin = s.h_in.shape[1]
     lnw = H if ln_width is None else int(ln_width)
     fused = H == 128 and current().FUSED and residual          # the fused backward kernels have the residual adds built in
+    # the two weight-gradient GEMMs of a 256-wide layer on the side stream (model_backward drains): see tn_on_side
+    defer_side = (defer_tn and H == 256 and batch_norm and current().TN_SIDE and _prof is None and current().ACTIVATIONS != "lean"
+                  and _lib.split_mode())
+    deferred_first = True
     new = lambda key, *shape: out[key] if key in out else torch.empty(*shape, dtype=torch.float32, device=gh_out.device)  # noqa: E731
     lib = _lib.load()
     dev = gh_out.device
@@ -798,7 +819,12 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             _call("gnm_edge_bwd_gt_nn", E, H, _ptr(ge), _ptr(s.t), _ptr(s.stat_e), _ptr(bstat_e), _ptr(prm.gamma_e),
                   _ptr(prm.W3), _ptr(gt), _ptr(ge_in), _ptr(ws), need, st)
             ge = ge_in
-            g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
+            if defer_side:          # round 6: beside the next layer's HBM-bound sweep instead of in front of it
+                g["b3"] = new("b3", H)
+                tn_on_side(dev, gt, s.e_in, g["W3"], g["b3"], first=True)
+                deferred_first = False
+            else:
+                g["b3"] = gemm_tn_colsum(gt, s.e_in, g["W3"], out.get("b3"))
             del gt
         else:
             gt = torch.empty(E, H, **f32)
@@ -831,8 +857,12 @@ def layer_backward(idx, N: int, E: int, H: int, prm: LayerParams, s: LayerSaved,
             _call("gnm_node_proj_bwd_tn", N, H, 5 * H, _ptr(gP), _ptr(s.h_in), _ptr(g["W5"]), _ptr(g["b5"]),
                   _ptr(sc.partials), _ptr(ws), need, 0, st)
     else:
-        g["b5"] = gemm_tn_colsum(gP, s.h_in, g["W5"], out.get("b5"))
         gemm(NN, gP, prm.W5, gh_in, resid=gh_out if residual else None)
+        if defer_side:
+            g["b5"] = new("b5", 5 * H)
+            tn_on_side(dev, gP, s.h_in, g["W5"], g["b5"], first=deferred_first)
+        else:
+            g["b5"] = gemm_tn_colsum(gP, s.h_in, g["W5"], out.get("b5"))
     return gh_in, ge, g
 
 
