@@ -22,8 +22,12 @@ KERNEL_WIDTHS = (32, 64, 128, 256)      # the hidden sizes the row kernels are i
 # separate by-destination / by-source passes), and at the metric's graph that is SLOWER than the same model zero-padded to 128 on the
 # fused kernels, the two-sided sweeps and the chained backward -- 222 against ~160 ms per step at L = 8, 50.7 against ~31 at
 # BASELINE config 1's H = 64 / L = 1 (profiles/r06_h64_padded.txt) -- although the padded model moves twice the bytes.  32-wide layers
-# stay native (141 ms).  GNM_NATIVE_64=1 / layers.RUN_WIDTHS = KERNEL_WIDTHS: the 64-wide kernels again (they stay built and tested).
+# stay native (141 against 144-145 ms at L = 8; a quarter of the memory).  GNM_NATIVE_64=1 / layers.RUN_WIDTHS = KERNEL_WIDTHS: the 64-wide kernels again (they stay built and tested).
 RUN_WIDTHS = KERNEL_WIDTHS if os.environ.get("GNM_NATIVE_64", "0") == "1" else (32, 128, 256)
+if os.environ.get("GNM_RUN_WIDTHS"):        # e.g. GNM_RUN_WIDTHS=128,256 (A/B runs): any subset of KERNEL_WIDTHS
+    RUN_WIDTHS = tuple(sorted(int(w) for w in os.environ["GNM_RUN_WIDTHS"].split(",")))
+    if not RUN_WIDTHS or any(w not in KERNEL_WIDTHS for w in RUN_WIDTHS):
+        raise ValueError(f"GNM_RUN_WIDTHS={os.environ['GNM_RUN_WIDTHS']!r}: expected a subset of {KERNEL_WIDTHS}")
 
 
 def padded_width(width: int) -> int:
