@@ -505,6 +505,10 @@ def main():
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "algorithmic_bytes_per_edge_step": per_edge,
                 "traffic": step_traffic, "traffic_source": traffic_src,
+                "rocprof_tables": "profiles/r06_kernel_stats_serial.csv (rocprofv3 --kernel-trace --stats of this command with GNM_TN_SIDE=0: one stream, "
+                                  "as the per-op HIP-event step below runs -- its average durations are the ones that agree with avg_launch_ms and sum to "
+                                  "the step); profiles/r06_kernel_stats.csv (the two-stream schedule `value` is measured on: a kernel that waits for CUs "
+                                  "beside the side-stream weight gradient shows the wait as its duration)",
                 "kernels": kernels, "dominant_kernel": kernels[0] if kernels else None}
         if kernels:     # scalars: a parser that keeps only scalar fields still has the kernel-level roofline
             k0 = kernels[0]
